@@ -1,0 +1,230 @@
+/*
+ * pais_oracle.h -- CPU restatement of the pais-mvs refine/expansion hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked into, imported by
+ * or executed from the product (pais_mvs_amd/, include/).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and
+ * there only as the checker / reported CPU baseline.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/TMVS/).  Plain C99, double precision throughout, same
+ * evaluation order, same tie-breaks as the reference.
+ *
+ * PARITY PINNING STATUS
+ *   - PSO solver (pso/psosolver.cpp, pso/particle.cpp): PINNED.  The
+ *     reference's own two source files compile unmodified with g++ and are
+ *     built into oracle/_ref/libpso_ref.so (oracle/Makefile); the golden
+ *     traces in tests/golden/pso_*.json were produced by that library and the
+ *     restatement in po_pso_run() reproduces them bit-for-bit.
+ *   - Everything that touches OpenCV types (mvs/patch.cpp, mvs/mvs.cpp,
+ *     mvs/camera.cpp): PARITY UNPINNED.  The reference needs OpenCV 2.4.2
+ *     (TMVS.vcxproj:148) which is not in this image and may not be stood in
+ *     for, the reference ships no tests/golden vectors,
+ *     so these functions restate the source line by line plus the published
+ *     OpenCV 2.4 algorithms they call (cv::invert 3x3, cv::fitEllipse,
+ *     cvRound, gemm summation order) and are anchored on the reference's own
+ *     call sites only.
+ */
+#ifndef PAIS_ORACLE_H
+#define PAIS_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PO_MAX_LEVELS 16   /* LOD 0..15 (config maxLOD default 15, TMVS.cpp:42) */
+#define PO_MAX_VIS    64   /* max visible cameras tracked per patch             */
+
+#define PO_TYPE_SEED   0   /* patch.h:17 */
+#define PO_TYPE_EXPAND 1   /* patch.h:18 */
+
+/* mvs/mvs.h:19-72 (field meaning identical; bools widened to int) */
+typedef struct po_config {
+    int    cellSize;
+    int    patchRadius;
+    int    patchSize;
+    int    minCamNum;
+    double textureVariation;
+    double visibleCorrelation;
+    double minCorrelation;
+    double maxFitness;
+    double lodRatio;
+    int    minLOD;
+    int    maxLOD;
+    int    maxCellPatchNum;
+    double reduceNormalRange;
+    int    adaptiveDistanceEnable;
+    int    adaptiveDifferenceEnable;
+    int    adaptiveGradientEnable;
+    double distWeighting;
+    double diffWeighting;
+    double gradientWeighting;
+    double neighborRadius;
+    double neighborRadiusScalar;
+    double minRegionRatio;
+    double depthRangeScalar;
+    int    particleNum;
+    int    maxIteration;
+    int    expansionStrategy;
+} po_config;
+
+/* mvs/camera.h:15-149 -- the data the hot path reads */
+typedef struct po_camera {
+    double focal[2];
+    double pp[2];            /* principle point                         */
+    double R[9];             /* rotation, row-major                     */
+    double T[3];             /* translation = -R*C   (camera.cpp:120)   */
+    double C[3];             /* centre                                  */
+    double KR[9];            /* camera.cpp:123                          */
+    double KT[3];            /* camera.cpp:124                          */
+    double optN[3];          /* optical normal = R^T e_z (camera.cpp:132) */
+    int    maxLOD;           /* camera.cpp:63-64                        */
+    int    width[PO_MAX_LEVELS];
+    int    height[PO_MAX_LEVELS];
+    const uint8_t *img[PO_MAX_LEVELS];   /* gray pyramid, row-major, stride = width */
+    const double  *edge[PO_MAX_LEVELS];  /* normalised Sobel magnitude pyramid (may be NULL if grad weighting off) */
+} po_camera;
+
+typedef struct po_scene {
+    po_config  cfg;
+    int        numCams;
+    po_camera *cams;
+    double    *gauss;                    /* patchDistWeight, S*S, mvs.cpp:97-114 */
+    double     lodScale[PO_MAX_LEVELS];  /* pow(lodRatio, LOD) */
+    uint64_t   seed;                     /* PSO stream seed */
+    int        ompParticles;             /* 1: OpenMP over particles (reference structure) */
+} po_scene;
+
+/* mvs/abstractpatch.h:22-53 + patch.h:19-20 */
+typedef struct po_patch {
+    int      id;
+    int      type;
+    int      drop;
+    int      expanded;
+    double   center[3];
+    int      numCam;
+    int      camIdx[PO_MAX_VIS];
+    int      refCamIdx;
+    double   normalS[2];
+    double   normal[3];
+    double   ray[3];
+    double   depth;
+    double   depthRange[2];
+    int      LOD;
+    double   imgPoint[PO_MAX_VIS][2];
+    double   fitness;
+    double   priority;
+    double   correlation;
+    double   corrTable[PO_MAX_VIS * PO_MAX_VIS];
+    /* deterministic-stream bookkeeping (not in the reference) */
+    uint64_t key;        /* schedule-independent candidate key */
+    int      psoRuns;    /* number of psoOptimization() calls so far  */
+    int      psoIters;   /* sum of PsoSolver::getIteration()          */
+    int      psoEvals;   /* number of getFitness calls                */
+} po_patch;
+
+/* ---- deterministic uniform stream (replaces rand()/srand(time)) */
+uint32_t po_rand31(uint64_t seed, uint64_t key, uint32_t run, uint32_t k);
+uint64_t po_child_key(uint64_t parentKey, int cam, int cx, int cy);
+
+/* ---- scene ------------------------------------------------------------- */
+void po_config_defaults(po_config *c);              /* TMVS.cpp:26-52            */
+void po_config_readme(po_config *c);                /* README.md:110-207         */
+void po_camera_init(po_camera *cam, const double focal[2], const double pp[2],
+                    const double quat[4], const double center[3]); /* camera.cpp:6-35,108-133 */
+int  po_camera_max_lod(int width, int height, double lodRatio, int cfgMaxLOD); /* camera.cpp:63-64 */
+po_scene *po_scene_create(const po_config *cfg, int numCams, const po_camera *cams, uint64_t seed);
+void po_scene_destroy(po_scene *s);
+void po_init_gauss(const po_config *cfg, double *out);   /* mvs.cpp:97-114 */
+
+/* ---- geometry ---------------------------------------------------------- */
+void po_spherical2normal(const double s[2], double n[3]);   /* utility.h:25-29 */
+void po_normal2spherical(const double n[3], double s[2]);   /* utility.h:17-22 */
+int  po_project(const po_scene *s, int cam, const double X[3], double out[2], int LOD); /* camera.cpp:138-160 */
+int  po_inv3(const double m[9], double out[9]);             /* OpenCV 2.4 cv::invert 3x3 */
+void po_homographies(const po_scene *s, const po_patch *p, const double center[3],
+                     const double normal[3], double *H /* numCam*9 */); /* patch.cpp:290-330 */
+double po_region_ratio(const po_scene *s, const double pt[2], const double H[9]); /* patch.cpp:269-288 */
+void po_fit_ellipse(int n, const float *xy, float *cx, float *cy, float *w, float *h, float *angle); /* OpenCV 2.4 */
+
+/* ---- cost -------------------------------------------------------------- */
+double po_get_fitness(const po_scene *s, const po_patch *p, const double pos[3]); /* patch.cpp:914-1047 */
+
+/* ---- PSO (pso/psosolver.cpp) ------------------------------------------ */
+typedef double (*po_fitness_fn)(const double *pos, void *obj);
+typedef uint32_t (*po_rand_fn)(void *rngObj);   /* next 31-bit draw */
+typedef struct po_pso_result {
+    double gBest[3];
+    double gBestFitness;
+    int    iterations;
+    int    evals;
+} po_pso_result;
+/* trace (optional): per iteration, per particle: pos[3] vec[3] pBest[3] fitness pBestFitness, then gIdx, iw */
+void po_pso_run(int dim, const double *rangeL, const double *rangeU,
+                po_fitness_fn fn, void *obj, int maxIteration, int particleNum,
+                const double *init, po_rand_fn rnd, void *rngObj, int omp,
+                po_pso_result *res, double *trace, int traceCap, int *traceLen);
+
+/* exported callbacks so the compiled reference PsoSolver (oracle/_ref) can be
+ * driven with the restated cost and the deterministic stream */
+typedef struct po_fit_ctx { const po_scene *s; const po_patch *p; } po_fit_ctx;
+typedef struct po_rng_ctx { uint64_t seed, key; uint32_t run, k; } po_rng_ctx;
+double   po_fit_cb(const double *pos, void *obj /* po_fit_ctx* */);
+uint32_t po_rng_cb(void *obj /* po_rng_ctx* */);
+
+/* ---- patch state machine (mvs/patch.cpp) ------------------------------ */
+void po_patch_init_seed(const po_scene *s, po_patch *p, const double center[3],
+                        int numCam, const int *camIdx, uint64_t key);        /* patch.cpp:26-34 */
+void po_patch_init_expand(const po_scene *s, po_patch *p, const double center[3],
+                          const double parentNormal[3], int parentNumCam,
+                          const int *parentCamIdx, uint64_t key);            /* patch.cpp:36-43 */
+void po_set_estimated_normal(const po_scene *s, po_patch *p);   /* patch.cpp:390-413 */
+void po_set_reference_camera(const po_scene *s, po_patch *p);   /* patch.cpp:415-445 */
+void po_set_depth_and_ray(const po_scene *s, po_patch *p);      /* patch.cpp:447-461 */
+void po_set_depth_range(const po_scene *s, po_patch *p);        /* patch.cpp:463-509 */
+void po_set_lod(const po_scene *s, po_patch *p);                /* patch.cpp:511-610 */
+void po_set_priority(const po_scene *s, po_patch *p);           /* patch.cpp:612-625 */
+void po_set_image_point(const po_scene *s, po_patch *p);        /* patch.cpp:627-653 */
+void po_pso_optimization(const po_scene *s, po_patch *p);       /* patch.cpp:180-219 */
+void po_set_correlation_table(const po_scene *s, po_patch *p, const double *H); /* patch.cpp:221-267 */
+void po_remove_invisible_camera(const po_scene *s, po_patch *p); /* patch.cpp:655-721 */
+void po_expand_visible_camera(const po_scene *s, po_patch *p);   /* patch.cpp:723-761 */
+void po_refine(const po_scene *s, po_patch *p);                  /* patch.cpp:114-176 */
+int  po_is_neighbor(const po_scene *s, const po_patch *a, const po_patch *b); /* patch.cpp:6-23 */
+
+/* ---- expansion loop (mvs/mvs.cpp) ------------------------------------- */
+typedef struct po_mvs po_mvs;
+po_mvs *po_mvs_create(po_scene *s);
+void    po_mvs_destroy(po_mvs *m);
+int     po_mvs_add_seed(po_mvs *m, const double center[3], int numCam, const int *camIdx); /* returns id */
+void    po_mvs_set_neighbor_radius(po_mvs *m);          /* mvs.cpp:147-152, 974-997 */
+void    po_mvs_refine_seed_patches(po_mvs *m);          /* mvs.cpp:196-231 */
+/* Round-based expansion R(B): pop B parents, then process them
+ * sequentially exactly as mvs.cpp:243-272 does.  B=1 is the reference loop.
+ * maxRounds<=0: run to convergence.  Returns number of refine() calls made. */
+long    po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail);
+int     po_mvs_num_patches(const po_mvs *m);
+int     po_mvs_num_slots(const po_mvs *m);              /* ids are 0..slots-1 */
+const po_patch *po_mvs_get_patch(const po_mvs *m, int id); /* NULL if deleted */
+long    po_mvs_refine_calls(const po_mvs *m);
+long    po_mvs_fitness_evals(const po_mvs *m);
+int     po_runtime_filtering(const po_mvs *m, const po_patch *p);   /* mvs.cpp:838-898 */
+void    po_expansion_center(const po_scene *s, int cam, const po_patch *parent, int cx, int cy, double out[3]); /* mvs.cpp:809-836 */
+/* single-candidate helper for per-candidate parity: constructs + refines +
+ * removeInvisibleCamera exactly as MVS::expandCell (mvs.cpp:566-577) */
+void    po_expand_candidate(const po_scene *s, po_patch *out, const double center[3],
+                            const double parentNormal[3], int parentNumCam,
+                            const int *parentCamIdx, uint64_t key);
+void    po_refine_seed(const po_scene *s, po_patch *p);  /* refine + removeInvisibleCamera, mvs.cpp:214-215 */
+
+size_t  po_sizeof_patch(void);
+size_t  po_sizeof_config(void);
+size_t  po_sizeof_camera(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
