@@ -1,0 +1,219 @@
+/*
+ * pais_hip.h -- C ABI of the MI355X-native PAIS-MVS refine/expansion hot path.
+ *
+ * This is the drop-in boundary.
+ * The reference has no FFI layer; the seams this library replaces are
+ *
+ *   - the C-style cost callback  double (*getFitness)(const Particle&, void*)
+ *     bound at  TMVS/mvs/patch.cpp:192,199  (declared pso/psosolver.h:72)
+ *       -> pais_fitness_batch()
+ *   - Patch::refine() + Patch::removeInvisibleCamera() as called from
+ *     MVS::refineSeedPatches (TMVS/mvs/mvs.cpp:214-215) and MVS::expandCell
+ *     (TMVS/mvs/mvs.cpp:573-574)
+ *       -> pais_refine_batch()
+ *   - the scene state those read through the MVS singleton
+ *     (TMVS/mvs/mvs.h:84-94,196-223; TMVS/mvs/camera.h:79-106)
+ *       -> pais_ctx_create() / pais_ctx_set_config() / pais_ctx_set_neighbor_radius()
+ *
+ * Conventions: plain C, POD structs, double precision, caller owns every
+ * buffer, the library keeps no pointer past a call (scene data is copied to
+ * the GPU in pais_ctx_create).  Functions return 0 on success, <0 on argument
+ * / HIP failure (text via pais_last_error()).  Numerical invalidity stays
+ * in-band exactly as in the reference: DBL_MAX fitness (patch.cpp:940,953,
+ * 961,1001), NaN passthrough, `dropped` flag (patch.cpp:119-122).
+ *
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ */
+#ifndef PAIS_HIP_H
+#define PAIS_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAIS_MAX_LEVELS 16  /* LOD 0..15; MvsConfig::maxLOD <= 15 (TMVS.cpp:42) */
+#define PAIS_MAX_VIS    64  /* visible cameras tracked per patch (camIdx)      */
+#define PAIS_MAX_PARTICLES 128 /* 2*particleNum for seeds must fit             */
+
+#define PAIS_TYPE_SEED   0  /* Patch::TYPE_SEED,   mvs/patch.h:17 */
+#define PAIS_TYPE_EXPAND 1  /* Patch::TYPE_EXPAND, mvs/patch.h:18 */
+
+/* PAIS::MvsConfig, TMVS/mvs/mvs.h:19-72 (same fields, same meaning; the three
+ * bools are widened to int32 so the struct has no padding surprises). */
+typedef struct pais_config {
+    int32_t cellSize;
+    int32_t patchRadius;
+    int32_t patchSize;              /* ignored on input: always 2*patchRadius+1 (mvs.cpp:67) */
+    int32_t minCamNum;
+    double  textureVariation;
+    double  visibleCorrelation;
+    double  minCorrelation;
+    double  maxFitness;
+    double  lodRatio;
+    int32_t minLOD;
+    int32_t maxLOD;
+    int32_t maxCellPatchNum;
+    int32_t _pad0;
+    double  reduceNormalRange;
+    int32_t adaptiveDistanceEnable;
+    int32_t adaptiveDifferenceEnable;
+    int32_t adaptiveGradientEnable;
+    int32_t _pad1;
+    double  distWeighting;
+    double  diffWeighting;
+    double  gradientWeighting;
+    double  neighborRadius;
+    double  neighborRadiusScalar;
+    double  minRegionRatio;
+    double  depthRangeScalar;
+    int32_t particleNum;
+    int32_t maxIteration;
+    int32_t expansionStrategy;
+    int32_t _pad2;
+} pais_config;
+
+/* What the hot path reads from PAIS::Camera (TMVS/mvs/camera.h:79-106).  The
+ * caller passes the reference's own matrices and pyramid buffers; nothing is
+ * recomputed here. */
+typedef struct pais_camera_desc {
+    double focal[2];             /* getFocalLength()                        */
+    double principle_point[2];   /* getPrinciplePoint()                     */
+    double rotation[9];          /* getRotation(), row-major 3x3            */
+    double translation[3];       /* getTranslation()                        */
+    double center[3];            /* getCenter()                             */
+    double KR[9];                /* getKR()                                 */
+    double KT[3];                /* getKT()                                 */
+    double optical_normal[3];    /* getOpticalNormal()                      */
+    int32_t max_lod;             /* getMaxLOD()                             */
+    int32_t _pad;
+    int32_t level_width[PAIS_MAX_LEVELS];    /* getPyramidImage(l).cols     */
+    int32_t level_height[PAIS_MAX_LEVELS];   /* getPyramidImage(l).rows     */
+    int64_t level_stride[PAIS_MAX_LEVELS];   /* Mat::step in bytes (0 = width) */
+    const uint8_t *level_image[PAIS_MAX_LEVELS]; /* getPyramidImage(l).data, host memory */
+    const double  *level_edge[PAIS_MAX_LEVELS];  /* getPyramidEdge(l).data (dense rows), host memory;
+                                                    may be NULL when adaptiveGradientEnable == 0 */
+} pais_camera_desc;
+
+/* The part of a Patch that PAIS::getFitness reads (patch.cpp:922-944). */
+typedef struct pais_patch_state {
+    double  ray[3];              /* getRay()                    */
+    int32_t ref_cam;             /* getReferenceCameraIndex()   */
+    int32_t lod;                 /* getLOD()                    */
+    int32_t num_cam;             /* getCameraNumber()           */
+    int32_t _pad;
+    int32_t cam_idx[PAIS_MAX_VIS]; /* getCameraIndices()        */
+} pais_patch_state;
+
+/* A constructed-but-unrefined patch: the state right after the seed
+ * constructor (patch.cpp:26-34) or the expansion constructor (patch.cpp:36-43,
+ * i.e. parent normal inherited and expandVisibleCamera() applied). */
+typedef struct pais_candidate {
+    double   center[3];
+    double   normal[3];
+    double   normalS[2];         /* spherical form of `normal` (abstractpatch.cpp:43-46) */
+    uint64_t key;                /* schedule-independent key of the deterministic PSO stream */
+    int32_t  type;               /* PAIS_TYPE_SEED / PAIS_TYPE_EXPAND */
+    int32_t  num_cam;
+    int32_t  cam_idx[PAIS_MAX_VIS];
+} pais_candidate;
+
+/* The patch after refine() + removeInvisibleCamera() (AbstractPatch fields,
+ * mvs/abstractpatch.h:22-53).  When `dropped` != 0 only `dropped` is meaningful. */
+typedef struct pais_patch_result {
+    double   center[3];
+    double   normal[3];
+    double   normalS[2];
+    double   ray[3];
+    double   depth;
+    double   depthRange[2];
+    double   fitness;
+    double   priority;
+    double   correlation;
+    double   imgPoint[PAIS_MAX_VIS][2];
+    uint64_t key;
+    int32_t  type;
+    int32_t  dropped;
+    int32_t  num_cam;
+    int32_t  ref_cam;
+    int32_t  lod;
+    int32_t  pso_runs;           /* psoOptimization() calls                 */
+    int32_t  pso_iterations;     /* sum of PsoSolver::getIteration()        */
+    int32_t  pso_evals;          /* getFitness evaluations executed         */
+    int32_t  cam_idx[PAIS_MAX_VIS];
+    /* refine() loop bookkeeping (patch.cpp:132-171); internal, kept in the
+     * record so that a record is the complete device-side state */
+    int32_t  stage;
+    int32_t  before_ref, before_num, after_ref, after_num, count, total_cam_num;
+    int32_t  ncc_tables;         /* setCorrelationTable() calls             */
+} pais_patch_result;
+
+typedef struct pais_ctx pais_ctx;
+
+/* Create the per-scene context on HIP device `device`: copies config, camera
+ * matrices, gray pyramids (and edge pyramids if given) into HBM and builds the
+ * Gaussian distance table (MVS::initPatchDistanceWeighting, mvs.cpp:97-114).
+ * `pso_seed` seeds the deterministic uniform stream that replaces
+ * srand(time)+rand() (psosolver.cpp:60-68). */
+int  pais_ctx_create(const pais_config *cfg, int num_cams, const pais_camera_desc *cams,
+                     int device, uint64_t pso_seed, pais_ctx **out);
+/* MVS::setConfig (mvs.cpp:42-72): replaces the config, rebuilds the table. */
+int  pais_ctx_set_config(pais_ctx *ctx, const pais_config *cfg);
+/* MVS::setNeighborRadius result (mvs.cpp:147-152); read by setDepthRange (patch.cpp:508). */
+int  pais_ctx_set_neighbor_radius(pais_ctx *ctx, double neighbor_radius);
+void pais_ctx_destroy(pais_ctx *ctx);
+
+/* out[e] = PAIS::getFitness(particle e, &patch[state_index[e]])  (patch.cpp:914-1047).
+ * particles: n_evals x 3 doubles (theta, phi, depth).  Host pointers. */
+int  pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_state *states,
+                        int n_evals, const int32_t *state_index, const double *particles,
+                        double *out);
+
+/* For each candidate: Patch::refine() followed by Patch::removeInvisibleCamera()
+ * (mvs.cpp:214-215 / 573-574).  Host pointers; synchronous at return. */
+int  pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *cands, pais_patch_result *out);
+
+/* Same, with device pointers (results stay in HBM, e.g. as the send buffer of
+ * the per-round RCCL all-gather).  Work is enqueued on the context's stream
+ * (pais_ctx_stream()).  `max_num_cam` bounds num_cam over the batch (<=0: use
+ * min(num_cams, PAIS_MAX_VIS)); `has_seeds` != 0 if any candidate is a seed
+ * (the seed loop needs one host decision per pass and is then synchronous;
+ * pure expansion batches are enqueued asynchronously). */
+int  pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candidate *d_cands,
+                              pais_patch_result *d_out, int max_num_cam, int has_seeds);
+/* The HIP stream (hipStream_t) all work of this context is enqueued on. */
+void *pais_ctx_stream(pais_ctx *ctx);
+int  pais_ctx_synchronize(pais_ctx *ctx);
+
+/* Timing of the dominant (PSO) kernel accumulated since the last reset, measured
+ * with HIP events on the launch stream: total ms, launches, evaluations executed,
+ * algorithmic bytes (S^2*(4K+1+8[dist]+8[grad]) per evaluation). */
+typedef struct pais_kernel_stats {
+    double   pso_ms;
+    double   begin_ms;
+    double   after_ms;
+    int64_t  pso_launches;
+    int64_t  pso_evals;
+    int64_t  pso_patches;
+    double   pso_algorithmic_bytes;
+    double   ncc_algorithmic_bytes;
+    int64_t  ncc_tables;
+} pais_kernel_stats;
+int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
+
+/* Deterministic stream helpers (shared by host scheduler and tests). */
+uint32_t pais_rand31(uint64_t seed, uint64_t key, uint32_t run, uint32_t k);
+uint64_t pais_child_key(uint64_t parent_key, int cam, int cx, int cy);
+
+const char *pais_last_error(void);
+size_t pais_sizeof_config(void);
+size_t pais_sizeof_camera_desc(void);
+size_t pais_sizeof_candidate(void);
+size_t pais_sizeof_patch_result(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAIS_HIP_H */

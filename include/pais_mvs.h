@@ -1,0 +1,86 @@
+/*
+ * pais_mvs.h -- C ABI of the host-side reconstruction driver: the MI355X
+ * drop-in behind MVS::refineSeedPatches() / MVS::expansionPatches()
+ * (TMVS/mvs/mvs.h:229,231; TMVS/mvs/mvs.cpp:196-275, 529-898).
+ *
+ * The driver owns what the reference's MVS singleton owns on this path --
+ * patches (map<int,Patch>, mvs.h:86), one CellMap per camera (mvs.h:88,
+ * cellmap.h:15-32), the priority queue (mvs.h:92), neighborRadius -- and
+ * forwards every batch of constructed-but-unrefined patches to
+ * pais_refine_batch() (include/pais_hip.h).
+ *
+ * Expansion runs in rounds R(B): pop B parents with the
+ * reference's queue policy, refine ALL their candidate cells speculatively in
+ * one GPU batch, then replay the reference's sequential loop (mvs.cpp:243-272,
+ * 529-601) on the host, consuming only the candidates the sequential order
+ * would have evaluated.  The accepted cloud is identical to processing the
+ * popped parents one by one, and independent of how the batch was split
+ * across GPUs.  B = 1 is the reference's own order.
+ *
+ * The stepwise entry points (round_begin / round_commit) exist so that several
+ * ranks, each with its own GPU and a replicated driver, can refine disjoint
+ * shards of a round's candidates and exchange the records with one all-gather.
+ */
+#ifndef PAIS_MVS_H
+#define PAIS_MVS_H
+
+#include "pais_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pais_mvs pais_mvs;
+
+typedef struct pais_mvs_stats {
+    int64_t seeds_refined;        /* refine() calls on seeds                                   */
+    int64_t candidates_refined;   /* expansion candidates sent to the GPU (speculative superset) */
+    int64_t candidates_effective; /* of those, the ones the sequential order evaluates          */
+    int64_t patches_inserted;     /* insertPatch() successes                                    */
+    int64_t patches_deleted;
+    int64_t rounds;
+    int64_t parents_popped;
+    int64_t pso_evals_effective;  /* getFitness calls of the effective refines                  */
+    double  host_enumerate_ms, host_commit_ms, gpu_refine_ms;
+} pais_mvs_stats;
+
+/* Creates the driver and its own pais_ctx on `device` (MVS::getInstance(config),
+ * mvs.cpp:22-34 + loading the cameras). */
+int  pais_mvs_create(const pais_config *cfg, int num_cams, const pais_camera_desc *cams,
+                     int device, uint64_t pso_seed, pais_mvs **out);
+void pais_mvs_destroy(pais_mvs *m);
+pais_ctx *pais_mvs_ctx(pais_mvs *m);
+
+/* Seed constructor Patch(center, color, camIdx, imgPoint) (patch.cpp:26-34,
+ * setEstimatedNormal :390-413).  Returns the patch id (>= 0) or < 0. */
+int  pais_mvs_add_seed(pais_mvs *m, const double center[3], int num_cam, const int32_t *cam_idx);
+
+/* MVS::refineSeedPatches (mvs.cpp:196-231), one GPU batch. */
+int  pais_mvs_refine_seed_patches(pais_mvs *m);
+/* MVS::expansionPatches (mvs.cpp:233-275) in rounds of `parents_per_round`
+ * parents; max_rounds <= 0: until the queue is empty. */
+int  pais_mvs_expansion_patches(pais_mvs *m, int parents_per_round, int max_rounds);
+
+/* ---- stepwise (multi-GPU) --------------------------------------------- */
+/* seeds: candidates of all seeds with camNum >= minCamNum (others are deleted) */
+int  pais_mvs_seed_begin(pais_mvs *m, const pais_candidate **cands, int *n);
+int  pais_mvs_seed_commit(pais_mvs *m, const pais_patch_result *results, int n);
+/* setCellMaps + initPriorityQueue + setNeighborRadius (mvs.cpp:235-239) */
+int  pais_mvs_expansion_begin(pais_mvs *m);
+/* returns 0 with *n >= 0 candidates (pointer valid until the next call), 1 when expansion is finished */
+int  pais_mvs_round_begin(pais_mvs *m, int parents_per_round, const pais_candidate **cands, int *n);
+int  pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *results, int n);
+int  pais_mvs_expansion_end(pais_mvs *m);   /* setNeighborRadius (mvs.cpp:274) */
+
+/* ---- inspection -------------------------------------------------------- */
+int    pais_mvs_num_patches(const pais_mvs *m);
+int    pais_mvs_num_slots(const pais_mvs *m);        /* ids are 0 .. slots-1 */
+/* returns 0 and fills *out (+ *expanded) if the id is alive, 1 if deleted */
+int    pais_mvs_get_patch(const pais_mvs *m, int id, pais_patch_result *out, int *expanded);
+double pais_mvs_neighbor_radius(const pais_mvs *m);
+int    pais_mvs_get_stats(const pais_mvs *m, pais_mvs_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

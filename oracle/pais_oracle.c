@@ -26,6 +26,31 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+#include "po_detmath.h"
+
+/* Elementary functions: the platform libm by default (what the reference does);
+ * the reproducible fdlibm statements when the scene asks for them (see
+ * po_detmath.h and DESIGN.md 5.3). */
+static inline double m_exp(const po_scene *s, double x) { return s->detMath ? po_det_exp(x) : exp(x); }
+static inline double m_sin(const po_scene *s, double x) { return s->detMath ? po_det_sin(x) : sin(x); }
+static inline double m_cos(const po_scene *s, double x) { return s->detMath ? po_det_cos(x) : cos(x); }
+double po_exp_det(double x) { return po_det_exp(x); }
+double po_sin_det(double x) { return po_det_sin(x); }
+double po_cos_det(double x) { return po_det_cos(x); }
+
+/* Sum of 64 partials in the order of a wave64 xor-butterfly (v += shfl_xor(v, m),
+ * m = 32,16,...,1): the reduction tree of the HIP kernels (po_scene.treeSum). */
+static double tree64(const double *p)
+{
+    double a[64], b[64];
+    for (int l = 0; l < 64; ++l) a[l] = p[l];
+    for (int m = 32; m >= 1; m >>= 1) {
+        for (int l = 0; l < 64; ++l) b[l] = a[l] + a[l ^ m];
+        for (int l = 0; l < 64; ++l) a[l] = b[l];
+    }
+    return a[0];
+}
+
 /* OpenCV: cvRound == lrint under the default rounding mode (round-half-even).
  * Call sites: patch.cpp:571-572,651,986,1037; mvs.cpp:860. */
 static inline int cv_round(double v) { return (int)lrint(v); }
@@ -265,6 +290,13 @@ void po_normal2spherical(const double in[3], double out[2])
 {
     out[0] = acos(in[2]);
     out[1] = atan2(in[1], in[0]);
+}
+
+static void s2n(const po_scene *s, const double in[2], double out[3])
+{
+    out[0] = m_sin(s, in[0]) * m_cos(s, in[1]);
+    out[1] = m_sin(s, in[0]) * m_sin(s, in[1]);
+    out[2] = m_cos(s, in[0]);
 }
 
 static inline double dot3(const double *a, const double *b)
@@ -549,6 +581,65 @@ double po_region_ratio(const po_scene *s, const double pt[2], const double H[9])
     return (double)(mn / mx);
 }
 
+typedef struct {
+    const po_scene *s; const po_patch *patch; const double *H; const uint8_t *refImg; const double *edgeImg;
+    int refCols, LOD, camNum;
+} fit_px_ctx;
+
+/* one window pixel of PAIS::getFitness (patch.cpp:981-1038).
+ * returns 0: masked (skipped), 1: ok (*weight, *avgSad set), -1: overflow -> whole call DBL_MAX */
+static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, double *weightOut, double *sadOut)
+{
+    const po_scene *s = f->s;
+    const po_patch *patch = f->patch;
+    const int camNum = f->camNum, LOD = f->LOD;
+    double mean = 0, avgSad = 0;
+    double w, ix, iy;
+    int px[4], py[4];
+    double c[PO_MAX_VIS];
+
+    if (f->refImg[(size_t)cv_round(y) * f->refCols + cv_round(x)] == 0) return 0; /* :986 */
+
+    for (int i = 0; i < camNum; ++i) {
+        const po_camera *cam = &s->cams[patch->camIdx[i]];
+        const uint8_t *img = cam->img[LOD];
+        const int cols = cam->width[LOD], rows = cam->height[LOD];
+        const double *Hi = f->H + 9 * i;
+
+        w = (Hi[6] * x + Hi[7] * y + Hi[8]);
+        ix = (Hi[0] * x + Hi[1] * y + Hi[2]) / w;
+        iy = (Hi[3] * x + Hi[4] * y + Hi[5]) / w;
+
+        if (ix < 2 || ix >= cols - 3 || iy < 2 || iy >= rows - 3 || w == 0) return -1; /* :999 */
+        /* (int)NaN is UB in the reference; NaN passes the test above only if w
+         * is NaN -- treated as overflow here. */
+        if (isnan(ix) || isnan(iy)) return -1;
+
+        px[0] = (int)ix; py[0] = (int)iy;
+        px[1] = px[0] + 1; py[1] = py[0];
+        px[2] = px[0]; py[2] = py[0] + 1;
+        px[3] = px[0] + 1; py[3] = py[0] + 1;
+
+        c[i] = (double)img[(size_t)py[0] * cols + px[0]] * (px[1] - ix) * (py[2] - iy) +
+               (double)img[(size_t)py[1] * cols + px[1]] * (ix - px[0]) * (py[2] - iy) +
+               (double)img[(size_t)py[2] * cols + px[2]] * (px[1] - ix) * (iy - py[0]) +
+               (double)img[(size_t)py[3] * cols + px[3]] * (ix - px[0]) * (iy - py[0]);
+        mean += c[i];
+    }
+    mean /= camNum;
+    for (int i = 0; i < camNum; i++) avgSad += fabs(c[i] - mean);
+    avgSad /= camNum;
+
+    double weight = 1;
+    if (s->cfg.adaptiveDistanceEnable) weight *= distW;
+    if (s->cfg.adaptiveDifferenceEnable) weight *= m_exp(s, -avgSad * avgSad / s->cfg.diffWeighting);
+    if (s->cfg.adaptiveGradientEnable)
+        weight *= m_exp(s, -1.0 / (f->edgeImg[(size_t)cv_round(y) * f->refCols + cv_round(x)] * s->cfg.gradientWeighting));
+    *weightOut = weight;
+    *sadOut = avgSad;
+    return 1;
+}
+
 /* ------------------------------------------------------------------------ */
 /* cost: PAIS::getFitness, patch.cpp:914-1047                                */
 /* ------------------------------------------------------------------------ */
@@ -564,7 +655,7 @@ double po_get_fitness(const po_scene *s, const po_patch *patch, const double pos
 
     double normal[3];
     double sph[2] = {pos[0], pos[1]};
-    po_spherical2normal(sph, normal);
+    s2n(s, sph, normal);
 
     if (dot3(normal, refCam->optN) > 0) return DBL_MAX; /* :939 */
 
@@ -581,65 +672,43 @@ double po_get_fitness(const po_scene *s, const po_patch *patch, const double pos
         pt[1] - patchRadius < 2 || pt[1] + patchRadius >= refRows - 3)
         return DBL_MAX; /* :957-962 (edgeImg dims == level dims) */
 
-    double mean, avgSad;
-    double w, ix, iy;
-    int px[4], py[4];
-    double c[PO_MAX_VIS];
+    fit_px_ctx fx;
+    fx.s = s; fx.patch = patch; fx.H = H; fx.refImg = refImg; fx.edgeImg = edgeImg; fx.refCols = refCols;
+    fx.LOD = LOD; fx.camNum = camNum;
     double fitness = 0;
-
-    const double diffWeighting = s->cfg.diffWeighting;
-    const double gradientWeighting = s->cfg.gradientWeighting;
-    const double *it = s->gauss;
-    double weight;
     double sumWeight = 0;
+    double weight, avgSad;
 
-    for (double x = pt[0] - patchRadius; x <= pt[0] + patchRadius; ++x) {
-        for (double y = pt[1] - patchRadius; y <= pt[1] + patchRadius; ++y, ++it) {
-            mean = 0;
-            avgSad = 0;
-
-            if (refImg[(size_t)cv_round(y) * refCols + cv_round(x)] == 0) continue; /* :986 */
-
-            for (int i = 0; i < camNum; ++i) {
-                const po_camera *cam = &s->cams[patch->camIdx[i]];
-                const uint8_t *img = cam->img[LOD];
-                const int cols = cam->width[LOD], rows = cam->height[LOD];
-                const double *Hi = H + 9 * i;
-
-                w = (Hi[6] * x + Hi[7] * y + Hi[8]);
-                ix = (Hi[0] * x + Hi[1] * y + Hi[2]) / w;
-                iy = (Hi[3] * x + Hi[4] * y + Hi[5]) / w;
-
-                if (ix < 2 || ix >= cols - 3 || iy < 2 || iy >= rows - 3 || w == 0) return DBL_MAX; /* :999 */
-                /* (int)NaN is UB in the reference; NaN passes the test above
-                 * only if w is NaN -- treated as overflow here. */
-                if (isnan(ix) || isnan(iy)) return DBL_MAX;
-
-                px[0] = (int)ix; py[0] = (int)iy;
-                px[1] = px[0] + 1; py[1] = py[0];
-                px[2] = px[0]; py[2] = py[0] + 1;
-                px[3] = px[0] + 1; py[3] = py[0] + 1;
-
-                c[i] = (double)img[(size_t)py[0] * cols + px[0]] * (px[1] - ix) * (py[2] - iy) +
-                       (double)img[(size_t)py[1] * cols + px[1]] * (ix - px[0]) * (py[2] - iy) +
-                       (double)img[(size_t)py[2] * cols + px[2]] * (px[1] - ix) * (iy - py[0]) +
-                       (double)img[(size_t)py[3] * cols + px[3]] * (ix - px[0]) * (iy - py[0]);
-                mean += c[i];
+    if (!s->treeSum) {
+        /* the reference's walk: x outer, y inner, sequential sums (patch.cpp:979-1041) */
+        const double *it = s->gauss;
+        for (double x = pt[0] - patchRadius; x <= pt[0] + patchRadius; ++x) {
+            for (double y = pt[1] - patchRadius; y <= pt[1] + patchRadius; ++y, ++it) {
+                int st = fit_pixel(&fx, x, y, *it, &weight, &avgSad);
+                if (st < 0) return DBL_MAX;
+                if (st == 0) continue;
+                sumWeight += weight;
+                fitness += weight * avgSad;
             }
-            mean /= camNum;
-            for (int i = 0; i < camNum; i++) avgSad += fabs(c[i] - mean);
-            avgSad /= camNum;
-
-            weight = 1;
-            if (s->cfg.adaptiveDistanceEnable) weight *= (*it);
-            if (s->cfg.adaptiveDifferenceEnable) weight *= exp(-avgSad * avgSad / diffWeighting);
-            if (s->cfg.adaptiveGradientEnable)
-                weight *= exp(-1.0 / (edgeImg[(size_t)cv_round(y) * refCols + cv_round(x)] * gradientWeighting));
-            sumWeight += weight;
-            fitness += weight * avgSad;
         }
+        return fitness / sumWeight;
+    } else {
+        /* the HIP kernels' order: pixel k = yi*S + xi goes to lane k%64, lanes add
+         * their pixels in increasing k, then the wave64 butterfly */
+        const int S = s->cfg.patchSize;
+        const double a0 = pt[0] - patchRadius, b0 = pt[1] - patchRadius;
+        double pf[64] = {0}, pw[64] = {0};
+        for (int k = 0; k < S * S; ++k) {
+            const int yi = k / S, xi = k - yi * S;
+            const double x = a0 + (double)xi, y = b0 + (double)yi;
+            int st = fit_pixel(&fx, x, y, s->gauss[xi * S + yi], &weight, &avgSad);
+            if (st < 0) return DBL_MAX;
+            if (st == 0) continue;
+            pw[k & 63] += weight;
+            pf[k & 63] += weight * avgSad;
+        }
+        return tree64(pf) / tree64(pw);
     }
-    return fitness / sumWeight;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -862,11 +931,11 @@ static void set_normal3(po_patch *p, const double n[3])
     po_normal2spherical(p->normal, p->normalS);
 }
 /* abstractpatch.cpp:48-51 */
-static void set_normal2(po_patch *p, const double ns[2])
+static void set_normal2(const po_scene *s, po_patch *p, const double ns[2])
 {
     p->normalS[0] = ns[0];
     p->normalS[1] = ns[1];
-    po_spherical2normal(p->normalS, p->normal);
+    s2n(s, p->normalS, p->normal);
 }
 
 /* patch.cpp:6-23 */
@@ -1073,7 +1142,19 @@ void po_set_lod(const po_scene *s, po_patch *p)
             }
         }
         mean /= count;
-        for (int i = 0; i < count; i++) variance += (textures[i] - mean) * (textures[i] - mean);
+        if (!s->treeSum) {
+            for (int i = 0; i < count; i++) variance += (textures[i] - mean) * (textures[i] - mean);
+        } else {
+            /* kernel order: window pixel k = yi*S + xi on lane k%64, then the butterfly */
+            double pv[64] = {0};
+            const int cx = cv_round(pt[0]), cy = cv_round(pt[1]);
+            for (int k = 0; k < size * size; ++k) {
+                int yi = k / size, xi = k - yi * size;
+                double t = (double)img[(size_t)(cy - patchRadius + yi) * cols + (cx - patchRadius + xi)];
+                pv[k & 63] += (t - mean) * (t - mean);
+            }
+            variance = tree64(pv);
+        }
         variance /= count;
     }
     free(textures);
@@ -1087,7 +1168,7 @@ void po_set_priority(const po_scene *s, po_patch *p)
     const int totalCamNum = s->numCams;
     const int camNum = p->numCam;
     double camRatio = ((double)camNum) / ((double)totalCamNum);
-    p->priority = p->fitness * exp(-p->correlation / w1 - camRatio / w2) * (p->LOD + 1.0);
+    p->priority = p->fitness * m_exp(s, -p->correlation / w1 - camRatio / w2) * (p->LOD + 1.0);
 }
 
 /* patch.cpp:627-653 (colour pick from the RGB image is host-side, not restated) */
@@ -1144,7 +1225,7 @@ void po_pso_optimization(const po_scene *s, po_patch *p)
 
     p->fitness = res.gBestFitness;
     double ns[2] = {res.gBest[0], res.gBest[1]};
-    set_normal2(p, ns);
+    set_normal2(s, p, ns);
     p->depth = res.gBest[2];
     const po_camera *rc2 = &s->cams[p->refCamIdx];
     for (int i = 0; i < 3; ++i) p->center[i] = p->ray[i] * p->depth + rc2->C[i];
@@ -1163,6 +1244,34 @@ static int homography_patch(const po_scene *s, po_patch *p, const double pt[2], 
     int px[4], py[4];
     int count = 0;
     double sum = 0;
+    if (s->treeSum) {
+        /* kernel order: hp index k = yi*S + xi, squared norm by lane partials + butterfly */
+        const int S = s->cfg.patchSize;
+        const double a0 = pt[0] - patchRadius, b0 = pt[1] - patchRadius;
+        double ps[64] = {0};
+        for (int k = 0; k < S * S; ++k) {
+            const int yi = k / S, xi = k - yi * S;
+            const double x = a0 + (double)xi, y = b0 + (double)yi;
+            w = (H[6] * x + H[7] * y + H[8]);
+            ix = (H[0] * x + H[1] * y + H[2]) / w;
+            iy = (H[3] * x + H[4] * y + H[5]) / w;
+            if (ix < 0 || ix >= cols - 1 || iy < 0 || iy >= rows - 1 || w == 0 || isnan(ix) || isnan(iy)) {
+                p->drop = 1;
+                return 0;
+            }
+            px[0] = (int)ix; py[0] = (int)iy;
+            px[1] = px[0] + 1; py[2] = py[0] + 1;
+            double v = (double)img[(size_t)py[0] * cols + px[0]] * (px[1] - ix) * (py[2] - iy) +
+                       (double)img[(size_t)py[0] * cols + px[1]] * (ix - px[0]) * (py[2] - iy) +
+                       (double)img[(size_t)py[2] * cols + px[0]] * (px[1] - ix) * (iy - py[0]) +
+                       (double)img[(size_t)py[2] * cols + px[1]] * (ix - px[0]) * (iy - py[0]);
+            hp[k] = v;
+            ps[k & 63] += v * v;
+        }
+        double inv = 1.0 / sqrt(tree64(ps));
+        for (int k = 0; k < S * S; ++k) hp[k] = hp[k] * inv;
+        return 1;
+    }
     for (double x = pt[0] - patchRadius; x <= pt[0] + patchRadius; ++x) {
         for (double y = pt[1] - patchRadius; y <= pt[1] + patchRadius; ++y) {
             w = (H[6] * x + H[7] * y + H[8]);
@@ -1214,7 +1323,13 @@ void po_set_correlation_table(const po_scene *s, po_patch *p, const double *H)
         for (int j = i + 1; j < camNum; ++j) {
             double corr = 0;
             const double *a = HP + (size_t)S2 * i, *b = HP + (size_t)S2 * j;
-            for (int k = 0; k < S2; ++k) corr += a[k] * b[k];
+            if (!s->treeSum) {
+                for (int k = 0; k < S2; ++k) corr += a[k] * b[k];
+            } else {
+                double pc[64] = {0};
+                for (int k = 0; k < S2; ++k) pc[k & 63] += a[k] * b[k];
+                corr = tree64(pc);
+            }
             p->corrTable[i * camNum + j] = corr;
             p->corrTable[j * camNum + i] = corr;
         }

@@ -96,6 +96,14 @@ typedef struct po_scene {
     double     lodScale[PO_MAX_LEVELS];  /* pow(lodRatio, LOD) */
     uint64_t   seed;                     /* PSO stream seed */
     int        ompParticles;             /* 1: OpenMP over particles (reference structure) */
+    /* Reproducibility switches.  Both 0 = the literal reference
+     * behaviour (platform libm, sequential sums in the reference's pixel order).
+     * Both 1 = the arithmetic the HIP kernels define: fdlibm exp/sin/cos
+     * (po_detmath.h) and wave64-butterfly reduction trees; the GPU parity tests
+     * compare against this mode bit for bit, and tests/test_oracle_modes.py
+     * measures (on the CPU) how far the two modes drift apart. */
+    int        detMath;
+    int        treeSum;
 } po_scene;
 
 /* mvs/abstractpatch.h:22-53 + patch.h:19-20 */
@@ -149,6 +157,8 @@ void po_homographies(const po_scene *s, const po_patch *p, const double center[3
                      const double normal[3], double *H /* numCam*9 */); /* patch.cpp:290-330 */
 double po_region_ratio(const po_scene *s, const double pt[2], const double H[9]); /* patch.cpp:269-288 */
 void po_fit_ellipse(int n, const float *xy, float *cx, float *cy, float *w, float *h, float *angle); /* OpenCV 2.4 */
+
+double po_exp_det(double x); double po_sin_det(double x); double po_cos_det(double x); /* po_detmath.h */
 
 /* ---- cost -------------------------------------------------------------- */
 double po_get_fitness(const po_scene *s, const po_patch *p, const double pos[3]); /* patch.cpp:914-1047 */

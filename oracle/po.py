@@ -46,6 +46,7 @@ class SceneS(C.Structure):
     _fields_ = [
         ("cfg", Config), ("numCams", C.c_int), ("cams", C.POINTER(CameraS)), ("gauss", C.POINTER(C.c_double)),
         ("lodScale", C.c_double * MAX_LEVELS), ("seed", C.c_uint64), ("ompParticles", C.c_int),
+        ("detMath", C.c_int), ("treeSum", C.c_int),
     ]
 
 
@@ -165,6 +166,9 @@ def lib():
     L.po_runtime_filtering.argtypes = [C.c_void_p, C.POINTER(Patch)]
     L.po_expansion_center.argtypes = [C.POINTER(SceneS), C.c_int, C.POINTER(Patch), C.c_int, C.c_int,
                                       C.POINTER(C.c_double)]
+    for n in ("po_exp_det", "po_sin_det", "po_cos_det"):
+        getattr(L, n).restype = C.c_double
+        getattr(L, n).argtypes = [C.c_double]
     L.po_sizeof_patch.restype = C.c_size_t
     L.po_sizeof_config.restype = C.c_size_t
     L.po_sizeof_camera.restype = C.c_size_t
@@ -286,3 +290,9 @@ class OracleScene:
 
     def set_omp(self, on: bool):
         self.ptr.contents.ompParticles = 1 if on else 0
+
+    def set_kernel_arithmetic(self, on: bool):
+        """on: fdlibm exp/sin/cos + wave64 reduction trees (what the HIP kernels compute);
+        off: platform libm + the reference's sequential sums."""
+        self.ptr.contents.detMath = 1 if on else 0
+        self.ptr.contents.treeSum = 1 if on else 0

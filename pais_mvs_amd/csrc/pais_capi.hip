@@ -1,0 +1,449 @@
+// pais_capi.hip -- the C ABI of include/pais_hip.h: scene upload, batch entry
+// points, kernel timing.  No algorithmic fallbacks live here: every entry point
+// either runs the gfx950 kernels or returns an error.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pais_hip.h"
+#include "pais_dev.hpp"
+#include "pais_internal.h"
+
+static thread_local std::string g_err;
+static int fail(const char *what, hipError_t e)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    g_err = buf;
+    return -2;
+}
+static int fail_msg(const char *what)
+{
+    g_err = what;
+    return -1;
+}
+#define HIPCHK(call)                                   \
+    do {                                               \
+        hipError_t e__ = (call);                       \
+        if (e__ != hipSuccess) return fail(#call, e__); \
+    } while (0)
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+struct pais_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int numCUs = 256;
+    size_t ldsLimit = 64 * 1024;
+    DevScene sc;
+    DevCamera *d_cams = nullptr;
+    uint8_t *d_img = nullptr;
+    double *d_edge = nullptr;
+    double *d_gauss = nullptr;
+    size_t imgBytes = 0, edgeBytes = 0;
+    // work buffers
+    pais_candidate *d_cands = nullptr;
+    pais_patch_result *d_recs = nullptr;
+    size_t recCap = 0;
+    double *d_hp = nullptr;
+    size_t hpBytes = 0;
+    int *d_counters = nullptr;          // [0] PSO work counter, [1] "needs another pass" count
+    unsigned long long *d_stat = nullptr; // [0] evals [1] evals*bytesPerPixel [2] patches [3] ncc tables [4] tables*K
+    int *h_counters = nullptr;          // pinned
+    // fitness batch buffers
+    pais_patch_state *d_states = nullptr;
+    int32_t *d_idx = nullptr;
+    double *d_particles = nullptr, *d_out = nullptr;
+    size_t stateCap = 0, evalCap = 0;
+    // timing
+    std::vector<EventPair> evPso, evBegin, evAfter;
+    std::vector<EventPair> evFree;
+    double psoMs = 0, beginMs = 0, afterMs = 0;
+    int64_t psoLaunches = 0;
+};
+
+// MVS::initPatchDistanceWeighting, mvs.cpp:97-114 (host; same arithmetic as the reference)
+static void build_gauss(const pais_config &cfg, std::vector<double> &g)
+{
+    const int S = cfg.patchSize, r = cfg.patchRadius;
+    g.assign((size_t)S * S, 0.0);
+    const double sigma = cfg.distWeighting;
+    const double s2 = 1.0 / (2.0 * sigma * sigma);
+    const double s = 1.0 / (2.0 * M_PI * sigma * sigma);
+    for (int x = 0; x < S; ++x)
+        for (int y = 0; y < S; ++y) {
+            double e = -(pow((double)(x - r), 2) + pow((double)(y - r), 2)) * s2;
+            g[(size_t)x * S + y] = s * exp(e);
+        }
+    double n = 0;
+    for (size_t i = 0; i < g.size(); ++i) n += g[i];
+    const double inv = 1.0 / n;
+    for (size_t i = 0; i < g.size(); ++i) g[i] = g[i] * inv;
+}
+
+static int apply_config(pais_ctx *ctx, const pais_config *cfg)
+{
+    pais_config c = *cfg;
+    c.patchSize = (c.patchRadius << 1) + 1; // mvs.cpp:67
+    if (c.patchRadius < 1 || c.patchRadius > 127) return fail_msg("patchRadius out of range");
+    if (c.particleNum < 1 || c.particleNum * 2 > PAIS_MAX_PARTICLES) return fail_msg("particleNum out of range");
+    if (c.maxLOD < 0 || c.maxLOD >= PAIS_MAX_LEVELS) return fail_msg("maxLOD out of range");
+    std::vector<double> g;
+    build_gauss(c, g);
+    if (ctx->d_gauss) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(ctx->d_gauss));
+        ctx->d_gauss = nullptr;
+    }
+    HIPCHK(hipMalloc(&ctx->d_gauss, g.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->d_gauss, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->sc.cfg = c;
+    ctx->sc.gauss = ctx->d_gauss;
+    for (int l = 0; l < PAIS_MAX_LEVELS; ++l) ctx->sc.lodScale[l] = pow(c.lodRatio, l);
+    return 0;
+}
+
+extern "C" const char *pais_last_error(void) { return g_err.c_str(); }
+extern "C" size_t pais_sizeof_config(void) { return sizeof(pais_config); }
+extern "C" size_t pais_sizeof_camera_desc(void) { return sizeof(pais_camera_desc); }
+extern "C" size_t pais_sizeof_candidate(void) { return sizeof(pais_candidate); }
+extern "C" size_t pais_sizeof_patch_result(void) { return sizeof(pais_patch_result); }
+extern "C" uint32_t pais_rand31(uint64_t seed, uint64_t key, uint32_t run, uint32_t k) { return pais::rand31(seed, key, run, k); }
+extern "C" uint64_t pais_child_key(uint64_t parent_key, int cam, int cx, int cy) { return pais::child_key(parent_key, cam, cx, cy); }
+
+extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device,
+                               uint64_t pso_seed, pais_ctx **out)
+{
+    if (!cfg || !cams || !out || num_cams <= 0) return fail_msg("pais_ctx_create: bad argument");
+    int ndev = 0;
+    hipError_t e0 = hipGetDeviceCount(&ndev);
+    if (e0 != hipSuccess || ndev <= 0) return fail_msg("pais_ctx_create: no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail_msg("pais_ctx_create: bad device index");
+    HIPCHK(hipSetDevice(device));
+    pais_ctx *ctx = new pais_ctx();
+    ctx->device = device;
+    memset(&ctx->sc, 0, sizeof(ctx->sc));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    ctx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->ldsLimit = prop.sharedMemPerBlock > 0 ? (size_t)prop.sharedMemPerBlock : 64 * 1024;
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->sc.seed = pso_seed;
+    ctx->sc.numCams = num_cams;
+    int rc = apply_config(ctx, cfg);
+    if (rc) { pais_ctx_destroy(ctx); return rc; }
+    const bool wantEdge = cfg->adaptiveGradientEnable != 0;
+
+    // layout the blobs
+    std::vector<DevCamera> hc((size_t)num_cams);
+    std::vector<size_t> imgOff((size_t)num_cams * PAIS_MAX_LEVELS, 0), edgeOff((size_t)num_cams * PAIS_MAX_LEVELS, 0);
+    size_t imgBytes = 0, edgeBytes = 0;
+    for (int c = 0; c < num_cams; ++c) {
+        const pais_camera_desc &d = cams[c];
+        if (d.max_lod < 0 || d.max_lod >= PAIS_MAX_LEVELS) { pais_ctx_destroy(ctx); return fail_msg("camera max_lod out of range"); }
+        for (int l = 0; l <= d.max_lod; ++l) {
+            if (!d.level_image[l] || d.level_width[l] <= 0 || d.level_height[l] <= 0) { pais_ctx_destroy(ctx); return fail_msg("camera level missing"); }
+            size_t px = (size_t)d.level_width[l] * d.level_height[l];
+            imgOff[(size_t)c * PAIS_MAX_LEVELS + l] = imgBytes;
+            imgBytes = (imgBytes + px + 16 + 255) & ~(size_t)255; // +16: taps read (px+1, py+1)
+            if (wantEdge) {
+                if (!d.level_edge[l]) { pais_ctx_destroy(ctx); return fail_msg("adaptiveGradientEnable set but level_edge missing"); }
+                edgeOff[(size_t)c * PAIS_MAX_LEVELS + l] = edgeBytes;
+                edgeBytes = (edgeBytes + px * sizeof(double) + 255) & ~(size_t)255;
+            }
+        }
+    }
+    std::vector<uint8_t> himg(imgBytes, 0);
+    for (int c = 0; c < num_cams; ++c) {
+        const pais_camera_desc &d = cams[c];
+        for (int l = 0; l <= d.max_lod; ++l) {
+            const int w = d.level_width[l], h = d.level_height[l];
+            const size_t stride = d.level_stride[l] > 0 ? (size_t)d.level_stride[l] : (size_t)w;
+            uint8_t *dst = himg.data() + imgOff[(size_t)c * PAIS_MAX_LEVELS + l];
+            for (int y = 0; y < h; ++y) memcpy(dst + (size_t)y * w, d.level_image[l] + (size_t)y * stride, (size_t)w);
+        }
+    }
+    HIPCHK(hipMalloc(&ctx->d_img, imgBytes));
+    HIPCHK(hipMemcpy(ctx->d_img, himg.data(), imgBytes, hipMemcpyHostToDevice));
+    ctx->imgBytes = imgBytes;
+    if (wantEdge && edgeBytes) {
+        HIPCHK(hipMalloc(&ctx->d_edge, edgeBytes));
+        for (int c = 0; c < num_cams; ++c) {
+            const pais_camera_desc &d = cams[c];
+            for (int l = 0; l <= d.max_lod; ++l) {
+                size_t px = (size_t)d.level_width[l] * d.level_height[l];
+                HIPCHK(hipMemcpy((uint8_t *)ctx->d_edge + edgeOff[(size_t)c * PAIS_MAX_LEVELS + l], d.level_edge[l],
+                                 px * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
+        ctx->edgeBytes = edgeBytes;
+    }
+    for (int c = 0; c < num_cams; ++c) {
+        const pais_camera_desc &d = cams[c];
+        DevCamera &h = hc[c];
+        memset(&h, 0, sizeof(h));
+        memcpy(h.KR, d.KR, sizeof(h.KR));
+        memcpy(h.KT, d.KT, sizeof(h.KT));
+        memcpy(h.R, d.rotation, sizeof(h.R));
+        memcpy(h.T, d.translation, sizeof(h.T));
+        memcpy(h.C, d.center, sizeof(h.C));
+        memcpy(h.optN, d.optical_normal, sizeof(h.optN));
+        h.focal[0] = d.focal[0]; h.focal[1] = d.focal[1];
+        h.pp[0] = d.principle_point[0]; h.pp[1] = d.principle_point[1];
+        h.maxLOD = d.max_lod;
+        for (int l = 0; l <= d.max_lod; ++l) {
+            h.w[l] = d.level_width[l];
+            h.h[l] = d.level_height[l];
+            h.img[l] = ctx->d_img + imgOff[(size_t)c * PAIS_MAX_LEVELS + l];
+            h.edge[l] = (wantEdge && ctx->d_edge) ? (const double *)((uint8_t *)ctx->d_edge + edgeOff[(size_t)c * PAIS_MAX_LEVELS + l]) : nullptr;
+        }
+    }
+    HIPCHK(hipMalloc(&ctx->d_cams, sizeof(DevCamera) * (size_t)num_cams));
+    HIPCHK(hipMemcpy(ctx->d_cams, hc.data(), sizeof(DevCamera) * (size_t)num_cams, hipMemcpyHostToDevice));
+    ctx->sc.cams = ctx->d_cams;
+
+    HIPCHK(hipMalloc(&ctx->d_counters, sizeof(int) * 4));
+    HIPCHK(hipMemset(ctx->d_counters, 0, sizeof(int) * 4));
+    HIPCHK(hipMalloc(&ctx->d_stat, sizeof(unsigned long long) * 8));
+    HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_counters, sizeof(int) * 4, hipHostMallocDefault));
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void pais_ctx_destroy(pais_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    auto freeEv = [](std::vector<EventPair> &v) {
+        for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        v.clear();
+    };
+    freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evFree);
+    (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
+    (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
+    (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat);
+    (void)hipFree(ctx->d_states); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_particles); (void)hipFree(ctx->d_out);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int pais_ctx_set_config(pais_ctx *ctx, const pais_config *cfg)
+{
+    if (!ctx || !cfg) return fail_msg("pais_ctx_set_config: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (cfg->adaptiveGradientEnable && !ctx->d_edge) return fail_msg("adaptiveGradientEnable needs edge pyramids at create time");
+    double nr = ctx->sc.cfg.neighborRadius;
+    int rc = apply_config(ctx, cfg);
+    (void)nr;
+    return rc;
+}
+
+extern "C" int pais_ctx_set_neighbor_radius(pais_ctx *ctx, double r)
+{
+    if (!ctx) return fail_msg("bad ctx");
+    ctx->sc.cfg.neighborRadius = r;
+    return 0;
+}
+
+extern "C" void *pais_ctx_stream(pais_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int pais_ctx_synchronize(pais_ctx *ctx)
+{
+    if (!ctx) return fail_msg("bad ctx");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------ fitness batch --
+extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_state *states, int n_evals,
+                                  const int32_t *state_index, const double *particles, double *out)
+{
+    if (!ctx || n_states < 0 || n_evals < 0) return fail_msg("pais_fitness_batch: bad argument");
+    if (n_evals == 0) return 0;
+    if (!states || !state_index || !particles || !out) return fail_msg("pais_fitness_batch: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    int Kmax = 1;
+    for (int i = 0; i < n_states; ++i) {
+        const pais_patch_state &s = states[i];
+        if (s.num_cam < 1 || s.num_cam > PAIS_MAX_VIS) return fail_msg("pais_fitness_batch: num_cam out of range");
+        if (s.ref_cam < 0 || s.ref_cam >= ctx->sc.numCams || s.lod < 0 || s.lod >= PAIS_MAX_LEVELS) return fail_msg("pais_fitness_batch: bad ref_cam/lod");
+        for (int k = 0; k < s.num_cam; ++k)
+            if (s.cam_idx[k] < 0 || s.cam_idx[k] >= ctx->sc.numCams) return fail_msg("pais_fitness_batch: bad cam_idx");
+        if (s.num_cam > Kmax) Kmax = s.num_cam;
+    }
+    for (int e = 0; e < n_evals; ++e)
+        if (state_index[e] < 0 || state_index[e] >= n_states) return fail_msg("pais_fitness_batch: bad state_index");
+    if ((size_t)n_states > ctx->stateCap) {
+        (void)hipFree(ctx->d_states);
+        ctx->stateCap = (size_t)n_states * 2;
+        HIPCHK(hipMalloc(&ctx->d_states, sizeof(pais_patch_state) * ctx->stateCap));
+    }
+    if ((size_t)n_evals > ctx->evalCap) {
+        (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_particles); (void)hipFree(ctx->d_out);
+        ctx->evalCap = (size_t)n_evals * 2;
+        HIPCHK(hipMalloc(&ctx->d_idx, sizeof(int32_t) * ctx->evalCap));
+        HIPCHK(hipMalloc(&ctx->d_particles, sizeof(double) * 3 * ctx->evalCap));
+        HIPCHK(hipMalloc(&ctx->d_out, sizeof(double) * ctx->evalCap));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_states, states, sizeof(pais_patch_state) * (size_t)n_states, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_idx, state_index, sizeof(int32_t) * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_particles, particles, sizeof(double) * 3 * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(pais_launch::fitness(ctx->sc, ctx->d_states, ctx->d_idx, ctx->d_particles, ctx->d_out, n_evals, Kmax, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)n_evals, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------- refine batch --
+static int get_event_pair(pais_ctx *ctx, EventPair &p)
+{
+    if (!ctx->evFree.empty()) {
+        p = ctx->evFree.back();
+        ctx->evFree.pop_back();
+        return 0;
+    }
+    HIPCHK(hipEventCreate(&p.a));
+    HIPCHK(hipEventCreate(&p.b));
+    return 0;
+}
+static int drain_events(pais_ctx *ctx, std::vector<EventPair> &v, double &acc)
+{
+    for (auto &p : v) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+        acc += ms;
+        ctx->evFree.push_back(p);
+    }
+    v.clear();
+    return 0;
+}
+
+extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out,
+                                        int max_num_cam, int has_seeds)
+{
+    if (!ctx || n < 0) return fail_msg("pais_refine_batch_device: bad argument");
+    if (n == 0) return 0;
+    if (!d_cands || !d_out) return fail_msg("pais_refine_batch_device: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    const DevScene &sc = ctx->sc;
+    int Kmax = max_num_cam > 0 ? max_num_cam : sc.numCams;
+    if (Kmax > PAIS_MAX_VIS) Kmax = PAIS_MAX_VIS;
+    if (Kmax > sc.numCams) Kmax = sc.numCams;
+    if (Kmax < 1) Kmax = 1;
+    const int N = has_seeds ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
+    const int Nmax = N;
+    const int W = pais_launch::pso_waves(N, Kmax, Nmax, ctx->ldsLimit);
+    if (pais_launch::pso_lds(W, Kmax, Nmax) > ctx->ldsLimit) return fail_msg("pais_refine_batch: LDS budget exceeded (too many visible cameras)");
+    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    int afterGrid = n < 2048 ? n : 2048;
+    size_t hpNeed = (size_t)afterGrid * Kmax * S2 * sizeof(double);
+    if (hpNeed > ctx->hpBytes) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_hp);
+        ctx->d_hp = nullptr;
+        size_t full = (size_t)2048 * Kmax * S2 * sizeof(double);
+        if (full < ((size_t)1 << 31)) hpNeed = full;
+        HIPCHK(hipMalloc(&ctx->d_hp, hpNeed));
+        ctx->hpBytes = hpNeed;
+    }
+    // persistent PSO grid: as many workgroups as can be resident (launcher caps it)
+    int psoGrid = n < ctx->numCUs * 16 ? n : ctx->numCUs * 16;
+
+    EventPair eb, ep, ea;
+    if (get_event_pair(ctx, eb)) return -2;
+    HIPCHK(hipEventRecord(eb.a, ctx->stream));
+    HIPCHK(pais_launch::begin(sc, d_cands, d_out, n, ctx->stream));
+    HIPCHK(hipEventRecord(eb.b, ctx->stream));
+    ctx->evBegin.push_back(eb);
+
+    const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
+    for (int pass = 0; pass < maxPass; ++pass) {
+        HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 2, ctx->stream));
+        if (get_event_pair(ctx, ep)) return -2;
+        HIPCHK(hipEventRecord(ep.a, ctx->stream));
+        HIPCHK(pais_launch::pso(sc, d_out, n, ctx->d_counters, ctx->d_stat, Kmax, Nmax, W, psoGrid, ctx->stream));
+        HIPCHK(hipEventRecord(ep.b, ctx->stream));
+        ctx->evPso.push_back(ep);
+        ctx->psoLaunches++;
+        if (get_event_pair(ctx, ea)) return -2;
+        HIPCHK(hipEventRecord(ea.a, ctx->stream));
+        HIPCHK(pais_launch::after(sc, d_out, n, ctx->d_hp, afterGrid, ctx->d_counters, ctx->d_stat, Kmax, ctx->stream));
+        HIPCHK(hipEventRecord(ea.b, ctx->stream));
+        ctx->evAfter.push_back(ea);
+        if (!has_seeds) break;
+        HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_counters[1] == 0) break;
+    }
+    return 0;
+}
+
+extern "C" int pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *cands, pais_patch_result *out)
+{
+    if (!ctx || n < 0) return fail_msg("pais_refine_batch: bad argument");
+    if (n == 0) return 0;
+    if (!cands || !out) return fail_msg("pais_refine_batch: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    int Kmax = 1, hasSeeds = 0;
+    for (int i = 0; i < n; ++i) {
+        const pais_candidate &c = cands[i];
+        if (c.num_cam < 0 || c.num_cam > PAIS_MAX_VIS) return fail_msg("pais_refine_batch: num_cam out of range");
+        for (int k = 0; k < c.num_cam; ++k)
+            if (c.cam_idx[k] < 0 || c.cam_idx[k] >= ctx->sc.numCams) return fail_msg("pais_refine_batch: bad cam_idx");
+        if (c.num_cam > Kmax) Kmax = c.num_cam;
+        if (c.type == PAIS_TYPE_SEED) hasSeeds = 1;
+        else if (c.type != PAIS_TYPE_EXPAND) return fail_msg("pais_refine_batch: bad type");
+    }
+    if ((size_t)n > ctx->recCap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs);
+        ctx->d_cands = nullptr; ctx->d_recs = nullptr;
+        ctx->recCap = (size_t)n + (size_t)n / 2 + 256;
+        HIPCHK(hipMalloc(&ctx->d_cands, sizeof(pais_candidate) * ctx->recCap));
+        HIPCHK(hipMalloc(&ctx->d_recs, sizeof(pais_patch_result) * ctx->recCap));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_cands, cands, sizeof(pais_candidate) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    int rc = pais_refine_batch_device(ctx, n, ctx->d_cands, ctx->d_recs, Kmax, hasSeeds);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, ctx->d_recs, sizeof(pais_patch_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset)
+{
+    if (!ctx || !out) return fail_msg("pais_get_kernel_stats: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (drain_events(ctx, ctx->evPso, ctx->psoMs)) return -2;
+    if (drain_events(ctx, ctx->evBegin, ctx->beginMs)) return -2;
+    if (drain_events(ctx, ctx->evAfter, ctx->afterMs)) return -2;
+    unsigned long long st[8];
+    HIPCHK(hipMemcpy(st, ctx->d_stat, sizeof(st), hipMemcpyDeviceToHost));
+    const double S2 = (double)ctx->sc.cfg.patchSize * ctx->sc.cfg.patchSize;
+    out->pso_ms = ctx->psoMs;
+    out->begin_ms = ctx->beginMs;
+    out->after_ms = ctx->afterMs;
+    out->pso_launches = ctx->psoLaunches;
+    out->pso_evals = (int64_t)st[0];
+    out->pso_patches = (int64_t)st[2];
+    out->pso_algorithmic_bytes = (double)st[1] * S2;
+    out->ncc_tables = (int64_t)st[3];
+    out->ncc_algorithmic_bytes = (double)st[4] * S2 * 4.0;
+    if (reset) {
+        HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
+        ctx->psoMs = ctx->beginMs = ctx->afterMs = 0;
+        ctx->psoLaunches = 0;
+    }
+    return 0;
+}

@@ -1,0 +1,45 @@
+// pais_internal.h -- device-side scene layout shared by pais_kernels.hip and pais_capi.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pais_hip.h"
+
+// refine() progress of a record (pais_patch_result::stage)
+#define PAIS_STAGE_DONE  0
+#define PAIS_STAGE_PSO   1  /* psoOptimization() pending (patch.cpp:153)           */
+#define PAIS_STAGE_AFTER 2  /* PSO finished, removeInvisibleCamera etc. pending     */
+
+// HBM layout: one DevCamera per camera in a dense array;
+// every pyramid level of every camera repacked row-major with stride == width
+// into one byte blob (levels 256-byte aligned), edge levels likewise as doubles.
+struct DevCamera {
+    double KR[9], KT[3], R[9], T[3], C[3], optN[3], focal[2], pp[2];
+    int maxLOD;
+    int pad;
+    int w[PAIS_MAX_LEVELS], h[PAIS_MAX_LEVELS];
+    const uint8_t *img[PAIS_MAX_LEVELS];
+    const double *edge[PAIS_MAX_LEVELS];
+};
+
+struct DevScene {
+    pais_config cfg;
+    const DevCamera *cams;
+    const double *gauss; // patchDistWeight, S*S, indexed [x*S + y] (mvs.cpp:104-109)
+    double lodScale[PAIS_MAX_LEVELS]; // pow(lodRatio, LOD) (camera.cpp:157, patch.cpp:309)
+    uint64_t seed;
+    int numCams;
+    int pad;
+};
+
+namespace pais_launch {
+hipError_t fitness(const DevScene &sc, const pais_patch_state *states, const int32_t *idx, const double *particles,
+                   double *out, int nEvals, int Kmax, hipStream_t stream);
+hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream);
+int pso_waves(int N, int Kmax, int Nmax, size_t ldsLimit);
+size_t pso_lds(int W, int Kmax, int Nmax);
+hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters, unsigned long long *stat, int Kmax,
+               int Nmax, int W, int grid, hipStream_t stream);
+hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
+                 unsigned long long *stat, int Kmax, hipStream_t stream);
+} // namespace pais_launch

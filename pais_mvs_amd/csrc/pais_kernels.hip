@@ -1,0 +1,1037 @@
+// pais_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the PAIS-MVS hot path.
+//
+//   k_fitness : batched PAIS::getFitness                      (patch.cpp:914-1047)
+//   k_begin   : head of Patch::refine()                       (patch.cpp:114-136)
+//   k_pso     : Patch::psoOptimization() == one GLN-PSO run    (patch.cpp:180-219,
+//               with the cost evaluated wave-parallel           pso/psosolver.cpp)
+//   k_after   : removeInvisibleCamera + setters + loop control (patch.cpp:156-175,
+//               + the trailing removeInvisibleCamera             655-721; mvs.cpp:215,574)
+//
+// Mapping: one workgroup per candidate patch in k_pso,
+// particles <-> waves, window pixels <-> lanes (row-major so that neighbouring
+// lanes read neighbouring bytes of the reprojected image rows), FP64 xor-butterfly
+// reductions in a fixed order so a cost value is a pure function of (patch,
+// particle).  Camera matrices / homographies / swarm state live in LDS.  No MFMA:
+// the work is byte gathers + FP64 VALU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pais_hip.h"
+#include "pais_dev.hpp"
+#include "pais_internal.h"
+
+using namespace pais;
+
+// --------------------------------------------------------------- helpers ---
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS/global traffic of one wave is processed in issue order; a
+    // wavefront-scope fence only has to stop the compiler from reordering.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ------------------------------------------------------- eval patch in LDS --
+struct EvalCam {
+    double KR[9];
+    double KT[3];
+    const uint8_t *img;
+    int w, h;
+    int cam;
+    int pad;
+};
+struct EvalPatch {
+    double ray[3], Cref[3], optNref[3], Rref[9], Tref[3], fref[2], ppref[2], KRref[9], KTref[3];
+    double lodScale;
+    const uint8_t *refImg;
+    const double *refEdge;
+    int refW, refH;
+    int K, LOD, refCam, pad;
+};
+
+// threads t < K fill cams[t]; thread 0 fills *ep.  Caller synchronises.
+__device__ void fill_eval_patch(const DevScene &sc, EvalPatch *ep, EvalCam *cams, const double *ray,
+                                int refCam, int LOD, int K, const int *camIdx, int tid, int nthreads)
+{
+    for (int c = tid; c < K; c += nthreads) {
+        const DevCamera &dc = sc.cams[camIdx[c]];
+        for (int i = 0; i < 9; ++i) cams[c].KR[i] = dc.KR[i];
+        for (int i = 0; i < 3; ++i) cams[c].KT[i] = dc.KT[i];
+        cams[c].img = dc.img[LOD];
+        cams[c].w = dc.w[LOD];
+        cams[c].h = dc.h[LOD];
+        cams[c].cam = camIdx[c];
+    }
+    if (tid == 0) {
+        const DevCamera &rc = sc.cams[refCam];
+        for (int i = 0; i < 3; ++i) {
+            ep->ray[i] = ray[i];
+            ep->Cref[i] = rc.C[i];
+            ep->optNref[i] = rc.optN[i];
+            ep->Tref[i] = rc.T[i];
+            ep->KTref[i] = rc.KT[i];
+        }
+        for (int i = 0; i < 9; ++i) {
+            ep->Rref[i] = rc.R[i];
+            ep->KRref[i] = rc.KR[i];
+        }
+        ep->fref[0] = rc.focal[0]; ep->fref[1] = rc.focal[1];
+        ep->ppref[0] = rc.pp[0]; ep->ppref[1] = rc.pp[1];
+        ep->lodScale = sc.lodScale[LOD];
+        ep->refImg = rc.img[LOD];
+        ep->refEdge = rc.edge[LOD];
+        ep->refW = rc.w[LOD];
+        ep->refH = rc.h[LOD];
+        ep->K = K;
+        ep->LOD = LOD;
+        ep->refCam = refCam;
+    }
+}
+
+// PAIS::getFitness for one particle, executed by ONE wave (all 64 lanes enter
+// with identical arguments and leave with the identical result).
+//   Hbuf : this wave's LDS scratch, K*9 doubles   (homographies, patch.cpp:290-330)
+//   cbuf : this wave's LDS scratch, K*64 doubles  (per-camera colour of the lane's pixel)
+__device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf,
+                               double *cbuf, double theta, double phi, double depth, int lane)
+{
+    double n[3];
+    spherical2normal(theta, phi, n);
+    {
+        double on[3] = {ep->optNref[0], ep->optNref[1], ep->optNref[2]};
+        if (dot3(n, on) > 0) return DBL_MAX; // patch.cpp:939
+    }
+    double center[3];
+    for (int i = 0; i < 3; ++i) center[i] = ep->ray[i] * depth + ep->Cref[i]; // :944
+    const int K = ep->K;
+    const double s = ep->lodScale;
+    {
+        const double d = -dot3(center, n);
+        double Mref[9], invH[9], kr[9], kt[3];
+        for (int i = 0; i < 9; ++i) kr[i] = ep->KRref[i];
+        for (int i = 0; i < 3; ++i) kt[i] = ep->KTref[i];
+        plane_matrix(d, s, kr, kt, n, Mref);
+        inv3(Mref, invH);
+        for (int c = lane; c < K; c += 64) {
+            double H[9];
+            if (cams[c].cam == ep->refCam) { // :317-320
+                H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0; H[6] = 0; H[7] = 0; H[8] = 1;
+            } else {
+                double M[9];
+                for (int i = 0; i < 9; ++i) kr[i] = cams[c].KR[i];
+                for (int i = 0; i < 3; ++i) kt[i] = cams[c].KT[i];
+                plane_matrix(d, s, kr, kt, n, M);
+                mul33(M, invH, H);
+            }
+            for (int i = 0; i < 9; ++i) Hbuf[c * 9 + i] = H[i];
+        }
+    }
+    wave_sync();
+
+    double pt[2];
+    {
+        double R[9], T[3], f[2], pp[2];
+        for (int i = 0; i < 9; ++i) R[i] = ep->Rref[i];
+        for (int i = 0; i < 3; ++i) T[i] = ep->Tref[i];
+        f[0] = ep->fref[0]; f[1] = ep->fref[1]; pp[0] = ep->ppref[0]; pp[1] = ep->ppref[1];
+        project_raw(R, T, f, pp, s, center, pt);
+    }
+    const int refW = ep->refW, refH = ep->refH;
+    if (!in_image_d(pt, refW, refH)) return DBL_MAX; // :952
+    const int r = sc.cfg.patchRadius;
+    if (pt[0] - r < 2 || pt[0] + r >= refW - 3 || pt[1] - r < 2 || pt[1] + r >= refH - 3) return DBL_MAX; // :957
+
+    const int S = sc.cfg.patchSize, S2 = S * S;
+    const double a0 = pt[0] - r, b0 = pt[1] - r;
+    const uint8_t *refImg = ep->refImg;
+    const double *refEdge = ep->refEdge;
+    const double diffW = sc.cfg.diffWeighting, gradW = sc.cfg.gradientWeighting;
+    const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useDiff = sc.cfg.adaptiveDifferenceEnable != 0,
+               useGrad = sc.cfg.adaptiveGradientEnable != 0;
+    const double dK = (double)K;
+    double fsum = 0, wsum = 0;
+    double *myc = cbuf + lane;
+
+    for (int base = 0; base < S2; base += 64) {
+        const int k = base + lane;
+        const bool valid = k < S2;
+        const int yi = k / S, xi = k - yi * S;
+        const double x = a0 + (double)xi, y = b0 + (double)yi; // == the reference's ++x / ++y walk
+        const int rx = cv_round(x), ry = cv_round(y);
+        bool bad = false;
+        if (valid && refImg[ry * refW + rx] != 0) { // :986
+            double mean = 0;
+            for (int c = 0; c < K; ++c) {
+                const double *H = Hbuf + 9 * c;
+                const double w = (H[6] * x + H[7] * y + H[8]);
+                const double ix = (H[0] * x + H[1] * y + H[2]) / w;
+                const double iy = (H[3] * x + H[4] * y + H[5]) / w;
+                const int cw = cams[c].w, ch = cams[c].h;
+                if (!(ix >= 2 && ix < cw - 3 && iy >= 2 && iy < ch - 3) || w == 0) { // :999 (NaN -> overflow)
+                    bad = true;
+                    break;
+                }
+                const double col = bilinear(cams[c].img, cw, ix, iy);
+                myc[c * 64] = col;
+                mean += col;
+            }
+            if (!bad) {
+                mean /= dK;
+                double sad = 0;
+                for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
+                sad /= dK;
+                double weight = 1;
+                if (useDist) weight *= sc.gauss[xi * S + yi];
+                if (useDiff) weight *= det_exp(-sad * sad / diffW);
+                if (useGrad) weight *= det_exp(-1.0 / (refEdge[ry * refW + rx] * gradW));
+                wsum += weight;
+                fsum += weight * sad;
+            }
+        }
+        if (__any(bad)) return DBL_MAX; // :1001 -- whole call
+    }
+    fsum = wave_sum(fsum);
+    wsum = wave_sum(wsum);
+    return fsum / wsum; // NaN when every pixel was masked, as in the reference
+}
+
+// ------------------------------------------------------------- k_fitness ---
+// one wave (= one 64-thread workgroup) per evaluation
+__global__ __launch_bounds__(64) void k_fitness(DevScene sc, const pais_patch_state *states, const int32_t *stateIndex,
+                                                const double *particles, double *out, int nEvals, int Kmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    EvalPatch *ep = (EvalPatch *)smem;
+    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
+    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
+    double *cbuf = Hbuf + Kmax * 9;
+    const int lane = threadIdx.x;
+    for (int e = blockIdx.x; e < nEvals; e += gridDim.x) {
+        const pais_patch_state *st = &states[stateIndex[e]];
+        __syncthreads();
+        fill_eval_patch(sc, ep, cams, st->ray, st->ref_cam, st->lod, st->num_cam, st->cam_idx, lane, 64);
+        __syncthreads();
+        double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, particles[3 * e], particles[3 * e + 1], particles[3 * e + 2], lane);
+        if (lane == 0) out[e] = v;
+    }
+}
+
+// ------------------------------------------- scalar setters on an LDS patch --
+// All lanes of the (single-wave) workgroup execute these with identical data;
+// stores are done by lane 0, callers __syncthreads() between phases.
+
+__device__ bool cam_project(const DevScene &sc, int cam, const double *X, double *out, int LOD)
+{
+    const DevCamera &c = sc.cams[cam];
+    project_raw(c.R, c.T, c.focal, c.pp, sc.lodScale[LOD], X, out);
+    if (LOD > c.maxLOD) return false;
+    return in_image_d(out, c.w[LOD], c.h[LOD]);
+}
+
+// Patch::setReferenceCameraIndex, patch.cpp:415-445
+__device__ void set_reference_camera(const DevScene &sc, pais_patch_result *st, int lane)
+{
+    if (st->dropped) return;
+    const int camNum = st->num_cam;
+    int ref = -1, drop = 0;
+    if (camNum < sc.cfg.minCamNum) {
+        drop = 1;
+        ref = st->ref_cam;
+    } else {
+        double maxCorr = -DBL_MAX;
+        const double n0 = st->normal[0], n1 = st->normal[1], n2 = st->normal[2];
+        for (int i = 0; i < camNum; i++) {
+            const DevCamera &c = sc.cams[st->cam_idx[i]];
+            double corr = n0 * (-c.optN[0]) + n1 * (-c.optN[1]) + n2 * (-c.optN[2]);
+            if (corr > maxCorr) {
+                maxCorr = corr;
+                ref = st->cam_idx[i];
+            }
+        }
+        if (ref < 0) {
+            ref = st->cam_idx[0];
+            drop = 1;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        st->ref_cam = ref;
+        if (drop) st->dropped = 1;
+    }
+    __syncthreads();
+}
+
+// Patch::setDepthAndRay, patch.cpp:447-461
+__device__ void set_depth_and_ray(const DevScene &sc, pais_patch_result *st, int lane)
+{
+    if (st->dropped) return;
+    if (st->ref_cam < 0) {
+        __syncthreads();
+        if (lane == 0) st->dropped = 1;
+        __syncthreads();
+        return;
+    }
+    const DevCamera &rc = sc.cams[st->ref_cam];
+    double ray[3];
+    for (int i = 0; i < 3; ++i) ray[i] = st->center[i] - rc.C[i];
+    double depth = norm3(ray);
+    double inv = (1.0 / depth);
+    __syncthreads();
+    if (lane == 0) {
+        st->depth = depth;
+        for (int i = 0; i < 3; ++i) st->ray[i] = ray[i] * inv;
+    }
+    __syncthreads();
+}
+
+// Patch::setDepthRange, patch.cpp:463-509
+__device__ void set_depth_range(const DevScene &sc, pais_patch_result *st, int lane)
+{
+    if (st->dropped) return;
+    const int camNum = st->num_cam;
+    if (camNum < sc.cfg.minCamNum) {
+        __syncthreads();
+        if (lane == 0) st->dropped = 1;
+        __syncthreads();
+        return;
+    }
+    const DevCamera &rc = sc.cams[st->ref_cam];
+    double c1[3], c2[3];
+    for (int i = 0; i < 3; ++i) {
+        c1[i] = st->center[i];
+        c2[i] = st->ray[i] * (st->depth + 1.0) + rc.C[i];
+    }
+    // per-camera image displacement in parallel, max() is order independent
+    double wd = -DBL_MAX;
+    for (int i = lane; i < camNum; i += 64) {
+        const int ci = st->cam_idx[i];
+        if (ci == st->ref_cam) continue;
+        double p1[2], p2[2];
+        cam_project(sc, ci, c1, p1, 0);
+        cam_project(sc, ci, c2, p2, 0);
+        double dx = p1[0] - p2[0], dy = p1[1] - p2[1];
+        double imgDist = sqrt(dx * dx + dy * dy);
+        double worldDist = 1.0 / imgDist;
+        if (worldDist > wd && imgDist >= 0.01) wd = worldDist;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double o = __shfl_xor(wd, m, 64);
+        wd = o > wd ? o : wd;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        if (wd == -DBL_MAX) {
+            st->dropped = 1;
+        } else {
+            double a = st->depth - wd * sc.cfg.depthRangeScalar;
+            st->depthRange[0] = a > 0.0 ? a : 0.0;
+            double b = wd * sc.cfg.depthRangeScalar, cc = sc.cfg.neighborRadius * 100;
+            st->depthRange[1] = st->depth + (cc < b ? cc : b);
+        }
+    }
+    __syncthreads();
+}
+
+// Patch::setLOD, patch.cpp:511-610
+__device__ void set_lod(const DevScene &sc, pais_patch_result *st, int lane)
+{
+    if (st->dropped) return;
+    if (st->ref_cam < 0) {
+        __syncthreads();
+        if (lane == 0) st->dropped = 1;
+        __syncthreads();
+        return;
+    }
+    const int r = sc.cfg.patchRadius, S = sc.cfg.patchSize, S2 = S * S;
+    const DevCamera &rc = sc.cams[st->ref_cam];
+    double c[3] = {st->center[0], st->center[1], st->center[2]};
+    int LOD = sc.cfg.minLOD - 1;
+    double variance = 0;
+    while (variance < sc.cfg.textureVariation) {
+        LOD++;
+        if (LOD >= rc.maxLOD) {
+            LOD = rc.maxLOD;
+            break;
+        }
+        double pt[2];
+        if (!cam_project(sc, st->ref_cam, c, pt, LOD)) {
+            LOD = (LOD - 1) > 0 ? (LOD - 1) : 0;
+            break;
+        }
+        const int cx = cv_round(pt[0]), cy = cv_round(pt[1]);
+        const int w = rc.w[LOD], h = rc.h[LOD];
+        if (cx - r < 0 || cx + r >= w || cy - r < 0 || cy + r >= h) { // inImage(x, y, LOD) for the whole window
+            LOD = (LOD - 1) > 0 ? (LOD - 1) : 0;
+            break;
+        }
+        const uint8_t *img = rc.img[LOD];
+        int isum = 0;
+        for (int k = lane; k < S2; k += 64) {
+            int yi = k / S, xi = k - yi * S;
+            isum += img[(cy - r + yi) * w + (cx - r + xi)];
+        }
+        isum = wave_sum_i(isum);
+        double mean = (double)isum / (double)S2;
+        double v = 0;
+        for (int k = lane; k < S2; k += 64) {
+            int yi = k / S, xi = k - yi * S;
+            double t = (double)img[(cy - r + yi) * w + (cx - r + xi)];
+            v += (t - mean) * (t - mean);
+        }
+        variance = wave_sum(v) / (double)S2;
+    }
+    __syncthreads();
+    if (lane == 0) st->lod = LOD;
+    __syncthreads();
+}
+
+// Patch::setPriority (patch.cpp:612-625) + Patch::setImagePoint (:627-653, colour is host-side)
+__device__ void set_priority_and_image_point(const DevScene &sc, pais_patch_result *st, int lane)
+{
+    if (st->dropped) return;
+    const int camNum = st->num_cam;
+    double camRatio = ((double)camNum) / ((double)sc.numCams);
+    double pri = st->fitness * det_exp(-st->correlation / 1.0 - camRatio / 1.0) * (st->lod + 1.0);
+    double c[3] = {st->center[0], st->center[1], st->center[2]};
+    __syncthreads();
+    if (lane == 0) st->priority = pri;
+    for (int i = lane; i < camNum; i += 64) {
+        double p[2];
+        cam_project(sc, st->cam_idx[i], c, p, 0);
+        st->imgPoint[i][0] = p[0];
+        st->imgPoint[i][1] = p[1];
+    }
+    __syncthreads();
+}
+
+// Patch::removeInvisibleCamera, patch.cpp:655-721 (with setCorrelationTable :221-267,
+// getHomographyPatch :332-386, getHomographyRegionRatio :269-288).
+//   hp    : global scratch of this workgroup, Kmax*S2 doubles (warped patches)
+//   table : LDS, Kmax*Kmax doubles ; Hn: LDS, Kmax*9 doubles ; tmp: LDS, Kmax doubles
+__device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *st, double *hp, double *table,
+                                        double *Hn, double *tmp, int lane)
+{
+    if (st->dropped) return;
+    const int K = st->num_cam;
+    const int r = sc.cfg.patchRadius, S = sc.cfg.patchSize, S2 = S * S;
+    const int LOD = st->lod, refCam = st->ref_cam;
+    const DevCamera &rc = sc.cams[refCam];
+    const double s = sc.lodScale[LOD];
+    double center[3] = {st->center[0], st->center[1], st->center[2]};
+    double n[3] = {st->normal[0], st->normal[1], st->normal[2]};
+
+    // getHomographies(center, normal, H)
+    {
+        const double d = -dot3(center, n);
+        double Mref[9], invH[9];
+        plane_matrix(d, s, rc.KR, rc.KT, n, Mref);
+        inv3(Mref, invH);
+        for (int c = lane; c < K; c += 64) {
+            double H[9];
+            const int ci = st->cam_idx[c];
+            if (ci == refCam) {
+                H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0; H[6] = 0; H[7] = 0; H[8] = 1;
+            } else {
+                double M[9];
+                plane_matrix(d, s, sc.cams[ci].KR, sc.cams[ci].KT, n, M);
+                mul33(M, invH, H);
+            }
+            for (int i = 0; i < 9; ++i) Hn[c * 9 + i] = H[i];
+        }
+    }
+    for (int i = lane; i < K * K; i += 64) table[i] = 0;
+    __syncthreads();
+
+    double pt[2];
+    cam_project(sc, refCam, center, pt, LOD);
+    const double a0 = pt[0] - r, b0 = pt[1] - r;
+
+    // setCorrelationTable: warped, L2-normalised patches
+    bool dropNow = false;
+    for (int c = 0; c < K && !dropNow; ++c) {
+        const DevCamera &cam = sc.cams[st->cam_idx[c]];
+        const uint8_t *img = cam.img[LOD];
+        const int cw = cam.w[LOD], ch = cam.h[LOD];
+        const double *H = Hn + 9 * c;
+        double *hpc = hp + (size_t)c * S2;
+        double sq = 0;
+        bool bad = false;
+        for (int k = lane; k < S2; k += 64) {
+            const int yi = k / S, xi = k - yi * S;
+            const double x = a0 + (double)xi, y = b0 + (double)yi;
+            const double w = (H[6] * x + H[7] * y + H[8]);
+            const double ix = (H[0] * x + H[1] * y + H[2]) / w;
+            const double iy = (H[3] * x + H[4] * y + H[5]) / w;
+            if (!(ix >= 0 && ix < cw - 1 && iy >= 0 && iy < ch - 1) || w == 0) { // :355
+                bad = true;
+                break;
+            }
+            const double v = bilinear(img, cw, ix, iy);
+            hpc[k] = v;
+            sq += v * v;
+        }
+        if (__any(bad)) {
+            dropNow = true;
+            break;
+        }
+        sq = wave_sum(sq);
+        const double inv = 1.0 / sqrt(sq);
+        for (int k = lane; k < S2; k += 64) hpc[k] = hpc[k] * inv; // hp /= sqrt(sum)
+    }
+    wave_sync();
+    if (lane == 0) st->ncc_tables += 1;
+    if (dropNow) {
+        // patch.cpp:243-247: drop, correlation = 0 (and every later step is a no-op)
+        __syncthreads();
+        if (lane == 0) {
+            st->dropped = 1;
+            st->correlation = 0;
+        }
+        __syncthreads();
+        return;
+    }
+    for (int i = 0; i < K; ++i) {
+        for (int j = i + 1; j < K; ++j) {
+            const double *a = hp + (size_t)i * S2, *b = hp + (size_t)j * S2;
+            double acc = 0;
+            for (int k = lane; k < S2; k += 64) acc += a[k] * b[k];
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                table[i * K + j] = acc;
+                table[j * K + i] = acc;
+            }
+        }
+    }
+    __syncthreads();
+
+    double correlation = 0;
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) correlation += table[i * K + j];
+    correlation /= (double)(K * K - K);
+
+    double maxCorr = -DBL_MAX;
+    int maxIdx = 0;
+    for (int i = 0; i < K; ++i) {
+        double corrSum = 0;
+        for (int j = 0; j < K; ++j) corrSum += table[i * K + j];
+        if (corrSum >= maxCorr) { // last max wins
+            maxIdx = i;
+            maxCorr = corrSum;
+        }
+    }
+    // region ratios, one camera per lane
+    for (int c = lane; c < K; c += 64) {
+        double H[9];
+        for (int i = 0; i < 9; ++i) H[i] = Hn[c * 9 + i];
+        tmp[c] = region_ratio(pt[0], pt[1], r, H);
+    }
+    __syncthreads();
+
+    // mark + erase, keeping order (removeIdx holds distinct camera indices)
+    int newIdx[PAIS_MAX_VIS];
+    int nn = 0;
+    for (int i = 0; i < K; ++i) {
+        bool rem = false;
+        const int ci = st->cam_idx[i];
+        if (tmp[i] < sc.cfg.minRegionRatio) {
+            rem = true;
+        } else {
+            const DevCamera &cam = sc.cams[ci];
+            double dd = n[0] * (-cam.optN[0]) + n[1] * (-cam.optN[1]) + n[2] * (-cam.optN[2]);
+            if (dd < 0) {
+                rem = true;
+            } else if (i != maxIdx && table[maxIdx * K + i] < sc.cfg.minCorrelation) {
+                rem = true;
+            }
+        }
+        if (!rem) newIdx[nn++] = ci;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        st->correlation = correlation;
+        for (int i = 0; i < nn; ++i) st->cam_idx[i] = newIdx[i];
+        st->num_cam = nn;
+        if (nn < sc.cfg.minCamNum) st->dropped = 1;
+    }
+    __syncthreads();
+}
+
+// LDS <-> global copy of a patch record by one wave
+__device__ void copy_record(pais_patch_result *dst, const pais_patch_result *src, int lane)
+{
+    const uint32_t *s = (const uint32_t *)src;
+    uint32_t *d = (uint32_t *)dst;
+    for (int i = lane; i < (int)(sizeof(pais_patch_result) / 4); i += 64) d[i] = s[i];
+}
+
+// ---------------------------------------------------------------- k_begin ---
+// candidate -> record; head of Patch::refine() (patch.cpp:117-136)
+__global__ __launch_bounds__(64) void k_begin(DevScene sc, const pais_candidate *cands, pais_patch_result *recs, int n)
+{
+    __shared__ pais_patch_result st;
+    const int lane = threadIdx.x;
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        const pais_candidate *cd = &cands[c];
+        __syncthreads();
+        {
+            uint32_t *d = (uint32_t *)&st;
+            for (int i = lane; i < (int)(sizeof(pais_patch_result) / 4); i += 64) d[i] = 0;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = 0; i < 3; ++i) {
+                st.center[i] = cd->center[i];
+                st.normal[i] = cd->normal[i];
+            }
+            st.normalS[0] = cd->normalS[0];
+            st.normalS[1] = cd->normalS[1];
+            st.key = cd->key;
+            st.type = cd->type;
+            int nc = cd->num_cam;
+            st.num_cam = nc > PAIS_MAX_VIS ? PAIS_MAX_VIS : (nc < 0 ? 0 : nc);
+            st.ref_cam = -1;
+            st.lod = -1;
+            st.fitness = DBL_MAX;   // abstractpatch.cpp:37-38
+            st.priority = DBL_MAX;
+            st.correlation = 0;
+            st.stage = PAIS_STAGE_DONE;
+        }
+        __syncthreads();
+        for (int i = lane; i < st.num_cam; i += 64) st.cam_idx[i] = cd->cam_idx[i];
+        __syncthreads();
+
+        if (st.num_cam < sc.cfg.minCamNum) { // patch.cpp:118-123
+            if (lane == 0) {
+                st.fitness = DBL_MAX;
+                st.priority = DBL_MAX;
+                st.dropped = 1;
+            }
+        } else {
+            set_reference_camera(sc, &st, lane);
+            set_depth_and_ray(sc, &st, lane);
+            set_depth_range(sc, &st, lane);
+            set_lod(sc, &st, lane);
+            if (!st.dropped) {
+                // patch.cpp:132-150: first evaluation of the while condition is always true
+                __syncthreads();
+                if (lane == 0) {
+                    st.before_ref = st.ref_cam;
+                    st.after_ref = -1;
+                    st.before_num = st.num_cam;
+                    st.after_num = -1;
+                    st.total_cam_num = st.num_cam;
+                    st.count = 1; // count++ evaluated once
+                    st.stage = PAIS_STAGE_PSO;
+                }
+            }
+        }
+        __syncthreads();
+        copy_record(&recs[c], &st, lane);
+    }
+}
+
+// ------------------------------------------------------------------ k_pso ---
+// One workgroup per candidate (pulled from a global counter: PSO runs converge
+// after a data-dependent number of iterations, patch.cpp:180-219 + psosolver.cpp).
+struct PsoHeader {
+    double rangeL[3], rangeU[3], rangeInter[3], init[3];
+    double iw, gBestFitness;
+    uint64_t streamBase;
+    int gIdx, N, maxIt, iteration, conv, cur, run, localK;
+    EvalPatch ep;
+};
+
+__global__ __launch_bounds__(512) void k_pso(DevScene sc, pais_patch_result *recs, int n, int *counters,
+                                              unsigned long long *stat, int Kmax, int Nmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6, T = blockDim.x;
+    // carve
+    PsoHeader *hd = (PsoHeader *)smem;
+    size_t off = (sizeof(PsoHeader) + 15) & ~(size_t)15;
+    double(*pos)[3] = (double(*)[3])(smem + off); off += sizeof(double) * 3 * Nmax;
+    double(*vec)[3] = (double(*)[3])(smem + off); off += sizeof(double) * 3 * Nmax;
+    double(*pBest)[3] = (double(*)[3])(smem + off); off += sizeof(double) * 3 * Nmax;
+    double(*nBest)[3] = (double(*)[3])(smem + off); off += sizeof(double) * 3 * Nmax;
+    double *fit = (double *)(smem + off); off += sizeof(double) * Nmax;
+    double *pBestFit = (double *)(smem + off); off += sizeof(double) * Nmax;
+    EvalCam *cams = (EvalCam *)(smem + off); off += sizeof(EvalCam) * Kmax;
+    double *Hall = (double *)(smem + off); off += sizeof(double) * 9 * Kmax * W;
+    double *call = (double *)(smem + off);
+    double *Hbuf = Hall + (size_t)wave * 9 * Kmax;
+    double *cbuf = call + (size_t)wave * 64 * Kmax;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) hd->cur = atomicAdd(&counters[0], 1);
+        __syncthreads();
+        const int c = hd->cur;
+        if (c >= n) break;
+        pais_patch_result *P = &recs[c];
+        if (P->stage != PAIS_STAGE_PSO || P->dropped) continue;
+
+        // ---- Patch::psoOptimization set-up (patch.cpp:183-200)
+        const int type = P->type;
+        const int N = (type == PAIS_TYPE_SEED) ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
+        const int maxIt = (type == PAIS_TYPE_SEED) ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
+        if (tid == 0) {
+            const double ns0 = P->normalS[0], ns1 = P->normalS[1];
+            double L[3] = {0.0, ns1 - M_PI / 2.0, P->depthRange[0]};
+            double U[3] = {M_PI, ns1 + M_PI / 2.0, P->depthRange[1]};
+            if (type != PAIS_TYPE_SEED) {
+                double lo = ns0 - M_PI / sc.cfg.reduceNormalRange, hi = ns0 + M_PI / sc.cfg.reduceNormalRange;
+                L[0] = 0.0 < lo ? lo : 0.0;
+                U[0] = hi < M_PI ? hi : M_PI;
+                L[1] = ns1 - M_PI / sc.cfg.reduceNormalRange;
+                U[1] = ns1 + M_PI / sc.cfg.reduceNormalRange;
+            }
+            for (int d = 0; d < 3; ++d) {
+                hd->rangeL[d] = L[d];
+                hd->rangeU[d] = U[d];
+                hd->rangeInter[d] = U[d] - L[d]; // psosolver.cpp:38
+            }
+            hd->init[0] = ns0; hd->init[1] = ns1; hd->init[2] = P->depth;
+            hd->N = N;
+            hd->maxIt = maxIt;
+            hd->localK = N < 5 ? N : 5; // psosolver.cpp:26
+            hd->run = P->pso_runs;
+            hd->streamBase = stream_base(sc.seed, P->key);
+            hd->iw = 0.8;
+        }
+        fill_eval_patch(sc, &hd->ep, cams, P->ray, P->ref_cam, P->lod, P->num_cam, P->cam_idx, tid, T);
+        __syncthreads();
+
+        // ---- initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
+        {
+            const uint64_t sb = hd->streamBase;
+            const uint32_t run = (uint32_t)hd->run;
+            for (int i = tid; i < N; i += T) {
+                for (int d = 0; d < 3; ++d) {
+                    const double ri = hd->rangeInter[d];
+                    const double u1 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i)));
+                    const double u2 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i) + 1));
+                    double p = (ri * u1) + hd->rangeL[d];
+                    double v = (2.0 * ri * u2) - ri;
+                    if (i == 0) {
+                        p = hd->init[d];
+                        v = (2.0 * ri * uniform_from(sb, run, (uint32_t)(6 * N + d))) - ri;
+                    }
+                    pos[i][d] = p;
+                    vec[i][d] = v;
+                    pBest[i][d] = p;
+                    nBest[i][d] = 0; // particle.cpp:16
+                }
+            }
+        }
+        __syncthreads();
+        // ---- initFitness (:112-119)
+        for (int i = wave; i < N; i += W) {
+            double v = eval_fitness(sc, &hd->ep, cams, Hbuf, cbuf, pos[i][0], pos[i][1], pos[i][2], lane);
+            if (lane == 0) {
+                fit[i] = v;
+                pBestFit[i] = v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { // run(): gBest = particles[0].pBest; updateGbest (:137-149, '<=' -> last min)
+            int g = 0;
+            double gf = pBestFit[0];
+            for (int j = 0; j < N; ++j)
+                if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
+            hd->gIdx = g;
+            hd->gBestFitness = gf;
+        }
+        __syncthreads();
+
+        int it = 0;
+        for (; it < maxIt; ++it) {
+            if (tid == 0) { // getDispersionIDX / getVelocityIDX (:70-92), break test (:295)
+                const int g = hd->gIdx;
+                const double g0 = pBest[g][0], g1 = pBest[g][1], g2 = pBest[g][2];
+                double disp = 0;
+                for (int i = 0; i < N; ++i) {
+                    disp += fabs(pos[i][0] - g0);
+                    disp += fabs(pos[i][1] - g1);
+                    disp += fabs(pos[i][2] - g2);
+                }
+                disp /= (double)(3 * N);
+                int conv = 0;
+                if (disp < 0.01) {
+                    double vel = 0;
+                    for (int i = 0; i < N; ++i) {
+                        vel += fabs(vec[i][0]);
+                        vel += fabs(vec[i][1]);
+                        vel += fabs(vec[i][2]);
+                    }
+                    vel /= (double)(3 * N);
+                    conv = vel < 0.01;
+                }
+                hd->conv = conv;
+            }
+            __syncthreads();
+            if (hd->conv) break;
+            // ---- moveParticles (:220-265)
+            {
+                const int g = hd->gIdx;
+                const double gB[3] = {pBest[g][0], pBest[g][1], pBest[g][2]};
+                const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
+                const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
+                const uint64_t sb = hd->streamBase;
+                const uint32_t run = (uint32_t)hd->run;
+                const double iw = hd->iw;
+                const int localK = hd->localK;
+                for (int i = tid; i < N; i += T) {
+                    double u[4];
+                    const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
+                    for (int q = 0; q < 4; ++q) u[q] = uniform_from(sb, run, k0 + q);
+                    pso_move_particle(i, N, localK, iw, u, pos, vec, pBest, nBest, fit, pBestFit, gB, rl, ru);
+                }
+            }
+            __syncthreads();
+            // ---- updateFitness (:121-135)
+            for (int i = wave; i < N; i += W) {
+                double v = eval_fitness(sc, &hd->ep, cams, Hbuf, cbuf, pos[i][0], pos[i][1], pos[i][2], lane);
+                if (lane == 0) {
+                    fit[i] = v;
+                    if (v < pBestFit[i]) {
+                        pBestFit[i] = v;
+                        pBest[i][0] = pos[i][0];
+                        pBest[i][1] = pos[i][1];
+                        pBest[i][2] = pos[i][2];
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { // updateGbest + inertia schedule (:301-304)
+                int g = hd->gIdx;
+                double gf = hd->gBestFitness;
+                for (int j = 0; j < N; ++j)
+                    if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
+                hd->gIdx = g;
+                hd->gBestFitness = gf;
+                double niw = hd->iw - 1.0 / maxIt;
+                hd->iw = niw > 0.4 ? niw : 0.4;
+            }
+            __syncthreads();
+        }
+
+        // ---- write back (patch.cpp:208-213) and the maxFitness gate (:156-159)
+        if (tid == 0) {
+            const int g = hd->gIdx;
+            const double fitness = hd->gBestFitness;
+            const double th = pBest[g][0], ph = pBest[g][1], dp = pBest[g][2];
+            double nn[3];
+            spherical2normal(th, ph, nn);
+            P->fitness = fitness;
+            P->normalS[0] = th;
+            P->normalS[1] = ph;
+            for (int i = 0; i < 3; ++i) P->normal[i] = nn[i];
+            P->depth = dp;
+            for (int i = 0; i < 3; ++i) P->center[i] = hd->ep.ray[i] * dp + hd->ep.Cref[i];
+            P->pso_runs += 1;
+            P->pso_iterations += it;
+            const int evals = N * (1 + it);
+            P->pso_evals += evals;
+            if (fitness > sc.cfg.maxFitness) {
+                P->dropped = 1;
+                P->stage = PAIS_STAGE_DONE;
+            } else {
+                P->stage = PAIS_STAGE_AFTER;
+            }
+            const int K = hd->ep.K;
+            const unsigned long long perEval = (unsigned long long)(4 * K + 1 + (sc.cfg.adaptiveDistanceEnable ? 8 : 0) +
+                                                                    (sc.cfg.adaptiveGradientEnable ? 8 : 0));
+            atomicAdd(&stat[0], (unsigned long long)evals);
+            atomicAdd(&stat[1], (unsigned long long)evals * perEval);
+            atomicAdd(&stat[2], 1ULL);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- k_after ---
+// After one PSO run: patch.cpp:161-175 (+ the caller's removeInvisibleCamera,
+// mvs.cpp:215 / :574, once the refine loop has ended).
+__global__ __launch_bounds__(64) void k_after(DevScene sc, pais_patch_result *recs, int n, double *hpScratch,
+                                              int *counters, unsigned long long *stat, int Kmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    pais_patch_result *st = (pais_patch_result *)smem;
+    size_t off = (sizeof(pais_patch_result) + 15) & ~(size_t)15;
+    double *table = (double *)(smem + off); off += sizeof(double) * Kmax * Kmax;
+    double *Hn = (double *)(smem + off); off += sizeof(double) * 9 * Kmax;
+    double *tmp = (double *)(smem + off);
+    const int lane = threadIdx.x;
+    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    double *hp = hpScratch + (size_t)blockIdx.x * Kmax * S2;
+
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        if (recs[c].stage != PAIS_STAGE_AFTER) continue;
+        __syncthreads();
+        copy_record(st, &recs[c], lane);
+        __syncthreads();
+
+        const int nccBefore = st->ncc_tables;
+        remove_invisible_camera(sc, st, hp, table, Hn, tmp, lane);
+        set_reference_camera(sc, st, lane);
+        set_depth_and_ray(sc, st, lane);
+        set_depth_range(sc, st, lane);
+        set_lod(sc, st, lane);
+
+        bool again = false;
+        if (st->type != PAIS_TYPE_EXPAND && !st->dropped) {
+            // patch.cpp:170-171 then the while condition of :140
+            const int afterRef = st->ref_cam, afterNum = st->num_cam;
+            const int cnt = st->count;
+            const bool cond = (st->before_ref != afterRef || st->before_num != afterNum) && (cnt <= st->total_cam_num);
+            __syncthreads();
+            if (lane == 0) {
+                st->after_ref = afterRef;
+                st->after_num = afterNum;
+                st->count = cnt + 1; // count++ is evaluated whenever the first operand is true ... (see note)
+            }
+            __syncthreads();
+            if (cond) {
+                if (st->num_cam < sc.cfg.minCamNum) { // :142-147
+                    __syncthreads();
+                    if (lane == 0) {
+                        st->fitness = DBL_MAX;
+                        st->priority = DBL_MAX;
+                        st->dropped = 1;
+                    }
+                    __syncthreads();
+                } else {
+                    again = true;
+                    __syncthreads();
+                    if (lane == 0) {
+                        st->before_ref = st->ref_cam;
+                        st->before_num = st->num_cam;
+                        st->stage = PAIS_STAGE_PSO;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (!again) {
+            set_priority_and_image_point(sc, st, lane);
+            remove_invisible_camera(sc, st, hp, table, Hn, tmp, lane); // mvs.cpp:215 / :574
+            __syncthreads();
+            if (lane == 0) st->stage = PAIS_STAGE_DONE;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            if (again) atomicAdd(&counters[1], 1);
+            atomicAdd(&stat[3], (unsigned long long)(st->ncc_tables - nccBefore));
+            atomicAdd(&stat[4], (unsigned long long)(st->ncc_tables - nccBefore) * (unsigned long long)st->total_cam_num);
+        }
+        copy_record(&recs[c], st, lane);
+    }
+}
+
+// --------------------------------------------------------------- launchers ---
+namespace pais_launch {
+
+static size_t pso_lds_bytes(int W, int Kmax, int Nmax)
+{
+    size_t off = (sizeof(PsoHeader) + 15) & ~(size_t)15;
+    off += sizeof(double) * 3 * Nmax * 4;
+    off += sizeof(double) * Nmax * 2;
+    off += sizeof(EvalCam) * Kmax;
+    off += sizeof(double) * 9 * Kmax * W;
+    off += sizeof(double) * 64 * Kmax * W;
+    return off;
+}
+static size_t after_lds_bytes(int Kmax)
+{
+    size_t off = (sizeof(pais_patch_result) + 15) & ~(size_t)15;
+    off += sizeof(double) * Kmax * Kmax;
+    off += sizeof(double) * 9 * Kmax;
+    off += sizeof(double) * Kmax;
+    return off;
+}
+static size_t fitness_lds_bytes(int Kmax)
+{
+    return sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * Kmax;
+}
+
+hipError_t fitness(const DevScene &sc, const pais_patch_state *states, const int32_t *idx, const double *particles,
+                   double *out, int nEvals, int Kmax, hipStream_t stream)
+{
+    if (nEvals <= 0) return hipSuccess;
+    size_t lds = fitness_lds_bytes(Kmax);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_fitness, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int grid = nEvals < 65536 ? nEvals : 65536;
+    hipLaunchKernelGGL(k_fitness, dim3(grid), dim3(64), lds, stream, sc, states, idx, particles, out, nEvals, Kmax);
+    return hipGetLastError();
+}
+
+hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    int grid = n < 16384 ? n : 16384;
+    hipLaunchKernelGGL(k_begin, dim3(grid), dim3(64), 0, stream, sc, cands, recs, n);
+    return hipGetLastError();
+}
+
+// picks the waves-per-workgroup so that particles divide evenly and the LDS fits
+int pso_waves(int N, int Kmax, int Nmax, size_t ldsLimit)
+{
+    int best = 1;
+    double bestScore = -1;
+    for (int W = 1; W <= 8; ++W) {
+        if (pso_lds_bytes(W, Kmax, Nmax) > ldsLimit) break;
+        int per = (N + W - 1) / W;
+        double eff = (double)N / (double)(per * W); // idle-wave efficiency
+        // prefer ~4..8 waves: enough waves to hide gather latency, several workgroups per CU
+        double score = eff - 0.02 * (W > 8 ? (W - 8) : 0) - 0.03 * (W < 4 ? (4 - W) : 0);
+        if (score > bestScore + 1e-9) {
+            bestScore = score;
+            best = W;
+        }
+    }
+    return best;
+}
+
+hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters, unsigned long long *stat, int Kmax,
+               int Nmax, int W, int grid, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    size_t lds = pso_lds_bytes(W, Kmax, Nmax);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_pso, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_pso, dim3(grid), dim3(64 * W), lds, stream, sc, recs, n, counters, stat, Kmax, Nmax);
+    return hipGetLastError();
+}
+size_t pso_lds(int W, int Kmax, int Nmax) { return pso_lds_bytes(W, Kmax, Nmax); }
+
+hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
+                 unsigned long long *stat, int Kmax, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    size_t lds = after_lds_bytes(Kmax);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_after, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_after, dim3(grid), dim3(64), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax);
+    return hipGetLastError();
+}
+
+} // namespace pais_launch

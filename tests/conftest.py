@@ -1,0 +1,45 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+HAS_GPU = _has_gpu()
+
+
+def pytest_collection_modifyitems(config, items):
+    if HAS_GPU:
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def pawn_small():
+    """Small pawn scene (5 README cameras, 320x240) shared by CPU and GPU tests."""
+    from pais_mvs_amd import synth
+    return synth.pawn_scene(width=320, height=240, n_seeds=24)
+
+
+@pytest.fixture(scope="session")
+def pawn_full():
+    from pais_mvs_amd import synth
+    return synth.pawn_scene(n_seeds=60)
