@@ -45,7 +45,9 @@ typedef struct pais_mvs_stats {
 } pais_mvs_stats;
 
 /* Creates the driver and its own pais_ctx on `device` (MVS::getInstance(config),
- * mvs.cpp:22-34 + loading the cameras). */
+ * mvs.cpp:22-34 + loading the cameras).  device < 0 creates the scheduler without
+ * a GPU context: only the stepwise entry points work then (records must come from
+ * a rank that has a GPU); nothing is ever computed on the host instead. */
 int  pais_mvs_create(const pais_config *cfg, int num_cams, const pais_camera_desc *cams,
                      int device, uint64_t pso_seed, pais_mvs **out);
 void pais_mvs_destroy(pais_mvs *m);
@@ -79,6 +81,7 @@ int    pais_mvs_num_slots(const pais_mvs *m);        /* ids are 0 .. slots-1 */
 int    pais_mvs_get_patch(const pais_mvs *m, int id, pais_patch_result *out, int *expanded);
 double pais_mvs_neighbor_radius(const pais_mvs *m);
 int    pais_mvs_get_stats(const pais_mvs *m, pais_mvs_stats *out);
+const char *pais_mvs_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,9 @@
 // double +,-,*,/ only -- identical bits on x86-64 and gfx950 as long as FP
 // contraction is off.  Accuracy < 1 ulp, i.e. within libm-to-libm variability.
 #pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 #include <string.h>
 

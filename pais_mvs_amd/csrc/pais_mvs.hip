@@ -1,0 +1,713 @@
+// pais_mvs.hip -- host-side reconstruction driver (no device code in this file):
+// the MI355X drop-in behind MVS::refineSeedPatches() / MVS::expansionPatches()
+// (TMVS/mvs/mvs.cpp:196-275).  Mirrors the reference's MVS / CellMap / Patch
+// bookkeeping (mvs.cpp:529-898, cellmap.cpp) and forwards every batch of
+// constructed-but-unrefined patches to pais_refine_batch().
+//
+// Host data structures are re-designed for 1e5..1e7 patches:
+//   * cell maps: one dense int32 "head" array per camera + pooled singly linked
+//     entries (the reference's vector<vector<vector<int>>> costs 24 B per empty
+//     cell; the order inside a cell is irrelevant to every query the path makes)
+//   * priority queue: binary heap keyed (priority, insertion sequence) with lazy
+//     deletion -- the reference scans a vector<int> per pop (O(n^2), mvs.cpp:656-693);
+//     ties resolve to the earliest queued id exactly as its strict '<' scan does.
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <deque>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "../../include/pais_mvs.h"
+#include "pais_dev.hpp"
+
+namespace {
+
+inline int cv_round_h(double v) { return (int)lrint(v); }            // cvRound
+inline int cv_ceil_h(double v) { int i = (int)v; return i + (i < v); } // cvCeil (cellmap.cpp:7-8)
+inline double dot3h(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct HostCamera { // what the driver needs of PAIS::Camera (camera.h)
+    double focal[2], pp[2], R[9], T[3], C[3], optN[3];
+    int w0, h0;
+    std::vector<uint8_t> img0; // LOD-0 gray image: background test of runtimeFiltering (mvs.cpp:853-862)
+};
+
+struct HostPatch { // AbstractPatch fields the expansion loop reads (abstractpatch.h:22-53)
+    pais_patch_result r;
+    int id;
+    bool expanded;
+    bool doomed; // popped this round and failing runtimeFiltering: treated as absent while enumerating
+};
+
+struct CellEntry { int id, next; };
+
+class CellMap { // cellmap.h:15-32
+public:
+    int width = 0, height = 0;
+    std::vector<int32_t> head;
+    void init(int w, int h) { width = w; height = h; head.assign((size_t)w * h, -1); }
+    bool inMap(int x, int y) const { return !(x < 0 || y < 0 || x >= width || y >= height); } // cellmap.cpp:18-23
+};
+
+struct Candidate { // one (parent, visible camera slot, 4-neighbour) cell
+    int parentSlot; // index into the round's parent list
+    int i, j;       // camera slot of the parent, neighbour 0..3
+    int cam, cx, cy;
+};
+
+struct QItem {
+    double pri;
+    uint64_t seq;
+    int id;
+};
+struct BestFirst { bool operator()(const QItem &a, const QItem &b) const { return a.pri > b.pri || (a.pri == b.pri && a.seq > b.seq); } };
+struct WorstFirst { bool operator()(const QItem &a, const QItem &b) const { return a.pri < b.pri || (a.pri == b.pri && a.seq > b.seq); } };
+
+} // namespace
+
+struct pais_mvs {
+    pais_config cfg;
+    pais_ctx *ctx = nullptr;
+    std::vector<HostCamera> cams;
+    std::vector<HostPatch *> patches; // index == id; nullptr once deleted  (map<int,Patch>, mvs.h:86)
+    int alive = 0;
+    std::vector<CellMap> cellMaps;     // mvs.h:88 (empty until setCellMaps)
+    std::vector<CellEntry> pool;
+    int freeEntry = -1;
+    std::priority_queue<QItem, std::vector<QItem>, BestFirst> qBest;
+    std::priority_queue<QItem, std::vector<QItem>, WorstFirst> qWorst;
+    std::deque<int> qList;             // breadth / depth strategies keep the literal container
+    uint64_t qSeq = 0;
+    long liveQueued = 0;               // alive, unexpanded, queued patches == the reference's queue.size() after a pop
+    double neighborRadius = 0;
+    // round state
+    std::vector<int> parents;
+    std::vector<char> parentOk;
+    std::vector<Candidate> cands;
+    std::vector<pais_candidate> candRecs;
+    std::vector<pais_patch_result> results;
+    std::vector<int> seedIds;
+    bool strictTail = true;
+    pais_mvs_stats st;
+    std::string err;
+
+    ~pais_mvs()
+    {
+        for (auto *p : patches) delete p;
+        if (ctx) pais_ctx_destroy(ctx);
+    }
+
+    // ---- Camera::project / inImage (camera.cpp:138-160, camera.h:116-131), LOD 0
+    bool project0(int cam, const double *X, double *out) const
+    {
+        const HostCamera &c = cams[cam];
+        pais::project_raw(c.R, c.T, c.focal, c.pp, 1.0, X, out);
+        return pais::in_image_d(out, c.w0, c.h0);
+    }
+
+    // ---- cell maps
+    int cellCount(const CellMap &m, int x, int y) const
+    {
+        int n = 0;
+        for (int e = m.head[(size_t)y * m.width + x]; e >= 0; e = pool[e].next) ++n;
+        return n;
+    }
+    bool cellInsert(CellMap &m, int x, int y, int id) // cellmap.cpp:25-29
+    {
+        if (!m.inMap(x, y)) return false;
+        int e;
+        if (freeEntry >= 0) { e = freeEntry; freeEntry = pool[e].next; }
+        else { e = (int)pool.size(); pool.push_back(CellEntry()); }
+        int32_t &h = m.head[(size_t)y * m.width + x];
+        pool[e].id = id;
+        pool[e].next = h;
+        h = e;
+        return true;
+    }
+    bool cellDrop(CellMap &m, int x, int y, int id) // cellmap.cpp:31-38
+    {
+        if (!m.inMap(x, y)) return false;
+        int32_t *link = &m.head[(size_t)y * m.width + x];
+        while (*link >= 0) {
+            int e = *link;
+            if (pool[e].id == id) {
+                *link = pool[e].next;
+                pool[e].next = freeEntry;
+                freeEntry = e;
+                return true;
+            }
+            link = &pool[e].next;
+        }
+        return false;
+    }
+
+    // ---- Patch::isNeighbor, patch.cpp:6-23
+    bool isNeighbor(const pais_patch_result &a, const pais_patch_result &b) const
+    {
+        double d[3] = {a.center[0] - b.center[0], a.center[1] - b.center[1], a.center[2] - b.center[2]};
+        double dist = 0;
+        dist += fabs(dot3h(d, a.normal));
+        dist += fabs(dot3h(d, b.normal));
+        return dist <= neighborRadius;
+    }
+
+    // ---- MVS::skipNeighborCell, mvs.cpp:792-807 (ignoreDoomed: enumeration view of the round)
+    bool skipNeighborCell(const CellMap &m, int x, int y, const pais_patch_result &ref, bool ignoreDoomed) const
+    {
+        int pthNum = 0;
+        for (int e = m.head[(size_t)y * m.width + x]; e >= 0; e = pool[e].next) {
+            const HostPatch *p = patches[pool[e].id];
+            if (ignoreDoomed && p && p->doomed) continue;
+            ++pthNum;
+        }
+        if (pthNum >= cfg.maxCellPatchNum) return true;
+        for (int e = m.head[(size_t)y * m.width + x]; e >= 0; e = pool[e].next) {
+            const HostPatch *p = patches[pool[e].id];
+            if (!p) continue;
+            if (ignoreDoomed && p->doomed) continue;
+            if (p->r.correlation > cfg.minCorrelation) return true;
+            if (isNeighbor(ref, p->r)) return true;
+        }
+        return false;
+    }
+
+    // ---- MVS::getExpansionPatchCenter, mvs.cpp:809-836
+    void expansionCenter(int camI, const pais_patch_result &parent, int cx, int cy, double *center) const
+    {
+        const HostCamera &cam = cams[camI];
+        const double px = (cx + 0.5) * cfg.cellSize;
+        const double py = (cy + 0.5) * cfg.cellSize;
+        double p3d[3], tmp[3];
+        p3d[0] = (px - cam.pp[0]) / cam.focal[0];
+        p3d[1] = (py - cam.pp[1]) / cam.focal[1];
+        p3d[2] = 1.0;
+        for (int i = 0; i < 3; ++i) tmp[i] = p3d[i] - cam.T[i];
+        for (int i = 0; i < 3; ++i) p3d[i] = cam.R[0 * 3 + i] * tmp[0] + cam.R[1 * 3 + i] * tmp[1] + cam.R[2 * 3 + i] * tmp[2];
+        double v13[3], v12[3];
+        for (int i = 0; i < 3; ++i) v13[i] = parent.center[i] - cam.C[i];
+        for (int i = 0; i < 3; ++i) v12[i] = p3d[i] - cam.C[i];
+        const double u = dot3h(parent.normal, v13) / dot3h(parent.normal, v12);
+        for (int i = 0; i < 3; ++i) center[i] = cam.C[i] + u * v12[i];
+    }
+
+    // ---- Patch(center, parent) constructor, patch.cpp:36-43 incl. expandVisibleCamera :723-761
+    void makeExpandCandidate(const pais_patch_result &parent, const double *center, uint64_t key, pais_candidate *c) const
+    {
+        memset(c, 0, sizeof(*c));
+        for (int i = 0; i < 3; ++i) { c->center[i] = center[i]; c->normal[i] = parent.normal[i]; }
+        pais::normal2spherical(c->normal, c->normalS); // setNormal(Vec3d), abstractpatch.cpp:43-46
+        c->key = key;
+        c->type = PAIS_TYPE_EXPAND;
+        int exp[PAIS_MAX_VIS * 2];
+        int n = 0;
+        for (int i = 0; i < (int)cams.size(); ++i) {
+            double neg[3] = {-cams[i].optN[0], -cams[i].optN[1], -cams[i].optN[2]};
+            if (dot3h(c->normal, neg) >= cfg.visibleCorrelation && n < PAIS_MAX_VIS) exp[n++] = i;
+        }
+        if (n < cfg.minCamNum) {
+            for (int i = 0; i < parent.num_cam; ++i) {
+                const HostCamera &cam = cams[parent.cam_idx[i]];
+                double neg[3] = {-cam.optN[0], -cam.optN[1], -cam.optN[2]};
+                if (dot3h(c->normal, neg) >= cfg.visibleCorrelation / 2.0 && n < PAIS_MAX_VIS * 2) exp[n++] = parent.cam_idx[i];
+            }
+            std::sort(exp, exp + n);
+            n = (int)(std::unique(exp, exp + n) - exp);
+        }
+        if (n > PAIS_MAX_VIS) n = PAIS_MAX_VIS;
+        c->num_cam = n; // < minCamNum => refine() drops it (patch.cpp:118-123), as `drop` would
+        for (int i = 0; i < n; ++i) c->cam_idx[i] = exp[i];
+    }
+
+    // ---- MVS::runtimeFiltering, mvs.cpp:838-898
+    bool runtimeFiltering(const pais_patch_result &p, int id) const
+    {
+        if (p.dropped) return false;
+        if (p.num_cam < cfg.minCamNum) return false;
+        if (p.fitness > cfg.maxFitness) return false;
+        if (p.fitness == 0.0) return false;
+        if (p.priority > 10000) return false;
+        if (std::isnan(p.fitness)) return false;
+        if (std::isnan(p.priority)) return false;
+        if (std::isnan(p.correlation)) return false;
+        if (p.correlation < cfg.minCorrelation) return false;
+        double pt[2];
+        for (int i = 0; i < (int)cams.size(); i++) {
+            if (!project0(i, p.center, pt)) return false;
+            const HostCamera &cam = cams[i];
+            if (cam.img0[(size_t)cv_round_h(pt[1]) * cam.w0 + cv_round_h(pt[0])] == 0) return false;
+        }
+        int count = 0;
+        for (int i = 0; i < p.num_cam; ++i) {
+            const HostCamera &cam = cams[p.cam_idx[i]];
+            double neg[3] = {-cam.optN[0], -cam.optN[1], -cam.optN[2]};
+            if (dot3h(p.normal, neg) > 0) count++;
+        }
+        if (count < cfg.minCamNum) return false;
+        if (cellMaps.empty()) return true;
+        int fullCellCounter = 0;
+        for (int i = 0; i < p.num_cam; ++i) {
+            int cx = (int)(p.imgPoint[i][0] / cfg.cellSize);
+            int cy = (int)(p.imgPoint[i][1] / cfg.cellSize);
+            const CellMap &m = cellMaps[p.cam_idx[i]];
+            if (!m.inMap(cx, cy)) continue;
+            bool found = false;
+            int n = 0;
+            for (int e = m.head[(size_t)cy * m.width + cx]; e >= 0; e = pool[e].next) {
+                ++n;
+                if (pool[e].id == id) found = true;
+            }
+            if (found) return true;
+            if (n >= cfg.maxCellPatchNum) ++fullCellCounter;
+        }
+        if (fullCellCounter >= p.num_cam) return false;
+        return true;
+    }
+
+    int storePatch(const pais_patch_result &r)
+    {
+        HostPatch *hp = new HostPatch();
+        hp->r = r;
+        hp->id = (int)patches.size();
+        hp->expanded = false;
+        hp->doomed = false;
+        patches.push_back(hp);
+        ++alive;
+        return hp->id;
+    }
+
+    void queuePush(int id)
+    {
+        QItem q{patches[id]->r.priority, qSeq++, id};
+        switch (cfg.expansionStrategy) {
+        default:
+        case 0: qBest.push(q); break;
+        case 1: qWorst.push(q); break;
+        case 2:
+        case 3: qList.push_back(id); break;
+        }
+        ++liveQueued;
+    }
+    bool queueLive(int id) const { return id >= 0 && id < (int)patches.size() && patches[id] && !patches[id]->expanded; }
+    // MVS::getPatchIdFromQueue (mvs.cpp:632-788)
+    int queuePop()
+    {
+        int id = -1;
+        switch (cfg.expansionStrategy) {
+        default:
+        case 0:
+            while (!qBest.empty()) { QItem q = qBest.top(); qBest.pop(); if (queueLive(q.id)) { id = q.id; break; } }
+            break;
+        case 1:
+            while (!qWorst.empty()) { QItem q = qWorst.top(); qWorst.pop(); if (queueLive(q.id)) { id = q.id; break; } }
+            break;
+        case 2: // breadth first :734-759
+            while (!qList.empty()) { int q = qList.front(); qList.pop_front(); if (queueLive(q)) { id = q; break; } }
+            break;
+        case 3: { // depth first :761-788 -- never examines queue[0]
+            while (qList.size() > 1) {
+                int q = qList.back();
+                if (!queueLive(q)) { qList.pop_back(); continue; }
+                id = q;
+                qList.pop_back();
+                break;
+            }
+            if (id < 0 && !qList.empty()) qList.pop_front(); // queue.erase(begin) with topId == -1
+            break;
+        }
+        }
+        if (id >= 0) --liveQueued;
+        return id;
+    }
+
+    // ---- MVS::deletePatch, mvs.cpp:603-630
+    void deletePatch(int id)
+    {
+        HostPatch *p = (id >= 0 && id < (int)patches.size()) ? patches[id] : nullptr;
+        if (!p) return;
+        if (!cellMaps.empty()) {
+            for (int i = 0; i < p->r.num_cam; ++i) {
+                int cx = (int)(p->r.imgPoint[i][0] / cfg.cellSize);
+                int cy = (int)(p->r.imgPoint[i][1] / cfg.cellSize);
+                cellDrop(cellMaps[p->r.cam_idx[i]], cx, cy, id);
+            }
+        }
+        delete p;
+        patches[id] = nullptr;
+        --alive;
+        st.patches_deleted++;
+    }
+
+    // ---- MVS::insertPatch, mvs.cpp:579-601
+    bool insertPatch(const pais_patch_result &r)
+    {
+        const int newId = (int)patches.size();
+        if (!runtimeFiltering(r, newId)) return false;
+        int id = storePatch(r);
+        queuePush(id);
+        for (int i = 0; i < r.num_cam; ++i) {
+            int cx = (int)(r.imgPoint[i][0] / cfg.cellSize);
+            int cy = (int)(r.imgPoint[i][1] / cfg.cellSize);
+            cellInsert(cellMaps[r.cam_idx[i]], cx, cy, id);
+        }
+        st.patches_inserted++;
+        return true;
+    }
+
+    // ---- MVS::setNeighborRadius + getBoundingVolume, mvs.cpp:147-152, 974-997
+    void setNeighborRadius()
+    {
+        double minP[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, maxP[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+        for (auto *p : patches) {
+            if (!p) continue;
+            for (int i = 0; i < 3; ++i) {
+                if (p->r.center[i] < minP[i]) minP[i] = p->r.center[i];
+                if (p->r.center[i] > maxP[i]) maxP[i] = p->r.center[i];
+            }
+        }
+        double vol[3] = {maxP[0] - minP[0], maxP[1] - minP[1], maxP[2] - minP[2]};
+        double volume = fabs(vol[0] * vol[1] * vol[2]);
+        neighborRadius = pow(volume, 1.0 / 3.0) * cfg.neighborRadiusScalar;
+        cfg.neighborRadius = neighborRadius;
+        if (ctx) pais_ctx_set_neighbor_radius(ctx, neighborRadius);
+    }
+
+    // ---- MVS::setCellMaps + initPriorityQueue, mvs.cpp:89-95, 116-133
+    void setCellMaps()
+    {
+        cellMaps.assign(cams.size(), CellMap());
+        pool.clear();
+        freeEntry = -1;
+        for (size_t c = 0; c < cams.size(); ++c)
+            cellMaps[c].init(cv_ceil_h((double)cams[c].w0 / (double)cfg.cellSize), cv_ceil_h((double)cams[c].h0 / (double)cfg.cellSize));
+        for (auto *p : patches) {
+            if (!p) continue;
+            for (int i = 0; i < p->r.num_cam; ++i) {
+                int cx = (int)(p->r.imgPoint[i][0] / cfg.cellSize);
+                int cy = (int)(p->r.imgPoint[i][1] / cfg.cellSize);
+                cellInsert(cellMaps[p->r.cam_idx[i]], cx, cy, p->id);
+            }
+        }
+    }
+    void initPriorityQueue()
+    {
+        qBest = decltype(qBest)();
+        qWorst = decltype(qWorst)();
+        qList.clear();
+        qSeq = 0;
+        liveQueued = 0;
+        for (auto *p : patches)
+            if (p) queuePush(p->id);
+    }
+};
+
+// ------------------------------------------------------------------ C ABI ---
+static thread_local std::string g_mvs_err;
+static int mfail(const char *m) { g_mvs_err = m; return -1; }
+
+extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device,
+                               uint64_t pso_seed, pais_mvs **out)
+{
+    if (!cfg || !cams || !out || num_cams <= 0) return mfail("pais_mvs_create: bad argument");
+    pais_mvs *m = new pais_mvs();
+    memset(&m->st, 0, sizeof(m->st));
+    m->cfg = *cfg;
+    m->cfg.patchSize = (cfg->patchRadius << 1) + 1;
+    // device < 0: scheduler only (stepwise API; e.g. a rank that replays rounds but owns no GPU,
+    // and the CPU tests that feed it externally computed records).  Entry points that need the
+    // GPU then fail; nothing is ever computed on the host instead.
+    if (device >= 0) {
+        int rc = pais_ctx_create(cfg, num_cams, cams, device, pso_seed, &m->ctx);
+        if (rc) { delete m; return rc; }
+    }
+    m->cams.resize((size_t)num_cams);
+    for (int c = 0; c < num_cams; ++c) {
+        const pais_camera_desc &d = cams[c];
+        HostCamera &h = m->cams[c];
+        h.focal[0] = d.focal[0]; h.focal[1] = d.focal[1];
+        h.pp[0] = d.principle_point[0]; h.pp[1] = d.principle_point[1];
+        memcpy(h.R, d.rotation, sizeof(h.R));
+        memcpy(h.T, d.translation, sizeof(h.T));
+        memcpy(h.C, d.center, sizeof(h.C));
+        memcpy(h.optN, d.optical_normal, sizeof(h.optN));
+        h.w0 = d.level_width[0];
+        h.h0 = d.level_height[0];
+        const size_t stride = d.level_stride[0] > 0 ? (size_t)d.level_stride[0] : (size_t)h.w0;
+        h.img0.resize((size_t)h.w0 * h.h0);
+        for (int y = 0; y < h.h0; ++y) memcpy(&h.img0[(size_t)y * h.w0], d.level_image[0] + (size_t)y * stride, (size_t)h.w0);
+    }
+    m->neighborRadius = cfg->neighborRadius;
+    *out = m;
+    return 0;
+}
+
+extern "C" void pais_mvs_destroy(pais_mvs *m) { delete m; }
+extern "C" pais_ctx *pais_mvs_ctx(pais_mvs *m) { return m ? m->ctx : nullptr; }
+
+// seed constructor: patch.cpp:26-34 + setEstimatedNormal :390-413
+extern "C" int pais_mvs_add_seed(pais_mvs *m, const double center[3], int num_cam, const int32_t *cam_idx)
+{
+    if (!m || !center || num_cam < 0 || num_cam > PAIS_MAX_VIS || (num_cam && !cam_idx)) return mfail("pais_mvs_add_seed: bad argument");
+    pais_patch_result r;
+    memset(&r, 0, sizeof(r));
+    for (int i = 0; i < 3; ++i) r.center[i] = center[i];
+    r.num_cam = num_cam;
+    for (int i = 0; i < num_cam; ++i) {
+        if (cam_idx[i] < 0 || cam_idx[i] >= (int)m->cams.size()) return mfail("pais_mvs_add_seed: bad camera index");
+        r.cam_idx[i] = cam_idx[i];
+    }
+    r.type = PAIS_TYPE_SEED;
+    r.fitness = DBL_MAX;
+    r.priority = DBL_MAX;
+    r.ref_cam = -1;
+    r.lod = -1;
+    r.key = (uint64_t)m->patches.size();
+    if (num_cam >= m->cfg.minCamNum) {
+        double normal[3] = {0, 0, 0}, dir[3];
+        for (int i = 0; i < num_cam; i++) {
+            const HostCamera &cam = m->cams[cam_idx[i]];
+            for (int k = 0; k < 3; ++k) dir[k] = cam.C[k] - center[k];
+            double sc = (1.0 / pais::norm3(dir));
+            for (int k = 0; k < 3; ++k) dir[k] *= sc;
+            for (int k = 0; k < 3; ++k) normal[k] += dir[k];
+        }
+        double sc = (1.0 / pais::norm3(normal));
+        for (int k = 0; k < 3; ++k) r.normal[k] = normal[k] * sc;
+        pais::normal2spherical(r.normal, r.normalS);
+    } else {
+        r.dropped = 1;
+    }
+    return m->storePatch(r);
+}
+
+extern "C" int pais_mvs_seed_begin(pais_mvs *m, const pais_candidate **cands, int *n)
+{
+    if (!m || !cands || !n) return mfail("pais_mvs_seed_begin: bad argument");
+    if (m->alive == 0) { *cands = nullptr; *n = 0; return 0; }
+    m->setNeighborRadius(); // mvs.cpp:202
+    m->candRecs.clear();
+    m->seedIds.clear();
+    for (size_t id = 0; id < m->patches.size(); ++id) {
+        HostPatch *p = m->patches[id];
+        if (!p) continue;
+        if (p->r.num_cam < m->cfg.minCamNum) { m->deletePatch((int)id); continue; } // :209-212
+        pais_candidate c;
+        memset(&c, 0, sizeof(c));
+        for (int i = 0; i < 3; ++i) { c.center[i] = p->r.center[i]; c.normal[i] = p->r.normal[i]; }
+        c.normalS[0] = p->r.normalS[0]; c.normalS[1] = p->r.normalS[1];
+        c.key = p->r.key;
+        c.type = PAIS_TYPE_SEED;
+        c.num_cam = p->r.num_cam;
+        for (int i = 0; i < c.num_cam; ++i) c.cam_idx[i] = p->r.cam_idx[i];
+        m->candRecs.push_back(c);
+        m->seedIds.push_back((int)id);
+    }
+    *cands = m->candRecs.data();
+    *n = (int)m->candRecs.size();
+    return 0;
+}
+
+extern "C" int pais_mvs_seed_commit(pais_mvs *m, const pais_patch_result *results, int n)
+{
+    if (!m || n != (int)m->seedIds.size() || (n && !results)) return mfail("pais_mvs_seed_commit: bad argument");
+    for (int k = 0; k < n; ++k) {
+        const int id = m->seedIds[k];
+        HostPatch *p = m->patches[id];
+        p->r = results[k];
+        m->st.seeds_refined++;
+        m->st.pso_evals_effective += results[k].pso_evals;
+        if (!m->runtimeFiltering(p->r, id)) m->deletePatch(id); // :217-220
+    }
+    m->setNeighborRadius(); // :230
+    m->seedIds.clear();
+    return 0;
+}
+
+extern "C" int pais_mvs_refine_seed_patches(pais_mvs *m)
+{
+    const pais_candidate *c;
+    int n;
+    int rc = pais_mvs_seed_begin(m, &c, &n);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    if (!m->ctx) return mfail("pais_mvs_refine_seed_patches: this driver was created without a GPU context");
+    m->results.resize((size_t)n);
+    double t0 = now_ms();
+    rc = pais_refine_batch(m->ctx, n, c, m->results.data());
+    m->st.gpu_refine_ms += now_ms() - t0;
+    if (rc) return rc;
+    return pais_mvs_seed_commit(m, m->results.data(), n);
+}
+
+extern "C" int pais_mvs_expansion_begin(pais_mvs *m)
+{
+    if (!m) return mfail("bad argument");
+    m->setCellMaps();
+    m->initPriorityQueue();
+    m->setNeighborRadius();
+    return 0;
+}
+
+extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **cands, int *n)
+{
+    if (!m || !cands || !n) return mfail("pais_mvs_round_begin: bad argument");
+    double t0 = now_ms();
+    if (B < 1) B = 1;
+    m->parents.clear();
+    while ((int)m->parents.size() < B) {
+        int id = m->queuePop();
+        if (id < 0) break;
+        m->parents.push_back(id);
+    }
+    *cands = nullptr;
+    *n = 0;
+    if (m->parents.empty()) return 1;
+    // reference quirk (mvs.cpp:241-243,271): with one parent per round, the parent popped
+    // last is expanded only while the queue is still non-empty
+    if (B == 1 && m->strictTail && m->liveQueued == 0) return 1;
+    m->st.parents_popped += (int64_t)m->parents.size();
+
+    // runtimeFiltering of an inserted patch does not depend on later insertions (its own id
+    // is found in its first visible cell, mvs.cpp:888-889), so it can be decided up front.
+    m->parentOk.assign(m->parents.size(), 0);
+    for (size_t k = 0; k < m->parents.size(); ++k) {
+        HostPatch *p = m->patches[m->parents[k]];
+        bool ok = m->runtimeFiltering(p->r, p->id);
+        m->parentOk[k] = ok ? 1 : 0;
+        p->doomed = !ok;
+    }
+    // speculative superset: enumerate against (state - doomed parents); insertions of this
+    // round can only turn a candidate into a skip (skipNeighborCell is monotone in the cell content)
+    m->cands.clear();
+    m->candRecs.clear();
+    for (size_t k = 0; k < m->parents.size(); ++k) {
+        if (!m->parentOk[k]) continue;
+        const pais_patch_result &pr = m->patches[m->parents[k]]->r;
+        for (int i = 0; i < pr.num_cam; ++i) {
+            const int camI = pr.cam_idx[i];
+            const CellMap &map = m->cellMaps[camI];
+            const int cx = (int)(pr.imgPoint[i][0] / m->cfg.cellSize);
+            const int cy = (int)(pr.imgPoint[i][1] / m->cfg.cellSize);
+            const int nx[4] = {cx - 1, cx, cx + 1, cx};
+            const int ny[4] = {cy, cy - 1, cy, cy + 1};
+            for (int j = 0; j < 4; ++j) {
+                if (!map.inMap(nx[j], ny[j])) continue;
+                if (m->skipNeighborCell(map, nx[j], ny[j], pr, true)) continue;
+                Candidate c{(int)k, i, j, camI, nx[j], ny[j]};
+                double center[3];
+                m->expansionCenter(camI, pr, nx[j], ny[j], center);
+                pais_candidate rec;
+                m->makeExpandCandidate(pr, center, pais_child_key(pr.key, camI, nx[j], ny[j]), &rec);
+                m->cands.push_back(c);
+                m->candRecs.push_back(rec);
+            }
+        }
+    }
+    *cands = m->candRecs.data();
+    *n = (int)m->candRecs.size();
+    m->st.host_enumerate_ms += now_ms() - t0;
+    return 0;
+}
+
+extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *results, int n)
+{
+    if (!m || n != (int)m->cands.size() || (n && !results)) return mfail("pais_mvs_round_commit: bad argument");
+    double t0 = now_ms();
+    // exact replay of mvs.cpp:243-272 over the popped parents
+    size_t ptr = 0;
+    for (size_t k = 0; k < m->parents.size(); ++k) {
+        const int pid = m->parents[k];
+        HostPatch *p = m->patches[pid];
+        p->expanded = true; // :250
+        p->doomed = false;
+        if (!m->parentOk[k]) { m->deletePatch(pid); continue; } // :255-260
+        const pais_patch_result pr = p->r; // copy: inserts may reallocate nothing we hold, but keep it simple
+        for (int i = 0; i < pr.num_cam; ++i) {
+            const int camI = pr.cam_idx[i];
+            const CellMap &map = m->cellMaps[camI];
+            const int cx = (int)(pr.imgPoint[i][0] / m->cfg.cellSize);
+            const int cy = (int)(pr.imgPoint[i][1] / m->cfg.cellSize);
+            const int nx[4] = {cx - 1, cx, cx + 1, cx};
+            const int ny[4] = {cy, cy - 1, cy, cy + 1};
+            for (int j = 0; j < 4; ++j) {
+                if (!map.inMap(nx[j], ny[j])) continue;
+                // advance to this (k,i,j) in the speculative list, if it is there
+                while (ptr < m->cands.size() &&
+                       (m->cands[ptr].parentSlot < (int)k ||
+                        (m->cands[ptr].parentSlot == (int)k && (m->cands[ptr].i < i || (m->cands[ptr].i == i && m->cands[ptr].j < j)))))
+                    ++ptr;
+                const bool have = ptr < m->cands.size() && m->cands[ptr].parentSlot == (int)k && m->cands[ptr].i == i && m->cands[ptr].j == j;
+                if (m->skipNeighborCell(map, nx[j], ny[j], pr, false)) continue; // :558
+                if (!have) return mfail("pais_mvs_round_commit: speculative candidate set is not a superset (internal error)");
+                m->st.candidates_effective++;
+                m->st.pso_evals_effective += results[ptr].pso_evals;
+                m->insertPatch(results[ptr]); // expandCell :576
+            }
+        }
+    }
+    m->st.candidates_refined += n;
+    m->st.rounds++;
+    m->cands.clear();
+    m->st.host_commit_ms += now_ms() - t0;
+    return 0;
+}
+
+extern "C" int pais_mvs_expansion_end(pais_mvs *m)
+{
+    if (!m) return mfail("bad argument");
+    m->setNeighborRadius(); // mvs.cpp:274
+    return 0;
+}
+
+extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
+{
+    if (!m || !m->ctx) return mfail("pais_mvs_expansion_patches: no GPU context");
+    int rc = pais_mvs_expansion_begin(m);
+    if (rc) return rc;
+    int rounds = 0;
+    for (;;) {
+        const pais_candidate *c;
+        int n;
+        rc = pais_mvs_round_begin(m, B, &c, &n);
+        if (rc < 0) return rc;
+        if (rc == 1) break;
+        m->results.resize((size_t)(n > 0 ? n : 1));
+        if (n > 0) {
+            double t0 = now_ms();
+            rc = pais_refine_batch(m->ctx, n, c, m->results.data());
+            m->st.gpu_refine_ms += now_ms() - t0;
+            if (rc) return rc;
+        }
+        rc = pais_mvs_round_commit(m, m->results.data(), n);
+        if (rc) return rc;
+        if (max_rounds > 0 && ++rounds >= max_rounds) break;
+    }
+    return pais_mvs_expansion_end(m);
+}
+
+extern "C" int pais_mvs_num_patches(const pais_mvs *m) { return m ? m->alive : 0; }
+extern "C" int pais_mvs_num_slots(const pais_mvs *m) { return m ? (int)m->patches.size() : 0; }
+extern "C" int pais_mvs_get_patch(const pais_mvs *m, int id, pais_patch_result *out, int *expanded)
+{
+    if (!m || id < 0 || id >= (int)m->patches.size() || !m->patches[id]) return 1;
+    if (out) *out = m->patches[id]->r;
+    if (expanded) *expanded = m->patches[id]->expanded ? 1 : 0;
+    return 0;
+}
+extern "C" double pais_mvs_neighbor_radius(const pais_mvs *m) { return m ? m->neighborRadius : 0.0; }
+extern "C" int pais_mvs_get_stats(const pais_mvs *m, pais_mvs_stats *out)
+{
+    if (!m || !out) return -1;
+    *out = m->st;
+    return 0;
+}
+extern "C" const char *pais_mvs_last_error(void) { return g_mvs_err.c_str(); }

@@ -1,0 +1,161 @@
+"""Host mirror of PAIS::MVS for the hot path: refineSeedPatches / expansionPatches
+(TMVS/mvs/mvs.h:229,231) over include/pais_mvs.h."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .camera import Camera
+from .config import MvsConfig
+from .context import camera_desc
+
+
+class MvsStats(C.Structure):
+    _fields_ = [("seeds_refined", C.c_int64), ("candidates_refined", C.c_int64), ("candidates_effective", C.c_int64),
+                ("patches_inserted", C.c_int64), ("patches_deleted", C.c_int64), ("rounds", C.c_int64),
+                ("parents_popped", C.c_int64), ("pso_evals_effective", C.c_int64),
+                ("host_enumerate_ms", C.c_double), ("host_commit_ms", C.c_double), ("gpu_refine_ms", C.c_double)]
+
+
+def _bind(L):
+    if getattr(L, "_mvs_bound", False):
+        return
+    vp = C.c_void_p
+    L.pais_mvs_create.argtypes = [C.POINTER(_lib.Config), C.c_int, C.POINTER(_lib.CameraDesc), C.c_int, C.c_uint64,
+                                  C.POINTER(vp)]
+    L.pais_mvs_destroy.argtypes = [vp]
+    L.pais_mvs_destroy.restype = None
+    L.pais_mvs_ctx.restype = vp
+    L.pais_mvs_ctx.argtypes = [vp]
+    L.pais_mvs_add_seed.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32)]
+    L.pais_mvs_refine_seed_patches.argtypes = [vp]
+    L.pais_mvs_expansion_patches.argtypes = [vp, C.c_int, C.c_int]
+    L.pais_mvs_seed_begin.argtypes = [vp, C.POINTER(C.POINTER(_lib.Candidate)), C.POINTER(C.c_int)]
+    L.pais_mvs_seed_commit.argtypes = [vp, C.POINTER(_lib.PatchResult), C.c_int]
+    L.pais_mvs_expansion_begin.argtypes = [vp]
+    L.pais_mvs_round_begin.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(_lib.Candidate)), C.POINTER(C.c_int)]
+    L.pais_mvs_round_commit.argtypes = [vp, C.POINTER(_lib.PatchResult), C.c_int]
+    L.pais_mvs_expansion_end.argtypes = [vp]
+    L.pais_mvs_num_patches.argtypes = [vp]
+    L.pais_mvs_num_slots.argtypes = [vp]
+    L.pais_mvs_get_patch.argtypes = [vp, C.c_int, C.POINTER(_lib.PatchResult), C.POINTER(C.c_int)]
+    L.pais_mvs_neighbor_radius.restype = C.c_double
+    L.pais_mvs_neighbor_radius.argtypes = [vp]
+    L.pais_mvs_get_stats.argtypes = [vp, C.POINTER(MvsStats)]
+    L.pais_mvs_last_error.restype = C.c_char_p
+    L._mvs_bound = True
+
+
+class MVS:
+    """Reconstruction driver.  device < 0: scheduler only (stepwise API)."""
+
+    def __init__(self, cfg: MvsConfig, cameras: Sequence[Camera], device: int = 0, seed: int = 42):
+        self.L = _lib.load()
+        _bind(self.L)
+        self.cfg = cfg
+        self.cameras = list(cameras)
+        keep: list = []
+        n = len(self.cameras)
+        descs = (_lib.CameraDesc * n)()
+        for i, cam in enumerate(self.cameras):
+            descs[i] = camera_desc(cam, bool(cfg.adaptiveGradientEnable), keep)
+        c = cfg.to_c()
+        h = C.c_void_p()
+        self._check(self.L.pais_mvs_create(C.byref(c), n, descs, device, seed, C.byref(h)), "pais_mvs_create")
+        self.h = h
+
+    def _check(self, rc, what):
+        if rc < 0:
+            msg = self.L.pais_mvs_last_error().decode() or self.L.pais_last_error().decode()
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pais_mvs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ctx_handle(self):
+        return self.L.pais_mvs_ctx(self.h)
+
+    def add_seed(self, center, cam_idx) -> int:
+        cen = (C.c_double * 3)(*[float(v) for v in center])
+        idx = (C.c_int32 * len(cam_idx))(*[int(v) for v in cam_idx])
+        return self._check(self.L.pais_mvs_add_seed(self.h, cen, len(cam_idx), idx), "pais_mvs_add_seed")
+
+    # ---- MVS::refineSeedPatches / MVS::expansionPatches
+    def refineSeedPatches(self):
+        self._check(self.L.pais_mvs_refine_seed_patches(self.h), "pais_mvs_refine_seed_patches")
+
+    def expansionPatches(self, parents_per_round: int = 1, max_rounds: int = 0):
+        self._check(self.L.pais_mvs_expansion_patches(self.h, parents_per_round, max_rounds), "pais_mvs_expansion_patches")
+
+    # ---- stepwise
+    def seed_begin(self):
+        p = C.POINTER(_lib.Candidate)()
+        n = C.c_int(0)
+        self._check(self.L.pais_mvs_seed_begin(self.h, C.byref(p), C.byref(n)), "pais_mvs_seed_begin")
+        return p, n.value
+
+    def seed_commit(self, results, n: int):
+        self._check(self.L.pais_mvs_seed_commit(self.h, results, n), "pais_mvs_seed_commit")
+
+    def expansion_begin(self):
+        self._check(self.L.pais_mvs_expansion_begin(self.h), "pais_mvs_expansion_begin")
+
+    def round_begin(self, parents_per_round: int):
+        p = C.POINTER(_lib.Candidate)()
+        n = C.c_int(0)
+        rc = self._check(self.L.pais_mvs_round_begin(self.h, parents_per_round, C.byref(p), C.byref(n)), "pais_mvs_round_begin")
+        return rc == 1, p, n.value
+
+    def round_commit(self, results, n: int):
+        self._check(self.L.pais_mvs_round_commit(self.h, results, n), "pais_mvs_round_commit")
+
+    def expansion_end(self):
+        self._check(self.L.pais_mvs_expansion_end(self.h), "pais_mvs_expansion_end")
+
+    # ---- inspection
+    def num_patches(self) -> int:
+        return self.L.pais_mvs_num_patches(self.h)
+
+    def num_slots(self) -> int:
+        return self.L.pais_mvs_num_slots(self.h)
+
+    def get_patch(self, i: int) -> Optional["_lib.PatchResult"]:
+        r = _lib.PatchResult()
+        e = C.c_int(0)
+        if self.L.pais_mvs_get_patch(self.h, i, C.byref(r), C.byref(e)) != 0:
+            return None
+        return r
+
+    def patches(self) -> List["_lib.PatchResult"]:
+        out = []
+        for i in range(self.num_slots()):
+            p = self.get_patch(i)
+            if p is not None:
+                out.append(p)
+        return out
+
+    def neighbor_radius(self) -> float:
+        return self.L.pais_mvs_neighbor_radius(self.h)
+
+    def stats(self) -> MvsStats:
+        s = MvsStats()
+        self.L.pais_mvs_get_stats(self.h, C.byref(s))
+        return s
+
+    def cloud(self) -> np.ndarray:
+        """(N, 6) array of patch centres and normals in id order."""
+        ps = self.patches()
+        return np.array([[*p.center[:], *p.normal[:]] for p in ps], dtype=np.float64).reshape(-1, 6)
