@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- refined+expanded patches/sec of the MI355X-native PAIS-MVS hot path.
+
+One "step" = one full reconstruction of the workload: MVS::refineSeedPatches +
+MVS::expansionPatches to convergence (BASELINE.json configs[1]: 5-camera pawn scene,
+patchRadius 15, README config) with the scene already resident in HBM.  Units =
+patches taken through refine() that the reference's sequential order evaluates
+(seeds + effective expansion candidates); speculative extra refines are reported
+separately and never counted.
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU;
+a round's candidates are sharded across ranks and the records all-gathered over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="pawn", choices=["pawn", "ring"])
+    ap.add_argument("--parents-per-round", type=int, default=int(os.environ.get("PAIS_B", "512")))
+    ap.add_argument("--max-rounds", type=int, default=0)
+    ap.add_argument("--seeds", type=int, default=200)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_scene(args):
+    from pais_mvs_amd import synth
+    from pais_mvs_amd.config import readme_config
+    if args.scene == "pawn":
+        cfg = readme_config()
+        scene = synth.pawn_scene(n_seeds=args.seeds, build_edges=False)
+        name = "5-camera pawn scene (README.md:68-72 cameras, synthetic 640x480 renders), patchRadius 15, README config, full expansion to convergence"
+    else:
+        cfg = readme_config(adaptiveGradientEnable=True)
+        scene = synth.ring_scene(n_seeds=max(args.seeds, 400), build_edges=True)
+        name = "32-camera synthetic ring 1920x1080, patchRadius 15, adaptive weighting on"
+    return cfg, scene, name
+
+
+def cpu_baseline(cfg, scene, budget_s: float):
+    """Oracle (CPU restatement, reference OpenMP structure: particles in parallel, patches
+    sequential) timed on a bounded sample of the same workload: seeds, then first-ring children."""
+    from oracle import po
+    from tests.common import oracle_cfg
+    ncores = os.cpu_count() or 1
+    S = po.OracleScene(oracle_cfg(cfg), scene.cameras, seed=42)
+    S.set_omp(True)
+    L = po.lib()
+    t0 = time.perf_counter()
+    units = 0
+    parents = []
+    # neighbour radius as the driver computes it before the seed pass (mvs.cpp:202)
+    mo = L.po_mvs_create(S.ptr)
+    for X, vis in scene.seeds:
+        L.po_mvs_add_seed(mo, po.darr(X), len(vis), po.iarr(vis))
+    L.po_mvs_set_neighbor_radius(mo)
+    for i, (X, vis) in enumerate(scene.seeds):
+        if time.perf_counter() - t0 > budget_s * 0.5:
+            break
+        p = S.seed_patch(X, vis, key=i)
+        L.po_refine_seed(S.ptr, C.byref(p))
+        units += 1
+        if not p.drop:
+            parents.append(p)
+    n_seed = units
+    for par in parents:
+        if time.perf_counter() - t0 > budget_s:
+            break
+        for j, camI in enumerate(par.cams()):
+            cx = int(par.imgPoint[j][0] / cfg.cellSize) + 1
+            cy = int(par.imgPoint[j][1] / cfg.cellSize)
+            cen = (C.c_double * 3)()
+            L.po_expansion_center(S.ptr, camI, C.byref(par), cx, cy, cen)
+            ch = po.Patch()
+            L.po_expand_candidate(S.ptr, C.byref(ch), cen, po.darr(par.normal[:]), par.numCam, po.iarr(par.cams()),
+                                  L.po_child_key(par.key, camI, cx, cy))
+            units += 1
+    dt = time.perf_counter() - t0
+    L.po_mvs_destroy(mo)
+    return {"value": units / dt, "unit": "patches/s", "cores": ncores, "kind": "port",
+            "sample": "%d seeds + %d first-ring expansion candidates of the same scene, oracle/pais_oracle.c with "
+                      "OpenMP over particles (the reference's structure), %.1f s" % (n_seed, units - n_seed, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the PAIS HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from pais_mvs_amd import _lib
+    from pais_mvs_amd.mvs import MVS
+    from pais_mvs_amd import distributed as D
+
+    cfg, scene, wname = build_scene(args)
+    m = MVS(cfg, scene.cameras, device=local, seed=42)
+    ex = D.torch_gpu_exchange(m, rank, world) if world > 1 else None
+    B = args.parents_per_round
+
+    def step():
+        m.reset()
+        for X, vis in scene.seeds:
+            m.add_seed(X, vis)
+        if world == 1:
+            m.refineSeedPatches()
+            m.expansionPatches(B, args.max_rounds)
+        else:
+            D.reconstruct(m, B, ex, args.max_rounds)
+        return m.stats()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ks = _lib.KernelStats()
+    m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 1)   # reset kernel timers
+    fence()
+    t0 = time.perf_counter()
+    units = 0
+    spec = 0
+    evals_eff = 0
+    last = None
+    for _ in range(args.steps):
+        st = step()
+        units += st.seeds_refined + st.candidates_effective
+        spec += st.candidates_refined - st.candidates_effective
+        evals_eff += st.pso_evals_effective
+        last = st
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
+
+    if rank == 0:
+        S2 = cfg.patchSize ** 2
+        pso_gbs = (ks.pso_algorithmic_bytes / 1e9) / (ks.pso_ms / 1e3) if ks.pso_ms > 0 else 0.0
+        out = {
+            "metric": "refined+expanded patches/sec",
+            "value": units / dt,
+            "unit": "patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": wname, "parents_per_round": B, "seeds": len(scene.seeds),
+                       "patches_per_step": units // max(args.steps, 1),
+                       "accepted_patches": int(m.num_patches()),
+                       "speculative_extra_refines_per_step": spec // max(args.steps, 1),
+                       "rounds_per_step": int(last.rounds) if last else 0,
+                       "pso_evals_per_patch": evals_eff / max(units, 1),
+                       "parallelism": "candidates sharded over %d GPU(s), 1 all-gather per round" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_pso", "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": pso_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "launches": int(ks.pso_launches), "avg_launch_ms": ks.pso_ms / max(ks.pso_launches, 1),
+                         "evals": int(ks.pso_evals),
+                         "algorithmic_bytes_per_eval": (ks.pso_algorithmic_bytes / ks.pso_evals) if ks.pso_evals else 0,
+                         "note": "rank-0 kernel; bytes = S^2*(4K+1+8[dist]+8[grad]) per cost evaluation (SURVEY 8d)"},
+            "kernel_ms": {"k_pso": ks.pso_ms, "k_begin": ks.begin_ms, "k_after": ks.after_ms,
+                          "host_enumerate": last.host_enumerate_ms if last else 0,
+                          "host_commit": last.host_commit_ms if last else 0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, scene, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+    m.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,8 @@ int  pais_mvs_create(const pais_config *cfg, int num_cams, const pais_camera_des
                      int device, uint64_t pso_seed, pais_mvs **out);
 void pais_mvs_destroy(pais_mvs *m);
 pais_ctx *pais_mvs_ctx(pais_mvs *m);
+/* forget all patches, cell maps and the queue; cameras and the GPU context stay */
+int  pais_mvs_reset(pais_mvs *m);
 
 /* Seed constructor Patch(center, color, camIdx, imgPoint) (patch.cpp:26-34,
  * setEstimatedNormal :390-413).  Returns the patch id (>= 0) or < 0. */

@@ -451,6 +451,29 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
 }
 
 extern "C" void pais_mvs_destroy(pais_mvs *m) { delete m; }
+
+// forget all patches / cell maps / queue (keeps the GPU context and the cameras): a fresh reconstruction
+extern "C" int pais_mvs_reset(pais_mvs *m)
+{
+    if (!m) return mfail("bad argument");
+    for (auto *p : m->patches) delete p;
+    m->patches.clear();
+    m->alive = 0;
+    m->cellMaps.clear();
+    m->pool.clear();
+    m->freeEntry = -1;
+    m->qBest = decltype(m->qBest)();
+    m->qWorst = decltype(m->qWorst)();
+    m->qList.clear();
+    m->qSeq = 0;
+    m->liveQueued = 0;
+    m->parents.clear();
+    m->cands.clear();
+    m->candRecs.clear();
+    m->seedIds.clear();
+    memset(&m->st, 0, sizeof(m->st));
+    return 0;
+}
 extern "C" pais_ctx *pais_mvs_ctx(pais_mvs *m) { return m ? m->ctx : nullptr; }
 
 // seed constructor: patch.cpp:26-34 + setEstimatedNormal :390-413

@@ -30,6 +30,7 @@ def _bind(L):
     L.pais_mvs_destroy.restype = None
     L.pais_mvs_ctx.restype = vp
     L.pais_mvs_ctx.argtypes = [vp]
+    L.pais_mvs_reset.argtypes = [vp]
     L.pais_mvs_add_seed.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32)]
     L.pais_mvs_refine_seed_patches.argtypes = [vp]
     L.pais_mvs_expansion_patches.argtypes = [vp, C.c_int, C.c_int]
@@ -87,6 +88,9 @@ class MVS:
     @property
     def ctx_handle(self):
         return self.L.pais_mvs_ctx(self.h)
+
+    def reset(self):
+        self._check(self.L.pais_mvs_reset(self.h), "pais_mvs_reset")
 
     def add_seed(self, center, cam_idx) -> int:
         cen = (C.c_double * 3)(*[float(v) for v in center])

@@ -184,3 +184,80 @@ def test_expand_candidates_match_oracle(pawn_small):
         ok += 0 if p.drop else 1
     assert ok >= 5
     ctx.close()
+
+
+@pytest.mark.parametrize("B,max_rounds", [(1, 12), (16, 5)])
+def test_reconstruction_rounds_match_oracle(pawn_small, B, max_rounds):
+    """End to end through the driver (include/pais_mvs.h): seeds + expansion rounds on the GPU
+    against the oracle's R(B) loop (B = 1: the reference's own order).  The accepted clouds must
+    be identical patch by patch (same order, same camera sets, same bits)."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    cfg = readme_config()
+    S = common.oracle_scene(cfg, pawn_small)
+    S.set_kernel_arithmetic(True)
+    L = po.lib()
+    mo = L.po_mvs_create(S.ptr)
+    for X, vis in pawn_small.seeds:
+        L.po_mvs_add_seed(mo, po.darr(X), len(vis), po.iarr(vis))
+    L.po_mvs_refine_seed_patches(mo)
+    L.po_mvs_expansion_patches(mo, B, max_rounds, 1)
+    want = []
+    for i in range(L.po_mvs_num_slots(mo)):
+        pp = L.po_mvs_get_patch(mo, i)
+        if pp:
+            p = pp.contents
+            want.append((list(p.center[:]), list(p.normal[:]), p.cams(), p.fitness, p.correlation, p.priority, p.LOD))
+    calls = L.po_mvs_refine_calls(mo)
+    L.po_mvs_destroy(mo)
+
+    m = MVS(cfg, pawn_small.cameras, device=0, seed=42)
+    for X, vis in pawn_small.seeds:
+        m.add_seed(X, vis)
+    m.refineSeedPatches()
+    m.expansionPatches(B, max_rounds)
+    got = [(list(p.center[:]), list(p.normal[:]), p.cams(), p.fitness, p.correlation, p.priority, p.lod) for p in m.patches()]
+    st = m.stats()
+    assert len(got) == len(want) and len(got) >= len(pawn_small.seeds) // 2, (len(got), len(want))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (i, a, b)
+    assert st.seeds_refined + st.candidates_effective == calls
+    m.close()
+
+
+def test_full_size_properties(pawn_full):
+    """BASELINE-size run (640x480 pawn, README config, full expansion): size-independent properties."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    cfg = readme_config()
+    clouds = []
+    for rep in range(2):
+        m = MVS(cfg, pawn_full.cameras, device=0, seed=42)
+        for X, vis in pawn_full.seeds:
+            m.add_seed(X, vis)
+        m.refineSeedPatches()
+        m.expansionPatches(256, 0)
+        ps = m.patches()
+        st = m.stats()
+        clouds.append(m.cloud())
+        assert len(ps) > 10 * len(pawn_full.seeds)                 # the surface was actually grown
+        for p in ps[:: max(1, len(ps) // 500)]:
+            assert not p.dropped and p.num_cam >= cfg.minCamNum
+            assert 0 < p.fitness <= cfg.maxFitness and p.correlation >= cfg.minCorrelation
+            assert len(set(p.cams())) == p.num_cam
+            n = np.array(p.normal[:]); assert abs(np.linalg.norm(n) - 1) < 1e-12
+        # every accepted patch lies on the synthetic surface (ray-cast check from its reference camera)
+        obj = pawn_full.obj
+        errs = []
+        for p in ps[:: max(1, len(ps) // 300)]:
+            cam = pawn_full.cameras[p.ref_cam]
+            d = np.array(p.center[:]) - cam.center
+            dist = np.linalg.norm(d)
+            t = obj.intersect(cam.center, (d / dist)[None, :])[0]
+            errs.append(abs(t - dist) / dist)
+        assert np.median(errs) < 2e-3, np.median(errs)
+        assert st.candidates_refined >= st.candidates_effective > 0
+        m.close()
+    # bit-reproducible run to run
+    assert clouds[0].shape == clouds[1].shape and np.array_equal(clouds[0], clouds[1])
