@@ -600,6 +600,46 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
 
     if (f->refImg[(size_t)cv_round(y) * f->refCols + cv_round(x)] == 0) return 0; /* :986 */
 
+    if (s->detMath) {
+        /* "kernel arithmetic" (DESIGN.md 5.3): the same quantities as the literal branch
+         * below, evaluated the way the HIP kernel does -- homography rows with fma, one
+         * reciprocal per tap, bilinear as two fma lerps, mean/SAD scaled by 1/K, fdlibm exp.
+         * Differs from the literal branch in the last bits only. */
+        const double invK = 1.0 / (double)camNum, invDiffW = 1.0 / s->cfg.diffWeighting;
+        double sum = 0;
+        for (int i = 0; i < camNum; ++i) {
+            const po_camera *cam = &s->cams[patch->camIdx[i]];
+            const uint8_t *img = cam->img[LOD];
+            const int cols = cam->width[LOD], rows = cam->height[LOD];
+            const double *Hi = f->H + 9 * i;
+            const double ww = fma(Hi[7], y, fma(Hi[6], x, Hi[8]));
+            const double nx = fma(Hi[1], y, fma(Hi[0], x, Hi[2]));
+            const double ny = fma(Hi[4], y, fma(Hi[3], x, Hi[5]));
+            const double rw = 1.0 / ww;
+            const double jx = nx * rw, jy = ny * rw;
+            if (!((jx >= 2 && jx < cols - 3 && jy >= 2 && jy < rows - 3) && (ww != 0))) return -1;
+            const int qx = (int)jx, qy = (int)jy;
+            const double bx = jx - (double)qx, by = jy - (double)qy;
+            const double ax = 1.0 - bx, ay = 1.0 - by;
+            const uint8_t *r0 = img + (size_t)qy * cols + qx, *r1 = r0 + cols;
+            const double t0 = fma((double)r0[1], bx, (double)r0[0] * ax);
+            const double t1 = fma((double)r1[1], bx, (double)r1[0] * ax);
+            c[i] = fma(t1, by, t0 * ay);
+            sum += c[i];
+        }
+        mean = sum * invK;
+        for (int i = 0; i < camNum; i++) avgSad += fabs(c[i] - mean);
+        avgSad *= invK;
+        double weight = 1;
+        if (s->cfg.adaptiveDistanceEnable) weight *= distW;
+        if (s->cfg.adaptiveDifferenceEnable) weight *= po_det_exp(-(avgSad * avgSad) * invDiffW);
+        if (s->cfg.adaptiveGradientEnable)
+            weight *= po_det_exp(-1.0 / (f->edgeImg[(size_t)cv_round(y) * f->refCols + cv_round(x)] * s->cfg.gradientWeighting));
+        *weightOut = weight;
+        *sadOut = avgSad;
+        return 1;
+    }
+
     for (int i = 0; i < camNum; ++i) {
         const po_camera *cam = &s->cams[patch->camIdx[i]];
         const uint8_t *img = cam->img[LOD];
@@ -705,7 +745,7 @@ double po_get_fitness(const po_scene *s, const po_patch *patch, const double pos
             if (st < 0) return DBL_MAX;
             if (st == 0) continue;
             pw[k & 63] += weight;
-            pf[k & 63] += weight * avgSad;
+            pf[k & 63] = s->detMath ? fma(weight, avgSad, pf[k & 63]) : pf[k & 63] + weight * avgSad;
         }
         return tree64(pf) / tree64(pw);
     }

@@ -201,13 +201,15 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
         for (int l = 0; l <= d.max_lod; ++l) {
             h.w[l] = d.level_width[l];
             h.h[l] = d.level_height[l];
-            h.img[l] = ctx->d_img + imgOff[(size_t)c * PAIS_MAX_LEVELS + l];
-            h.edge[l] = (wantEdge && ctx->d_edge) ? (const double *)((uint8_t *)ctx->d_edge + edgeOff[(size_t)c * PAIS_MAX_LEVELS + l]) : nullptr;
+            h.imgOff[l] = (uint64_t)imgOff[(size_t)c * PAIS_MAX_LEVELS + l];
+            h.edgeOff[l] = (uint64_t)(edgeOff[(size_t)c * PAIS_MAX_LEVELS + l] / sizeof(double));
         }
     }
     HIPCHK(hipMalloc(&ctx->d_cams, sizeof(DevCamera) * (size_t)num_cams));
     HIPCHK(hipMemcpy(ctx->d_cams, hc.data(), sizeof(DevCamera) * (size_t)num_cams, hipMemcpyHostToDevice));
     ctx->sc.cams = ctx->d_cams;
+    ctx->sc.imgBlob = ctx->d_img;
+    ctx->sc.edgeBlob = ctx->d_edge;
 
     HIPCHK(hipMalloc(&ctx->d_counters, sizeof(int) * 4));
     HIPCHK(hipMemset(ctx->d_counters, 0, sizeof(int) * 4));

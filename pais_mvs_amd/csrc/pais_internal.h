@@ -18,13 +18,17 @@ struct DevCamera {
     int maxLOD;
     int pad;
     int w[PAIS_MAX_LEVELS], h[PAIS_MAX_LEVELS];
-    const uint8_t *img[PAIS_MAX_LEVELS];
-    const double *edge[PAIS_MAX_LEVELS];
+    // offsets into DevScene::imgBlob (bytes) / DevScene::edgeBlob (doubles): keeping the base in a
+    // kernel argument lets the compiler emit global_load (saddr) instead of flat_load for every tap
+    uint64_t imgOff[PAIS_MAX_LEVELS];
+    uint64_t edgeOff[PAIS_MAX_LEVELS];
 };
 
 struct DevScene {
     pais_config cfg;
     const DevCamera *cams;
+    const uint8_t *imgBlob;
+    const double *edgeBlob;
     const double *gauss; // patchDistWeight, S*S, indexed [x*S + y] (mvs.cpp:104-109)
     double lodScale[PAIS_MAX_LEVELS]; // pow(lodRatio, LOD) (camera.cpp:157, patch.cpp:309)
     uint64_t seed;

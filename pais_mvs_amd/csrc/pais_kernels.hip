@@ -47,7 +47,7 @@ __device__ __forceinline__ int wave_sum_i(int v)
 struct EvalCam {
     double KR[9];
     double KT[3];
-    const uint8_t *img;
+    uint64_t imgOff; // into DevScene::imgBlob
     int w, h;
     int cam;
     int pad;
@@ -55,8 +55,7 @@ struct EvalCam {
 struct EvalPatch {
     double ray[3], Cref[3], optNref[3], Rref[9], Tref[3], fref[2], ppref[2], KRref[9], KTref[3];
     double lodScale;
-    const uint8_t *refImg;
-    const double *refEdge;
+    uint64_t refImgOff, refEdgeOff;
     int refW, refH;
     int K, LOD, refCam, pad;
 };
@@ -69,7 +68,7 @@ __device__ void fill_eval_patch(const DevScene &sc, EvalPatch *ep, EvalCam *cams
         const DevCamera &dc = sc.cams[camIdx[c]];
         for (int i = 0; i < 9; ++i) cams[c].KR[i] = dc.KR[i];
         for (int i = 0; i < 3; ++i) cams[c].KT[i] = dc.KT[i];
-        cams[c].img = dc.img[LOD];
+        cams[c].imgOff = dc.imgOff[LOD];
         cams[c].w = dc.w[LOD];
         cams[c].h = dc.h[LOD];
         cams[c].cam = camIdx[c];
@@ -90,8 +89,8 @@ __device__ void fill_eval_patch(const DevScene &sc, EvalPatch *ep, EvalCam *cams
         ep->fref[0] = rc.focal[0]; ep->fref[1] = rc.focal[1];
         ep->ppref[0] = rc.pp[0]; ep->ppref[1] = rc.pp[1];
         ep->lodScale = sc.lodScale[LOD];
-        ep->refImg = rc.img[LOD];
-        ep->refEdge = rc.edge[LOD];
+        ep->refImgOff = rc.imgOff[LOD];
+        ep->refEdgeOff = rc.edgeOff[LOD];
         ep->refW = rc.w[LOD];
         ep->refH = rc.h[LOD];
         ep->K = K;
@@ -100,10 +99,22 @@ __device__ void fill_eval_patch(const DevScene &sc, EvalPatch *ep, EvalCam *cams
     }
 }
 
+// two adjacent bytes with one (unaligned) 16-bit global load
+__device__ __forceinline__ uint32_t load_pair(const uint8_t *p)
+{
+    uint16_t v;
+    __builtin_memcpy(&v, p, 2);
+    return (uint32_t)v;
+}
+
 // PAIS::getFitness for one particle, executed by ONE wave (all 64 lanes enter
 // with identical arguments and leave with the identical result).
 //   Hbuf : this wave's LDS scratch, K*9 doubles   (homographies, patch.cpp:290-330)
 //   cbuf : this wave's LDS scratch, K*64 doubles  (per-camera colour of the lane's pixel)
+// Arithmetic ("kernel arithmetic"; mirrored bit for bit by the oracle's
+// detMath/treeSum mode): homography rows with fma, ONE reciprocal per tap, bilinear as
+// two fma lerps, mean/SAD scaled by 1/K, exp/sin/cos from pais_detmath.hpp, lane partial
+// sums in increasing pixel index followed by the wave64 xor butterfly.
 __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf,
                                double *cbuf, double theta, double phi, double depth, int lane)
 {
@@ -155,12 +166,12 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
 
     const int S = sc.cfg.patchSize, S2 = S * S;
     const double a0 = pt[0] - r, b0 = pt[1] - r;
-    const uint8_t *refImg = ep->refImg;
-    const double *refEdge = ep->refEdge;
-    const double diffW = sc.cfg.diffWeighting, gradW = sc.cfg.gradientWeighting;
+    const uint8_t *refImg = sc.imgBlob + ep->refImgOff;
+    const double *refEdge = sc.edgeBlob + ep->refEdgeOff;
+    const double invDiffW = 1.0 / sc.cfg.diffWeighting, gradW = sc.cfg.gradientWeighting;
     const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useDiff = sc.cfg.adaptiveDifferenceEnable != 0,
                useGrad = sc.cfg.adaptiveGradientEnable != 0;
-    const double dK = (double)K;
+    const double invK = 1.0 / (double)K;
     double fsum = 0, wsum = 0;
     double *myc = cbuf + lane;
 
@@ -170,37 +181,72 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
         const int yi = k / S, xi = k - yi * S;
         const double x = a0 + (double)xi, y = b0 + (double)yi; // == the reference's ++x / ++y walk
         const int rx = cv_round(x), ry = cv_round(y);
+        const bool act = valid && refImg[ry * refW + rx] != 0; // :986
         bool bad = false;
-        if (valid && refImg[ry * refW + rx] != 0) { // :986
-            double mean = 0;
-            for (int c = 0; c < K; ++c) {
-                const double *H = Hbuf + 9 * c;
-                const double w = (H[6] * x + H[7] * y + H[8]);
-                const double ix = (H[0] * x + H[1] * y + H[2]) / w;
-                const double iy = (H[3] * x + H[4] * y + H[5]) / w;
-                const int cw = cams[c].w, ch = cams[c].h;
-                if (!(ix >= 2 && ix < cw - 3 && iy >= 2 && iy < ch - 3) || w == 0) { // :999 (NaN -> overflow)
-                    bad = true;
-                    break;
+        double sum = 0;
+        for (int c0 = 0; c0 < K; c0 += 4) {
+            double bx[4], by[4];
+            uint32_t r0[4], r1[4];
+            bool in[4];
+            const uint8_t *p0[4];
+            int cwv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u;
+                in[u] = act && (c < K);
+                bx[u] = 0; by[u] = 0; p0[u] = sc.imgBlob; cwv[u] = 0;
+                if (in[u]) {
+                    const double *H = Hbuf + 9 * c;
+                    const double w = fma(H[7], y, fma(H[6], x, H[8]));
+                    const double nx = fma(H[1], y, fma(H[0], x, H[2]));
+                    const double ny = fma(H[4], y, fma(H[3], x, H[5]));
+                    const double rw = 1.0 / w;
+                    const double ix = nx * rw, iy = ny * rw;
+                    const int cw = cams[c].w, ch = cams[c].h;
+                    const bool ok = (ix >= 2 && ix < cw - 3 && iy >= 2 && iy < ch - 3) && (w != 0); // :999 (NaN -> overflow)
+                    bad = bad || !ok;
+                    const int px = ok ? (int)ix : 0, py = ok ? (int)iy : 0;
+                    bx[u] = ix - (double)px;
+                    by[u] = iy - (double)py;
+                    p0[u] = sc.imgBlob + (cams[c].imgOff + (uint64_t)(py * cw + px));
+                    cwv[u] = cw;
                 }
-                const double col = bilinear(cams[c].img, cw, ix, iy);
-                myc[c * 64] = col;
-                mean += col;
             }
-            if (!bad) {
-                mean /= dK;
-                double sad = 0;
-                for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
-                sad /= dK;
-                double weight = 1;
-                if (useDist) weight *= sc.gauss[xi * S + yi];
-                if (useDiff) weight *= det_exp(-sad * sad / diffW);
-                if (useGrad) weight *= det_exp(-1.0 / (refEdge[ry * refW + rx] * gradW));
-                wsum += weight;
-                fsum += weight * sad;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                r0[u] = 0; r1[u] = 0;
+                if (in[u]) {
+                    r0[u] = load_pair(p0[u]);
+                    r1[u] = load_pair(p0[u] + cwv[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (in[u]) {
+                    const double i00 = (double)(r0[u] & 0xffu), i10 = (double)(r0[u] >> 8);
+                    const double i01 = (double)(r1[u] & 0xffu), i11 = (double)(r1[u] >> 8);
+                    const double ax = 1.0 - bx[u], ay = 1.0 - by[u];
+                    const double t0 = fma(i10, bx[u], i00 * ax);
+                    const double t1 = fma(i11, bx[u], i01 * ax);
+                    const double col = fma(t1, by[u], t0 * ay);
+                    myc[(c0 + u) * 64] = col;
+                    sum += col;
+                }
             }
         }
         if (__any(bad)) return DBL_MAX; // :1001 -- whole call
+        if (act) {
+            const double mean = sum * invK;
+            double sad = 0;
+            for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
+            sad *= invK;
+            double weight = 1;
+            if (useDist) weight *= sc.gauss[xi * S + yi];
+            if (useDiff) weight *= det_exp(-(sad * sad) * invDiffW);
+            if (useGrad) weight *= det_exp(-1.0 / (refEdge[ry * refW + rx] * gradW));
+            wsum += weight;
+            fsum = fma(weight, sad, fsum);
+        }
     }
     fsum = wave_sum(fsum);
     wsum = wave_sum(wsum);
@@ -377,7 +423,7 @@ __device__ void set_lod(const DevScene &sc, pais_patch_result *st, int lane)
             LOD = (LOD - 1) > 0 ? (LOD - 1) : 0;
             break;
         }
-        const uint8_t *img = rc.img[LOD];
+        const uint8_t *img = sc.imgBlob + rc.imgOff[LOD];
         int isum = 0;
         for (int k = lane; k < S2; k += 64) {
             int yi = k / S, xi = k - yi * S;
@@ -463,7 +509,7 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
     bool dropNow = false;
     for (int c = 0; c < K && !dropNow; ++c) {
         const DevCamera &cam = sc.cams[st->cam_idx[c]];
-        const uint8_t *img = cam.img[LOD];
+        const uint8_t *img = sc.imgBlob + cam.imgOff[LOD];
         const int cw = cam.w[LOD], ch = cam.h[LOD];
         const double *H = Hn + 9 * c;
         double *hpc = hp + (size_t)c * S2;
