@@ -9,13 +9,16 @@
  * forwards every batch of constructed-but-unrefined patches to
  * pais_refine_batch() (include/pais_hip.h).
  *
- * Expansion runs in rounds R(B): pop B parents with the
- * reference's queue policy, refine ALL their candidate cells speculatively in
- * one GPU batch, then replay the reference's sequential loop (mvs.cpp:243-272,
- * 529-601) on the host, consuming only the candidates the sequential order
- * would have evaluated.  The accepted cloud is identical to processing the
- * popped parents one by one, and independent of how the batch was split
- * across GPUs.  B = 1 is the reference's own order.
+ * Expansion runs in slot-synchronous rounds R(B): an ordered
+ * active set of up to B parents popped with the reference's queue policy; every
+ * round handles ONE visible-camera slot of each active parent -- all candidate
+ * cells of the round are refined speculatively in one GPU batch, then the
+ * reference's sequential steps (skipNeighborCell, expandCell, insertPatch:
+ * mvs.cpp:552-562, 566-601) are replayed on the host in activation order,
+ * consuming only the candidates the sequential order evaluates.  The accepted
+ * cloud is identical to running that schedule one candidate at a time (the
+ * oracle does exactly that), independent of how a batch was split across GPUs,
+ * and B = 1 is the reference's own order.
  *
  * The stepwise entry points (round_begin / round_commit) exist so that several
  * ranks, each with its own GPU and a replicated driver, can refine disjoint

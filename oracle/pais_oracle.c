@@ -1871,38 +1871,44 @@ static void mvs_insert_patch(po_mvs *m, po_patch *pth)
     }
 }
 
-/* mvs.cpp:529-564 + expandCell :566-577 */
-static void mvs_expand_neighbor_cell(po_mvs *m, int parentId)
+/* one camera slot i of MVS::expandNeighborCell (mvs.cpp:535-563) + expandCell :566-577 */
+static void mvs_expand_slot(po_mvs *m, int parentId, int i)
 {
     const po_scene *s = m->s;
     /* the reference holds a reference into the map; inserting children does
      * not invalidate it, and our slots are stable pointers as well */
     const po_patch *pth = m->patches[parentId];
-    const int camNum = pth->numCam;
-    for (int i = 0; i < camNum; ++i) {
-        const int camI = pth->camIdx[i];
-        po_cellmap *map = &m->cellMaps[camI];
-        int cx = (int)(pth->imgPoint[i][0] / s->cfg.cellSize);
-        int cy = (int)(pth->imgPoint[i][1] / s->cfg.cellSize);
-        int nx[] = {cx - 1, cx, cx + 1, cx};
-        int ny[] = {cy, cy - 1, cy, cy + 1};
-        for (int j = 0; j < 4; ++j) {
-            if (!cm_in_map(map, nx[j], ny[j])) continue;
-            const po_cell *cell = &map->cells[(long)ny[j] * map->width + nx[j]];
-            if (skip_neighbor_cell(m, cell, pth)) continue;
-            double center[3];
-            po_expansion_center(s, camI, pth, nx[j], ny[j], center);
-            po_patch child;
-            po_expand_candidate(s, &child, center, pth->normal, pth->numCam, pth->camIdx,
-                                po_child_key(pth->key, camI, nx[j], ny[j]));
-            m->refineCalls++;
-            m->fitnessEvals += child.psoEvals;
-            mvs_insert_patch(m, &child);
-        }
+    const int camI = pth->camIdx[i];
+    po_cellmap *map = &m->cellMaps[camI];
+    int cx = (int)(pth->imgPoint[i][0] / s->cfg.cellSize);
+    int cy = (int)(pth->imgPoint[i][1] / s->cfg.cellSize);
+    int nx[] = {cx - 1, cx, cx + 1, cx};
+    int ny[] = {cy, cy - 1, cy, cy + 1};
+    for (int j = 0; j < 4; ++j) {
+        if (!cm_in_map(map, nx[j], ny[j])) continue;
+        const po_cell *cell = &map->cells[(long)ny[j] * map->width + nx[j]];
+        if (skip_neighbor_cell(m, cell, pth)) continue;
+        double center[3];
+        po_expansion_center(s, camI, pth, nx[j], ny[j], center);
+        po_patch child;
+        po_expand_candidate(s, &child, center, pth->normal, pth->numCam, pth->camIdx,
+                            po_child_key(pth->key, camI, nx[j], ny[j]));
+        m->refineCalls++;
+        m->fitnessEvals += child.psoEvals;
+        mvs_insert_patch(m, &child);
     }
 }
 
-/* mvs.cpp:233-275 generalised to rounds R(B); B = 1 + strictTail is the reference loop */
+/* MVS::expansionPatches (mvs.cpp:233-275) generalised to the slot-synchronous rounds R(B)
+ * of DESIGN.md section 6:
+ *   - an ordered active set holds up to B popped parents, each with a camera-slot cursor;
+ *   - a round first tops the set up from the queue (reference pop policy, setExpanded,
+ *     runtimeFiltering/delete, mvs.cpp:245-260), then processes ONE camera slot of every
+ *     active parent in activation order, exactly as the body of expandNeighborCell's outer
+ *     loop does (skip test, expandCell, insertPatch), then advances the cursors;
+ *   - a parent leaves the set after its last visible camera.
+ * With B = 1 the sequence of refine()/insertPatch() calls is the reference's own
+ * (including its quirk that the parent popped last is not expanded, :241-243,271). */
 long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
 {
     long before = m->refineCalls;
@@ -1912,30 +1918,40 @@ long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
         if (m->patches[id]) q_push(m, id); /* initPriorityQueue :89-95 */
     po_mvs_set_neighbor_radius(m);
     if (B < 1) B = 1;
-    int *parents = (int *)malloc(sizeof(int) * (size_t)B);
-    int rounds = 0;
+    int *actId = (int *)malloc(sizeof(int) * (size_t)B);
+    int *actSlot = (int *)malloc(sizeof(int) * (size_t)B);
+    int nA = 0, rounds = 0, stop = 0;
     for (;;) {
-        int np = 0;
-        while (np < B) {
+        while (nA < B && !stop) {
             int id = q_pop(m);
             if (id < 0) break;
-            parents[np++] = id;
-        }
-        if (np == 0) break;
-        /* reference quirk (:241-243,271): the parent popped last is processed
-         * only while the queue is still non-empty */
-        if (strictTail && m->qn == 0) break;
-        for (int k = 0; k < np; ++k) {
-            po_patch *pth = m->patches[parents[k]];
-            if (!pth) continue;
+            if (strictTail && B == 1 && m->qn == 0) { stop = 1; break; }
+            po_patch *pth = m->patches[id];
             pth->expanded = 1;
-            if (!po_runtime_filtering(m, pth)) { mvs_delete_patch(m, parents[k]); continue; }
-            mvs_expand_neighbor_cell(m, parents[k]);
+            if (!po_runtime_filtering(m, pth)) { mvs_delete_patch(m, id); continue; }
+            actId[nA] = id;
+            actSlot[nA] = 0;
+            nA++;
         }
+        if (nA == 0) break;
+        for (int a = 0; a < nA; ++a) {
+            mvs_expand_slot(m, actId[a], actSlot[a]);
+            actSlot[a]++;
+        }
+        int w = 0;
+        for (int a = 0; a < nA; ++a) {
+            if (actSlot[a] < m->patches[actId[a]]->numCam) {
+                actId[w] = actId[a];
+                actSlot[w] = actSlot[a];
+                w++;
+            }
+        }
+        nA = w;
         rounds++;
         if (maxRounds > 0 && rounds >= maxRounds) break;
     }
-    free(parents);
+    free(actId);
+    free(actSlot);
     po_mvs_set_neighbor_radius(m);
     return m->refineCalls - before;
 }

@@ -212,9 +212,10 @@ void    po_mvs_destroy(po_mvs *m);
 int     po_mvs_add_seed(po_mvs *m, const double center[3], int numCam, const int *camIdx); /* returns id */
 void    po_mvs_set_neighbor_radius(po_mvs *m);          /* mvs.cpp:147-152, 974-997 */
 void    po_mvs_refine_seed_patches(po_mvs *m);          /* mvs.cpp:196-231 */
-/* Round-based expansion R(B): pop B parents, then process them
- * sequentially exactly as mvs.cpp:243-272 does.  B=1 is the reference loop.
- * maxRounds<=0: run to convergence.  Returns number of refine() calls made. */
+/* Slot-synchronous rounds R(B): an active set of up to B popped
+ * parents; every round processes one visible-camera slot of each active parent, in
+ * activation order, exactly as the body of MVS::expandNeighborCell does.  B=1 is the
+ * reference loop.  maxRounds<=0: run to convergence.  Returns number of refine() calls. */
 long    po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail);
 int     po_mvs_num_patches(const po_mvs *m);
 int     po_mvs_num_slots(const po_mvs *m);              /* ids are 0..slots-1 */

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -344,7 +345,11 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     if (Kmax < 1) Kmax = 1;
     const int N = has_seeds ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
     const int Nmax = N;
-    const int W = pais_launch::pso_waves(N, Kmax, Nmax, ctx->ldsLimit);
+    int W = pais_launch::pso_waves(N, Kmax, Nmax, ctx->ldsLimit);
+    if (const char *e = getenv("PAIS_PSO_WAVES")) { // tuning knob: waves (= concurrent particles) per candidate
+        int w = atoi(e);
+        if (w >= 1 && w <= 16 && pais_launch::pso_lds(w, Kmax, Nmax) <= ctx->ldsLimit) W = w;
+    }
     if (pais_launch::pso_lds(W, Kmax, Nmax) > ctx->ldsLimit) return fail_msg("pais_refine_batch: LDS budget exceeded (too many visible cameras)");
     const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
     int afterGrid = n < 2048 ? n : 2048;

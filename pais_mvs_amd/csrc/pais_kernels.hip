@@ -107,6 +107,53 @@ __device__ __forceinline__ uint32_t load_pair(const uint8_t *p)
     return (uint32_t)v;
 }
 
+// G consecutive cameras of one window pixel: homography (fma), one reciprocal, bounds test,
+// two 16-bit row loads and the fma lerps.  No lane-dependent branches; loads of the G cameras
+// are independent so they overlap.
+template <int G>
+__device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
+                                          int c0, double x, double y, bool act, bool &bad, double &sum)
+{
+    double bx[G], by[G];
+    const uint8_t *p0[G];
+    int cwv[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const int c = c0 + u;
+        const double *H = Hbuf + 9 * c;
+        const double w = fma(H[7], y, fma(H[6], x, H[8]));
+        const double nx = fma(H[1], y, fma(H[0], x, H[2]));
+        const double ny = fma(H[4], y, fma(H[3], x, H[5]));
+        const double rw = 1.0 / w;
+        const double ix = nx * rw, iy = ny * rw;
+        const int cw = cams[c].w, ch = cams[c].h;
+        const bool ok = (ix >= 2 && ix < cw - 3 && iy >= 2 && iy < ch - 3) && (w != 0); // :999 (NaN -> overflow)
+        bad = bad || (act && !ok);
+        const int px = ok ? (int)ix : 0, py = ok ? (int)iy : 0;
+        bx[u] = ix - (double)px;
+        by[u] = iy - (double)py;
+        p0[u] = sc.imgBlob + (cams[c].imgOff + (uint64_t)(uint32_t)(py * cw + px));
+        cwv[u] = cw;
+    }
+    uint32_t r0[G], r1[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        r0[u] = load_pair(p0[u]);
+        r1[u] = load_pair(p0[u] + cwv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const double i00 = (double)(r0[u] & 0xffu), i10 = (double)(r0[u] >> 8);
+        const double i01 = (double)(r1[u] & 0xffu), i11 = (double)(r1[u] >> 8);
+        const double ax = 1.0 - bx[u], ay = 1.0 - by[u];
+        const double t0 = fma(i10, bx[u], i00 * ax);
+        const double t1 = fma(i11, bx[u], i01 * ax);
+        const double col = fma(t1, by[u], t0 * ay);
+        myc[(c0 + u) * 64] = col;
+        sum += col;
+    }
+}
+
 // PAIS::getFitness for one particle, executed by ONE wave (all 64 lanes enter
 // with identical arguments and leave with the identical result).
 //   Hbuf : this wave's LDS scratch, K*9 doubles   (homographies, patch.cpp:290-330)
@@ -175,78 +222,34 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
     double fsum = 0, wsum = 0;
     double *myc = cbuf + lane;
 
+    // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel
+    // index / clamped addresses for lanes that have no pixel, a masked pixel or an overflowing
+    // tap); only wave-uniform conditions branch.  Contributions are selected at the end.
     for (int base = 0; base < S2; base += 64) {
         const int k = base + lane;
         const bool valid = k < S2;
-        const int yi = k / S, xi = k - yi * S;
+        const int kk = valid ? k : (S2 - 1);
+        const int yi = kk / S, xi = kk - yi * S;
         const double x = a0 + (double)xi, y = b0 + (double)yi; // == the reference's ++x / ++y walk
         const int rx = cv_round(x), ry = cv_round(y);
-        const bool act = valid && refImg[ry * refW + rx] != 0; // :986
+        const bool act = valid && (refImg[ry * refW + rx] != 0); // :986
         bool bad = false;
         double sum = 0;
-        for (int c0 = 0; c0 < K; c0 += 4) {
-            double bx[4], by[4];
-            uint32_t r0[4], r1[4];
-            bool in[4];
-            const uint8_t *p0[4];
-            int cwv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + u;
-                in[u] = act && (c < K);
-                bx[u] = 0; by[u] = 0; p0[u] = sc.imgBlob; cwv[u] = 0;
-                if (in[u]) {
-                    const double *H = Hbuf + 9 * c;
-                    const double w = fma(H[7], y, fma(H[6], x, H[8]));
-                    const double nx = fma(H[1], y, fma(H[0], x, H[2]));
-                    const double ny = fma(H[4], y, fma(H[3], x, H[5]));
-                    const double rw = 1.0 / w;
-                    const double ix = nx * rw, iy = ny * rw;
-                    const int cw = cams[c].w, ch = cams[c].h;
-                    const bool ok = (ix >= 2 && ix < cw - 3 && iy >= 2 && iy < ch - 3) && (w != 0); // :999 (NaN -> overflow)
-                    bad = bad || !ok;
-                    const int px = ok ? (int)ix : 0, py = ok ? (int)iy : 0;
-                    bx[u] = ix - (double)px;
-                    by[u] = iy - (double)py;
-                    p0[u] = sc.imgBlob + (cams[c].imgOff + (uint64_t)(py * cw + px));
-                    cwv[u] = cw;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                r0[u] = 0; r1[u] = 0;
-                if (in[u]) {
-                    r0[u] = load_pair(p0[u]);
-                    r1[u] = load_pair(p0[u] + cwv[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (in[u]) {
-                    const double i00 = (double)(r0[u] & 0xffu), i10 = (double)(r0[u] >> 8);
-                    const double i01 = (double)(r1[u] & 0xffu), i11 = (double)(r1[u] >> 8);
-                    const double ax = 1.0 - bx[u], ay = 1.0 - by[u];
-                    const double t0 = fma(i10, bx[u], i00 * ax);
-                    const double t1 = fma(i11, bx[u], i01 * ax);
-                    const double col = fma(t1, by[u], t0 * ay);
-                    myc[(c0 + u) * 64] = col;
-                    sum += col;
-                }
-            }
-        }
+        int c0 = 0;
+        for (; c0 + 4 <= K; c0 += 4) tap_group<4>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
+        if (c0 + 2 <= K) { tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum); c0 += 2; }
+        if (c0 < K) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
         if (__any(bad)) return DBL_MAX; // :1001 -- whole call
-        if (act) {
-            const double mean = sum * invK;
-            double sad = 0;
-            for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
-            sad *= invK;
-            double weight = 1;
-            if (useDist) weight *= sc.gauss[xi * S + yi];
-            if (useDiff) weight *= det_exp(-(sad * sad) * invDiffW);
-            if (useGrad) weight *= det_exp(-1.0 / (refEdge[ry * refW + rx] * gradW));
-            wsum += weight;
-            fsum = fma(weight, sad, fsum);
-        }
+        const double mean = sum * invK;
+        double sad = 0;
+        for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
+        sad *= invK;
+        double weight = 1;
+        if (useDist) weight *= sc.gauss[xi * S + yi];
+        if (useDiff) weight *= det_exp(-(sad * sad) * invDiffW);
+        if (useGrad) weight *= det_exp(-1.0 / (refEdge[ry * refW + rx] * gradW));
+        wsum = act ? (wsum + weight) : wsum;
+        fsum = act ? fma(weight, sad, fsum) : fsum;
     }
     fsum = wave_sum(fsum);
     wsum = wave_sum(wsum);
@@ -700,7 +703,7 @@ struct PsoHeader {
     EvalPatch ep;
 };
 
-__global__ __launch_bounds__(512) void k_pso(DevScene sc, pais_patch_result *recs, int n, int *counters,
+__global__ __launch_bounds__(1024) void k_pso(DevScene sc, pais_patch_result *recs, int n, int *counters,
                                               unsigned long long *stat, int Kmax, int Nmax)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1039,7 +1042,7 @@ int pso_waves(int N, int Kmax, int Nmax, size_t ldsLimit)
 {
     int best = 1;
     double bestScore = -1;
-    for (int W = 1; W <= 8; ++W) {
+    for (int W = 1; W <= 16; ++W) {
         if (pso_lds_bytes(W, Kmax, Nmax) > ldsLimit) break;
         int per = (N + W - 1) / W;
         double eff = (double)N / (double)(per * W); // idle-wave efficiency

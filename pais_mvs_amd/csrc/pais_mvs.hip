@@ -59,11 +59,12 @@ public:
     bool inMap(int x, int y) const { return !(x < 0 || y < 0 || x >= width || y >= height); } // cellmap.cpp:18-23
 };
 
-struct Candidate { // one (parent, visible camera slot, 4-neighbour) cell
-    int parentSlot; // index into the round's parent list
-    int i, j;       // camera slot of the parent, neighbour 0..3
+struct Candidate { // one (active parent, its current camera slot, 4-neighbour) cell
+    int act;        // index into the round's active list
+    int j;          // neighbour 0..3
     int cam, cx, cy;
 };
+struct Active { int id, slot; bool ok; }; // a popped parent and its camera-slot cursor
 
 struct QItem {
     double pri;
@@ -91,8 +92,8 @@ struct pais_mvs {
     long liveQueued = 0;               // alive, unexpanded, queued patches == the reference's queue.size() after a pop
     double neighborRadius = 0;
     // round state
-    std::vector<int> parents;
-    std::vector<char> parentOk;
+    std::vector<Active> active;        // ordered active set of the slot-synchronous rounds
+    bool queueExhausted = false;
     std::vector<Candidate> cands;
     std::vector<pais_candidate> candRecs;
     std::vector<pais_patch_result> results;
@@ -467,7 +468,8 @@ extern "C" int pais_mvs_reset(pais_mvs *m)
     m->qList.clear();
     m->qSeq = 0;
     m->liveQueued = 0;
-    m->parents.clear();
+    m->active.clear();
+    m->queueExhausted = false;
     m->cands.clear();
     m->candRecs.clear();
     m->seedIds.clear();
@@ -577,62 +579,62 @@ extern "C" int pais_mvs_expansion_begin(pais_mvs *m)
     m->setCellMaps();
     m->initPriorityQueue();
     m->setNeighborRadius();
+    m->active.clear();
+    m->queueExhausted = false;
     return 0;
 }
 
+// One round of the slot-synchronous schedule R(B) (the oracle's
+// po_mvs_expansion_patches states the same schedule sequentially):
+//   1. top the ordered active set up to B parents from the queue (reference pop policy,
+//      setExpanded, runtimeFiltering/delete: mvs.cpp:245-260);
+//   2. enumerate, for the CURRENT camera slot of every active parent, the <= 4 neighbour
+//      cells that pass skipNeighborCell on the state before this round -- a superset of what
+//      the sequential order evaluates, because insertions can only turn a candidate into a skip;
+//   3. (caller) refine them all in one GPU batch;
+//   4. round_commit replays the sequential order with the skip test re-applied.
 extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **cands, int *n)
 {
     if (!m || !cands || !n) return mfail("pais_mvs_round_begin: bad argument");
     double t0 = now_ms();
     if (B < 1) B = 1;
-    m->parents.clear();
-    while ((int)m->parents.size() < B) {
-        int id = m->queuePop();
-        if (id < 0) break;
-        m->parents.push_back(id);
-    }
     *cands = nullptr;
     *n = 0;
-    if (m->parents.empty()) return 1;
-    // reference quirk (mvs.cpp:241-243,271): with one parent per round, the parent popped
-    // last is expanded only while the queue is still non-empty
-    if (B == 1 && m->strictTail && m->liveQueued == 0) return 1;
-    m->st.parents_popped += (int64_t)m->parents.size();
-
-    // runtimeFiltering of an inserted patch does not depend on later insertions (its own id
-    // is found in its first visible cell, mvs.cpp:888-889), so it can be decided up front.
-    m->parentOk.assign(m->parents.size(), 0);
-    for (size_t k = 0; k < m->parents.size(); ++k) {
-        HostPatch *p = m->patches[m->parents[k]];
-        bool ok = m->runtimeFiltering(p->r, p->id);
-        m->parentOk[k] = ok ? 1 : 0;
-        p->doomed = !ok;
+    while ((int)m->active.size() < B && !m->queueExhausted) {
+        int id = m->queuePop();
+        if (id < 0) break;
+        // reference quirk (mvs.cpp:241-243,271): with one parent at a time, the parent popped
+        // last is expanded only while the queue is still non-empty
+        if (B == 1 && m->strictTail && m->liveQueued == 0) { m->queueExhausted = true; break; }
+        HostPatch *p = m->patches[id];
+        p->expanded = true;                                   // :250
+        m->st.parents_popped++;
+        if (!m->runtimeFiltering(p->r, p->id)) { m->deletePatch(id); continue; } // :255-260
+        m->active.push_back(Active{id, 0, true});
     }
-    // speculative superset: enumerate against (state - doomed parents); insertions of this
-    // round can only turn a candidate into a skip (skipNeighborCell is monotone in the cell content)
+    if (m->active.empty()) return 1;
+
     m->cands.clear();
     m->candRecs.clear();
-    for (size_t k = 0; k < m->parents.size(); ++k) {
-        if (!m->parentOk[k]) continue;
-        const pais_patch_result &pr = m->patches[m->parents[k]]->r;
-        for (int i = 0; i < pr.num_cam; ++i) {
-            const int camI = pr.cam_idx[i];
-            const CellMap &map = m->cellMaps[camI];
-            const int cx = (int)(pr.imgPoint[i][0] / m->cfg.cellSize);
-            const int cy = (int)(pr.imgPoint[i][1] / m->cfg.cellSize);
-            const int nx[4] = {cx - 1, cx, cx + 1, cx};
-            const int ny[4] = {cy, cy - 1, cy, cy + 1};
-            for (int j = 0; j < 4; ++j) {
-                if (!map.inMap(nx[j], ny[j])) continue;
-                if (m->skipNeighborCell(map, nx[j], ny[j], pr, true)) continue;
-                Candidate c{(int)k, i, j, camI, nx[j], ny[j]};
-                double center[3];
-                m->expansionCenter(camI, pr, nx[j], ny[j], center);
-                pais_candidate rec;
-                m->makeExpandCandidate(pr, center, pais_child_key(pr.key, camI, nx[j], ny[j]), &rec);
-                m->cands.push_back(c);
-                m->candRecs.push_back(rec);
-            }
+    for (size_t a = 0; a < m->active.size(); ++a) {
+        const pais_patch_result &pr = m->patches[m->active[a].id]->r;
+        const int i = m->active[a].slot;
+        const int camI = pr.cam_idx[i];
+        const CellMap &map = m->cellMaps[camI];
+        const int cx = (int)(pr.imgPoint[i][0] / m->cfg.cellSize);
+        const int cy = (int)(pr.imgPoint[i][1] / m->cfg.cellSize);
+        const int nx[4] = {cx - 1, cx, cx + 1, cx};
+        const int ny[4] = {cy, cy - 1, cy, cy + 1};
+        for (int j = 0; j < 4; ++j) {
+            if (!map.inMap(nx[j], ny[j])) continue;
+            if (m->skipNeighborCell(map, nx[j], ny[j], pr, false)) continue;
+            Candidate c{(int)a, j, camI, nx[j], ny[j]};
+            double center[3];
+            m->expansionCenter(camI, pr, nx[j], ny[j], center);
+            pais_candidate rec;
+            m->makeExpandCandidate(pr, center, pais_child_key(pr.key, camI, nx[j], ny[j]), &rec);
+            m->cands.push_back(c);
+            m->candRecs.push_back(rec);
         }
     }
     *cands = m->candRecs.data();
@@ -645,38 +647,35 @@ extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *resul
 {
     if (!m || n != (int)m->cands.size() || (n && !results)) return mfail("pais_mvs_round_commit: bad argument");
     double t0 = now_ms();
-    // exact replay of mvs.cpp:243-272 over the popped parents
     size_t ptr = 0;
-    for (size_t k = 0; k < m->parents.size(); ++k) {
-        const int pid = m->parents[k];
-        HostPatch *p = m->patches[pid];
-        p->expanded = true; // :250
-        p->doomed = false;
-        if (!m->parentOk[k]) { m->deletePatch(pid); continue; } // :255-260
-        const pais_patch_result pr = p->r; // copy: inserts may reallocate nothing we hold, but keep it simple
-        for (int i = 0; i < pr.num_cam; ++i) {
-            const int camI = pr.cam_idx[i];
-            const CellMap &map = m->cellMaps[camI];
-            const int cx = (int)(pr.imgPoint[i][0] / m->cfg.cellSize);
-            const int cy = (int)(pr.imgPoint[i][1] / m->cfg.cellSize);
-            const int nx[4] = {cx - 1, cx, cx + 1, cx};
-            const int ny[4] = {cy, cy - 1, cy, cy + 1};
-            for (int j = 0; j < 4; ++j) {
-                if (!map.inMap(nx[j], ny[j])) continue;
-                // advance to this (k,i,j) in the speculative list, if it is there
-                while (ptr < m->cands.size() &&
-                       (m->cands[ptr].parentSlot < (int)k ||
-                        (m->cands[ptr].parentSlot == (int)k && (m->cands[ptr].i < i || (m->cands[ptr].i == i && m->cands[ptr].j < j)))))
-                    ++ptr;
-                const bool have = ptr < m->cands.size() && m->cands[ptr].parentSlot == (int)k && m->cands[ptr].i == i && m->cands[ptr].j == j;
-                if (m->skipNeighborCell(map, nx[j], ny[j], pr, false)) continue; // :558
-                if (!have) return mfail("pais_mvs_round_commit: speculative candidate set is not a superset (internal error)");
-                m->st.candidates_effective++;
-                m->st.pso_evals_effective += results[ptr].pso_evals;
-                m->insertPatch(results[ptr]); // expandCell :576
-            }
+    for (size_t a = 0; a < m->active.size(); ++a) {
+        const pais_patch_result pr = m->patches[m->active[a].id]->r;
+        const int i = m->active[a].slot;
+        const int camI = pr.cam_idx[i];
+        const CellMap &map = m->cellMaps[camI];
+        const int cx = (int)(pr.imgPoint[i][0] / m->cfg.cellSize);
+        const int cy = (int)(pr.imgPoint[i][1] / m->cfg.cellSize);
+        const int nx[4] = {cx - 1, cx, cx + 1, cx};
+        const int ny[4] = {cy, cy - 1, cy, cy + 1};
+        for (int j = 0; j < 4; ++j) {
+            if (!map.inMap(nx[j], ny[j])) continue;
+            while (ptr < m->cands.size() && (m->cands[ptr].act < (int)a || (m->cands[ptr].act == (int)a && m->cands[ptr].j < j))) ++ptr;
+            const bool have = ptr < m->cands.size() && m->cands[ptr].act == (int)a && m->cands[ptr].j == j;
+            if (m->skipNeighborCell(map, nx[j], ny[j], pr, false)) continue; // mvs.cpp:558
+            if (!have) return mfail("pais_mvs_round_commit: speculative candidate set is not a superset (internal error)");
+            m->st.candidates_effective++;
+            m->st.pso_evals_effective += results[ptr].pso_evals;
+            m->insertPatch(results[ptr]); // expandCell, mvs.cpp:576
         }
     }
+    // advance the cursors; parents that have shown all their cameras leave the set
+    size_t w = 0;
+    for (size_t a = 0; a < m->active.size(); ++a) {
+        Active e = m->active[a];
+        e.slot++;
+        if (e.slot < m->patches[e.id]->r.num_cam) m->active[w++] = e;
+    }
+    m->active.resize(w);
     m->st.candidates_refined += n;
     m->st.rounds++;
     m->cands.clear();
@@ -734,3 +733,4 @@ extern "C" int pais_mvs_get_stats(const pais_mvs *m, pais_mvs_stats *out)
     return 0;
 }
 extern "C" const char *pais_mvs_last_error(void) { return g_mvs_err.c_str(); }
+

@@ -99,7 +99,7 @@ def _run_oracle(cfg, scene, B, max_rounds):
     return pats, calls, S
 
 
-@pytest.mark.parametrize("B,max_rounds", [(1, 25), (8, 6)])
+@pytest.mark.parametrize("B,max_rounds", [(1, 60), (8, 25)])
 def test_scheduler_reproduces_oracle_rounds(pawn_small, B, max_rounds):
     from pais_mvs_amd.config import readme_config
     cfg = readme_config(particleNum=6, maxIteration=8)   # small swarm: this test is about the scheduler
