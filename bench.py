@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="pawn", choices=["pawn", "ring"])
-    ap.add_argument("--parents-per-round", type=int, default=int(os.environ.get("PAIS_B", "512")))
+    ap.add_argument("--parents-per-round", type=int, default=int(os.environ.get("PAIS_B", "4096")))
     ap.add_argument("--max-rounds", type=int, default=0)
     ap.add_argument("--seeds", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
@@ -116,6 +116,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    os.environ.setdefault("PAIS_FINE_TIMING", "1")   # HIP events around every k_pso_eval launch
     from pais_mvs_amd import _lib
     from pais_mvs_amd.mvs import MVS
     from pais_mvs_amd import distributed as D
@@ -168,7 +169,11 @@ def main():
 
     if rank == 0:
         S2 = cfg.patchSize ** 2
-        pso_gbs = (ks.pso_algorithmic_bytes / 1e9) / (ks.pso_ms / 1e3) if ks.pso_ms > 0 else 0.0
+        split = ks.eval_launches > 0 and ks.eval_ms > 0
+        k_ms = ks.eval_ms if split else ks.pso_ms
+        k_launches = ks.eval_launches if split else ks.pso_launches
+        k_name = "k_pso_eval" if split else "k_pso"
+        pso_gbs = (ks.pso_algorithmic_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
         out = {
             "metric": "refined+expanded patches/sec",
             "value": units / dt,
@@ -189,13 +194,13 @@ def main():
                        "rounds_per_step": int(last.rounds) if last else 0,
                        "pso_evals_per_patch": evals_eff / max(units, 1),
                        "parallelism": "candidates sharded over %d GPU(s), 1 all-gather per round" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_pso", "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": k_name, "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pso_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "launches": int(ks.pso_launches), "avg_launch_ms": ks.pso_ms / max(ks.pso_launches, 1),
+                         "launches": int(k_launches), "avg_launch_ms": k_ms / max(k_launches, 1),
                          "evals": int(ks.pso_evals),
                          "algorithmic_bytes_per_eval": (ks.pso_algorithmic_bytes / ks.pso_evals) if ks.pso_evals else 0,
                          "note": "rank-0 kernel; bytes = S^2*(4K+1+8[dist]+8[grad]) per cost evaluation (SURVEY 8d)"},
-            "kernel_ms": {"k_pso": ks.pso_ms, "k_begin": ks.begin_ms, "k_after": ks.after_ms,
+            "kernel_ms": {"pso_pass": ks.pso_ms, "k_pso_eval": ks.eval_ms, "k_begin": ks.begin_ms, "k_after": ks.after_ms,
                           "host_enumerate": last.host_enumerate_ms if last else 0,
                           "host_commit": last.host_commit_ms if last else 0},
         }

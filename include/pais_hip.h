@@ -187,9 +187,12 @@ int  pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candidate *d_cand
 void *pais_ctx_stream(pais_ctx *ctx);
 int  pais_ctx_synchronize(pais_ctx *ctx);
 
-/* Timing of the dominant (PSO) kernel accumulated since the last reset, measured
- * with HIP events on the launch stream: total ms, launches, evaluations executed,
- * algorithmic bytes (S^2*(4K+1+8[dist]+8[grad]) per evaluation). */
+/* Kernel timing accumulated since the last reset, measured with HIP events on the
+ * launch stream.  pso_ms spans one whole PSO pass (k_pso_init + the k_pso_eval /
+ * k_pso_step sequence, or the fused k_pso when PAIS_PSO_MODE=fused); eval_ms /
+ * eval_launches cover the dominant kernel k_pso_eval alone and are only collected
+ * when the environment sets PAIS_FINE_TIMING=1 (bench.py does).  Algorithmic bytes:
+ * SURVEY 8d, S^2*(4K+1+8[dist]+8[grad]) per cost evaluation. */
 typedef struct pais_kernel_stats {
     double   pso_ms;
     double   begin_ms;
@@ -200,6 +203,8 @@ typedef struct pais_kernel_stats {
     double   pso_algorithmic_bytes;
     double   ncc_algorithmic_bytes;
     int64_t  ncc_tables;
+    double   eval_ms;
+    int64_t  eval_launches;
 } pais_kernel_stats;
 int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
 

@@ -58,6 +58,13 @@ struct pais_ctx {
     int *d_counters = nullptr;          // [0] PSO work counter, [1] "needs another pass" count
     unsigned long long *d_stat = nullptr; // [0] evals [1] evals*bytesPerPixel [2] patches [3] ncc tables [4] tables*K
     int *h_counters = nullptr;          // pinned
+    unsigned char *d_psoStates = nullptr; // split pipeline: one PsoState block per candidate
+    size_t psoStateBytes = 0;
+    int psoMode = 1;                    // 1: launch-per-iteration pipeline (default), 0: fused k_pso
+    bool fineTiming = false;            // HIP events around every k_pso_eval launch (bench.py)
+    std::vector<EventPair> evEval;
+    double evalMs = 0;
+    int64_t evalLaunches = 0;
     // fitness batch buffers
     pais_patch_state *d_states = nullptr;
     int32_t *d_idx = nullptr;
@@ -217,6 +224,8 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     HIPCHK(hipMalloc(&ctx->d_stat, sizeof(unsigned long long) * 8));
     HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
     HIPCHK(hipHostMalloc((void **)&ctx->h_counters, sizeof(int) * 4, hipHostMallocDefault));
+    if (const char *e = getenv("PAIS_PSO_MODE")) ctx->psoMode = (strcmp(e, "fused") == 0) ? 0 : 1;
+    if (const char *e = getenv("PAIS_FINE_TIMING")) ctx->fineTiming = atoi(e) != 0;
     *out = ctx;
     return 0;
 }
@@ -230,7 +239,8 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         v.clear();
     };
-    freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evFree);
+    freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evEval); freeEv(ctx->evFree);
+    (void)hipFree(ctx->d_psoStates);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
     (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat);
@@ -348,7 +358,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     int W = pais_launch::pso_waves(N, Kmax, Nmax, ctx->ldsLimit);
     if (const char *e = getenv("PAIS_PSO_WAVES")) { // tuning knob: waves (= concurrent particles) per candidate
         int w = atoi(e);
-        if (w >= 1 && w <= 16 && pais_launch::pso_lds(w, Kmax, Nmax) <= ctx->ldsLimit) W = w;
+        if (w >= 1 && w <= 8 && pais_launch::pso_lds(w, Kmax, Nmax) <= ctx->ldsLimit) W = w;
     }
     if (pais_launch::pso_lds(W, Kmax, Nmax) > ctx->ldsLimit) return fail_msg("pais_refine_batch: LDS budget exceeded (too many visible cameras)");
     const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
@@ -378,7 +388,35 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 2, ctx->stream));
         if (get_event_pair(ctx, ep)) return -2;
         HIPCHK(hipEventRecord(ep.a, ctx->stream));
-        HIPCHK(pais_launch::pso(sc, d_out, n, ctx->d_counters, ctx->d_stat, Kmax, Nmax, W, psoGrid, ctx->stream));
+        if (ctx->psoMode == 0) {
+            HIPCHK(pais_launch::pso(sc, d_out, n, ctx->d_counters, ctx->d_stat, Kmax, Nmax, W, psoGrid, ctx->stream));
+        } else {
+            // launch-per-iteration pipeline: init, eval, step(initFitness), then maxIt x (eval, step)
+            const size_t need = pais_launch::pso_split_state_bytes(Nmax) * (size_t)n;
+            if (need > ctx->psoStateBytes) {
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                (void)hipFree(ctx->d_psoStates);
+                ctx->d_psoStates = nullptr;
+                ctx->psoStateBytes = need + need / 2;
+                HIPCHK(hipMalloc(&ctx->d_psoStates, ctx->psoStateBytes));
+            }
+            const int maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
+            HIPCHK(pais_launch::pso_split_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->stream));
+            for (int it = 0; it <= maxIt; ++it) {
+                EventPair ee;
+                if (ctx->fineTiming) {
+                    if (get_event_pair(ctx, ee)) return -2;
+                    HIPCHK(hipEventRecord(ee.a, ctx->stream));
+                }
+                HIPCHK(pais_launch::pso_split_eval(sc, ctx->d_psoStates, n, Nmax, Kmax, ctx->stream));
+                if (ctx->fineTiming) {
+                    HIPCHK(hipEventRecord(ee.b, ctx->stream));
+                    ctx->evEval.push_back(ee);
+                }
+                ctx->evalLaunches++;
+                HIPCHK(pais_launch::pso_split_step(sc, d_out, ctx->d_psoStates, n, Nmax, ctx->d_stat, ctx->stream));
+            }
+        }
         HIPCHK(hipEventRecord(ep.b, ctx->stream));
         ctx->evPso.push_back(ep);
         ctx->psoLaunches++;
@@ -435,6 +473,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
     if (drain_events(ctx, ctx->evPso, ctx->psoMs)) return -2;
     if (drain_events(ctx, ctx->evBegin, ctx->beginMs)) return -2;
     if (drain_events(ctx, ctx->evAfter, ctx->afterMs)) return -2;
+    if (drain_events(ctx, ctx->evEval, ctx->evalMs)) return -2;
     unsigned long long st[8];
     HIPCHK(hipMemcpy(st, ctx->d_stat, sizeof(st), hipMemcpyDeviceToHost));
     const double S2 = (double)ctx->sc.cfg.patchSize * ctx->sc.cfg.patchSize;
@@ -447,10 +486,13 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
     out->pso_algorithmic_bytes = (double)st[1] * S2;
     out->ncc_tables = (int64_t)st[3];
     out->ncc_algorithmic_bytes = (double)st[4] * S2 * 4.0;
+    out->eval_ms = ctx->evalMs;
+    out->eval_launches = ctx->evalLaunches;
     if (reset) {
         HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
-        ctx->psoMs = ctx->beginMs = ctx->afterMs = 0;
+        ctx->psoMs = ctx->beginMs = ctx->afterMs = ctx->evalMs = 0;
         ctx->psoLaunches = 0;
+        ctx->evalLaunches = 0;
     }
     return 0;
 }

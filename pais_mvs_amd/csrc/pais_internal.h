@@ -44,6 +44,12 @@ int pso_waves(int N, int Kmax, int Nmax, size_t ldsLimit);
 size_t pso_lds(int W, int Kmax, int Nmax);
 hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters, unsigned long long *stat, int Kmax,
                int Nmax, int W, int grid, hipStream_t stream);
+size_t pso_split_state_bytes(int Nmax);
+hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax,
+                          hipStream_t stream);
+hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, hipStream_t stream);
+hipError_t pso_split_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
+                          unsigned long long *stat, hipStream_t stream);
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
                  unsigned long long *stat, int Kmax, hipStream_t stream);
 } // namespace pais_launch

@@ -47,7 +47,8 @@ __device__ __forceinline__ int wave_sum_i(int v)
 struct EvalCam {
     double KR[9];
     double KT[3];
-    uint64_t imgOff; // into DevScene::imgBlob
+    double xmax, ymax; // (double)(w - 3), (double)(h - 3): upper tap bounds of patch.cpp:999
+    uint64_t imgOff;   // into DevScene::imgBlob
     int w, h;
     int cam;
     int pad;
@@ -71,6 +72,8 @@ __device__ void fill_eval_patch(const DevScene &sc, EvalPatch *ep, EvalCam *cams
         cams[c].imgOff = dc.imgOff[LOD];
         cams[c].w = dc.w[LOD];
         cams[c].h = dc.h[LOD];
+        cams[c].xmax = (double)(dc.w[LOD] - 3);
+        cams[c].ymax = (double)(dc.h[LOD] - 3);
         cams[c].cam = camIdx[c];
     }
     if (tid == 0) {
@@ -115,8 +118,8 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
                                           int c0, double x, double y, bool act, bool &bad, double &sum)
 {
     double bx[G], by[G];
-    const uint8_t *p0[G];
-    int cwv[G];
+    const uint8_t *base[G];
+    uint32_t off[G], cwv[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         const int c = c0 + u;
@@ -126,20 +129,22 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
         const double ny = fma(H[4], y, fma(H[3], x, H[5]));
         const double rw = 1.0 / w;
         const double ix = nx * rw, iy = ny * rw;
-        const int cw = cams[c].w, ch = cams[c].h;
-        const bool ok = (ix >= 2 && ix < cw - 3 && iy >= 2 && iy < ch - 3) && (w != 0); // :999 (NaN -> overflow)
-        bad = bad || (act && !ok);
+        // patch.cpp:999 -- evaluated without short-circuit branches; NaN fails every comparison
+        const bool ok = (ix >= 2.0) & (ix < cams[c].xmax) & (iy >= 2.0) & (iy < cams[c].ymax) & (w != 0.0);
+        bad = bad | (act & !ok);
         const int px = ok ? (int)ix : 0, py = ok ? (int)iy : 0;
         bx[u] = ix - (double)px;
         by[u] = iy - (double)py;
-        p0[u] = sc.imgBlob + (cams[c].imgOff + (uint64_t)(uint32_t)(py * cw + px));
+        const uint32_t cw = (uint32_t)cams[c].w;
+        base[u] = sc.imgBlob + cams[c].imgOff; // wave-uniform
+        off[u] = (uint32_t)py * cw + (uint32_t)px;
         cwv[u] = cw;
     }
     uint32_t r0[G], r1[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        r0[u] = load_pair(p0[u]);
-        r1[u] = load_pair(p0[u] + cwv[u]);
+        r0[u] = load_pair(base[u] + off[u]);
+        r1[u] = load_pair(base[u] + (off[u] + cwv[u]));
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -703,7 +708,7 @@ struct PsoHeader {
     EvalPatch ep;
 };
 
-__global__ __launch_bounds__(1024) void k_pso(DevScene sc, pais_patch_result *recs, int n, int *counters,
+__global__ __launch_bounds__(512) void k_pso(DevScene sc, pais_patch_result *recs, int n, int *counters,
                                               unsigned long long *stat, int Kmax, int Nmax)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -910,6 +915,294 @@ __global__ __launch_bounds__(1024) void k_pso(DevScene sc, pais_patch_result *re
     }
 }
 
+// ------------------------------------------------ split PSO pipeline (default) ---
+// The same GLN-PSO as k_pso, as a launch-per-iteration pipeline:
+//   k_pso_init : per candidate, Patch::psoOptimization set-up + initParticles/setParticle
+//   k_pso_eval : ONE WAVE PER (candidate, particle) -- PAIS::getFitness; no barriers, waves that
+//                leave early (DBL_MAX particles) are simply replaced by the next pair
+//   k_pso_step : per candidate, initFitness/updateFitness bookkeeping, updateGbest, inertia,
+//                convergence test, moveParticles -- or the write-back when the run has ended
+// Dependent launches cost ~2 us each against ~100 us of evaluation work per iteration, and the
+// evaluation kernel runs at the throughput of the barrier-free k_fitness.
+struct PsoState { // one per candidate, in global memory; the per-particle arrays follow (stride Nmax)
+    double rangeL[3], rangeU[3], rangeInter[3], init[3];
+    double iw, gBestFitness;
+    uint64_t streamBase;
+    int gIdx, N, maxIt, iteration, active, run, localK, started;
+    // what the evaluation reads from the patch (patch.cpp:922-944)
+    double ray[3];
+    int refCam, LOD, K, pad;
+    int camIdx[PAIS_MAX_VIS];
+};
+__host__ __device__ inline size_t pso_state_bytes(int Nmax)
+{
+    return ((sizeof(PsoState) + 15) & ~(size_t)15) + sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
+}
+struct PsoArrays {
+    double (*pos)[3], (*vec)[3], (*pBest)[3], (*nBest)[3];
+    double *fit, *pBestFit;
+};
+__device__ __forceinline__ PsoArrays pso_arrays(unsigned char *base, int Nmax)
+{
+    PsoArrays a;
+    unsigned char *q = base + ((sizeof(PsoState) + 15) & ~(size_t)15);
+    a.pos = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
+    a.vec = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
+    a.pBest = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
+    a.nBest = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
+    a.fit = (double *)q; q += sizeof(double) * Nmax;
+    a.pBestFit = (double *)q;
+    return a;
+}
+
+__global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_result *recs, int n, unsigned char *states,
+                                                 int Nmax)
+{
+    const int lane = threadIdx.x;
+    const size_t SB = pso_state_bytes(Nmax);
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        const pais_patch_result *P = &recs[c];
+        if (P->stage != PAIS_STAGE_PSO || P->dropped) {
+            if (lane == 0) { hd->active = 0; hd->started = 0; }
+            continue;
+        }
+        const int type = P->type;
+        const int N = (type == PAIS_TYPE_SEED) ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
+        const int maxIt = (type == PAIS_TYPE_SEED) ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
+        // Patch::psoOptimization set-up (patch.cpp:183-200), identical in all lanes
+        const double ns0 = P->normalS[0], ns1 = P->normalS[1];
+        double L[3] = {0.0, ns1 - M_PI / 2.0, P->depthRange[0]};
+        double U[3] = {M_PI, ns1 + M_PI / 2.0, P->depthRange[1]};
+        if (type != PAIS_TYPE_SEED) {
+            double lo = ns0 - M_PI / sc.cfg.reduceNormalRange, hi = ns0 + M_PI / sc.cfg.reduceNormalRange;
+            L[0] = 0.0 < lo ? lo : 0.0;
+            U[0] = hi < M_PI ? hi : M_PI;
+            L[1] = ns1 - M_PI / sc.cfg.reduceNormalRange;
+            U[1] = ns1 + M_PI / sc.cfg.reduceNormalRange;
+        }
+        const double init[3] = {ns0, ns1, P->depth};
+        const uint64_t sb = stream_base(sc.seed, P->key);
+        const uint32_t run = (uint32_t)P->pso_runs;
+        if (lane == 0) {
+            for (int d = 0; d < 3; ++d) {
+                hd->rangeL[d] = L[d];
+                hd->rangeU[d] = U[d];
+                hd->rangeInter[d] = U[d] - L[d]; // psosolver.cpp:38
+                hd->init[d] = init[d];
+                hd->ray[d] = P->ray[d];
+            }
+            hd->N = N;
+            hd->maxIt = maxIt;
+            hd->localK = N < 5 ? N : 5; // psosolver.cpp:26
+            hd->run = (int)run;
+            hd->streamBase = sb;
+            hd->iw = 0.8;
+            hd->iteration = 0;
+            hd->gIdx = 0;
+            hd->gBestFitness = DBL_MAX;
+            hd->active = 1;
+            hd->started = 0;
+            hd->refCam = P->ref_cam;
+            hd->LOD = P->lod;
+            hd->K = P->num_cam;
+        }
+        for (int k = lane; k < P->num_cam; k += 64) hd->camIdx[k] = P->cam_idx[k];
+        // initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
+        for (int i = lane; i < N; i += 64) {
+            for (int d = 0; d < 3; ++d) {
+                const double ri = U[d] - L[d];
+                const double u1 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i)));
+                const double u2 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i) + 1));
+                double p = (ri * u1) + L[d];
+                double v = (2.0 * ri * u2) - ri;
+                if (i == 0) {
+                    p = init[d];
+                    v = (2.0 * ri * uniform_from(sb, run, (uint32_t)(6 * N + d))) - ri;
+                }
+                A.pos[i][d] = p;
+                A.vec[i][d] = v;
+                A.pBest[i][d] = p;
+                A.nBest[i][d] = 0; // particle.cpp:16
+            }
+        }
+    }
+}
+
+// one wave per (candidate, particle)
+__global__ __launch_bounds__(64) void k_pso_eval(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    EvalPatch *ep = (EvalPatch *)smem;
+    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
+    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
+    double *cbuf = Hbuf + Kmax * 9;
+    const int lane = threadIdx.x;
+    const size_t SB = pso_state_bytes(Nmax);
+    const int total = n * Nmax;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        // particle-major task order: the particles of one candidate run on different CUs at the same time
+        const int i = t / n, c = t - i * n;
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        if (!hd->active || i >= hd->N) continue;
+        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        __syncthreads();
+        fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
+        __syncthreads();
+        const double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, A.pos[i][0], A.pos[i][1], A.pos[i][2], lane);
+        if (lane == 0) A.fit[i] = v;
+    }
+}
+
+// one wave per candidate: everything of PsoSolver::run() between two fitness passes
+__global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result *recs, unsigned char *states, int n,
+                                                 int Nmax, unsigned long long *stat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const size_t SB = pso_state_bytes(Nmax);
+    // LDS copies of the swarm (the move reads every particle's pBest)
+    double(*pos)[3] = (double(*)[3])smem;
+    double(*vec)[3] = pos + Nmax;
+    double(*pBest)[3] = vec + Nmax;
+    double(*nBest)[3] = pBest + Nmax;
+    double *fit = (double *)(nBest + Nmax);
+    double *pBestFit = fit + Nmax;
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        if (!hd->active) continue;
+        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        const int N = hd->N, maxIt = hd->maxIt;
+        __syncthreads();
+        for (int i = lane; i < N; i += 64) {
+            for (int d = 0; d < 3; ++d) {
+                pos[i][d] = A.pos[i][d];
+                vec[i][d] = A.vec[i][d];
+                pBest[i][d] = A.pBest[i][d];
+                nBest[i][d] = A.nBest[i][d];
+            }
+            fit[i] = A.fit[i];
+            pBestFit[i] = A.pBestFit[i];
+        }
+        __syncthreads();
+        int it = hd->iteration;
+        int g = hd->gIdx;
+        double gf = hd->gBestFitness;
+        double iw = hd->iw;
+        if (!hd->started) {
+            // initFitness (:112-119) + run(): gBest = particles[0].pBest; updateGbest (:137-149)
+            for (int i = lane; i < N; i += 64) pBestFit[i] = fit[i];
+            __syncthreads();
+            g = 0;
+            gf = pBestFit[0];
+            for (int j = 0; j < N; ++j)
+                if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
+            it = 0;
+        } else {
+            // updateFitness (:121-135): pBest on strict '<'
+            for (int i = lane; i < N; i += 64) {
+                if (fit[i] < pBestFit[i]) {
+                    pBestFit[i] = fit[i];
+                    pBest[i][0] = pos[i][0];
+                    pBest[i][1] = pos[i][1];
+                    pBest[i][2] = pos[i][2];
+                }
+            }
+            __syncthreads();
+            for (int j = 0; j < N; ++j)
+                if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
+            const double niw = iw - 1.0 / maxIt; // :304
+            iw = niw > 0.4 ? niw : 0.4;
+            it += 1;
+        }
+        // loop head of run(): `iteration < maxIteration`, then the convergence break (:293-297)
+        bool finished = it >= maxIt;
+        if (!finished) {
+            const double g0 = pBest[g][0], g1 = pBest[g][1], g2 = pBest[g][2];
+            double disp = 0;
+            for (int i = 0; i < N; ++i) {
+                disp += fabs(pos[i][0] - g0);
+                disp += fabs(pos[i][1] - g1);
+                disp += fabs(pos[i][2] - g2);
+            }
+            disp /= (double)(3 * N);
+            if (disp < 0.01) {
+                double vel = 0;
+                for (int i = 0; i < N; ++i) {
+                    vel += fabs(vec[i][0]);
+                    vel += fabs(vec[i][1]);
+                    vel += fabs(vec[i][2]);
+                }
+                vel /= (double)(3 * N);
+                finished = vel < 0.01;
+            }
+        }
+        if (!finished) {
+            // moveParticles (:220-265) for iteration `it`
+            const double gB[3] = {pBest[g][0], pBest[g][1], pBest[g][2]};
+            const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
+            const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
+            const uint64_t sb = hd->streamBase;
+            const uint32_t run = (uint32_t)hd->run;
+            const int localK = hd->localK;
+            for (int i = lane; i < N; i += 64) {
+                double u[4];
+                const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
+                for (int q = 0; q < 4; ++q) u[q] = uniform_from(sb, run, k0 + q);
+                pso_move_particle(i, N, localK, iw, u, pos, vec, pBest, nBest, fit, pBestFit, gB, rl, ru);
+            }
+            __syncthreads();
+            for (int i = lane; i < N; i += 64) {
+                for (int d = 0; d < 3; ++d) {
+                    A.pos[i][d] = pos[i][d];
+                    A.vec[i][d] = vec[i][d];
+                    A.pBest[i][d] = pBest[i][d];
+                    A.nBest[i][d] = nBest[i][d];
+                }
+                A.pBestFit[i] = pBestFit[i];
+            }
+            if (lane == 0) {
+                hd->iteration = it;
+                hd->gIdx = g;
+                hd->gBestFitness = gf;
+                hd->iw = iw;
+                hd->started = 1;
+            }
+        } else if (lane == 0) {
+            // write back (patch.cpp:208-213) and the maxFitness gate (:156-159)
+            pais_patch_result *P = &recs[c];
+            const double th = pBest[g][0], ph = pBest[g][1], dp = pBest[g][2];
+            double nn[3];
+            spherical2normal(th, ph, nn);
+            P->fitness = gf;
+            P->normalS[0] = th;
+            P->normalS[1] = ph;
+            for (int q = 0; q < 3; ++q) P->normal[q] = nn[q];
+            P->depth = dp;
+            const DevCamera &rc = sc.cams[hd->refCam];
+            for (int q = 0; q < 3; ++q) P->center[q] = hd->ray[q] * dp + rc.C[q];
+            P->pso_runs += 1;
+            P->pso_iterations += it;
+            const int evals = N * (1 + it);
+            P->pso_evals += evals;
+            if (gf > sc.cfg.maxFitness) {
+                P->dropped = 1;
+                P->stage = PAIS_STAGE_DONE;
+            } else {
+                P->stage = PAIS_STAGE_AFTER;
+            }
+            hd->active = 0;
+            const int K = hd->K;
+            const unsigned long long perEval = (unsigned long long)(4 * K + 1 + (sc.cfg.adaptiveDistanceEnable ? 8 : 0) +
+                                                                    (sc.cfg.adaptiveGradientEnable ? 8 : 0));
+            atomicAdd(&stat[0], (unsigned long long)evals);
+            atomicAdd(&stat[1], (unsigned long long)evals * perEval);
+            atomicAdd(&stat[2], 1ULL);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- k_after ---
 // After one PSO run: patch.cpp:161-175 (+ the caller's removeInvisibleCamera,
 // mvs.cpp:215 / :574, once the refine loop has ended).
@@ -1042,7 +1335,7 @@ int pso_waves(int N, int Kmax, int Nmax, size_t ldsLimit)
 {
     int best = 1;
     double bestScore = -1;
-    for (int W = 1; W <= 16; ++W) {
+    for (int W = 1; W <= 8; ++W) {
         if (pso_lds_bytes(W, Kmax, Nmax) > ldsLimit) break;
         int per = (N + W - 1) / W;
         double eff = (double)N / (double)(per * W); // idle-wave efficiency
@@ -1069,6 +1362,37 @@ hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters
     return hipGetLastError();
 }
 size_t pso_lds(int W, int Kmax, int Nmax) { return pso_lds_bytes(W, Kmax, Nmax); }
+
+size_t pso_split_state_bytes(int Nmax) { return pso_state_bytes(Nmax); }
+hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax,
+                          hipStream_t stream)
+{
+    int grid = n < 65536 ? n : 65536;
+    hipLaunchKernelGGL(k_pso_init, dim3(grid), dim3(64), 0, stream, sc, recs, n, states, Nmax);
+    return hipGetLastError();
+}
+hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, hipStream_t stream)
+{
+    size_t lds = fitness_lds_bytes(Kmax);
+    static bool attrSet = false;
+    if (lds > 64 * 1024 && !attrSet) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_pso_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    long total = (long)n * Nmax;
+    int grid = (int)(total < 262144 ? total : 262144);
+    hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax);
+    return hipGetLastError();
+}
+hipError_t pso_split_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
+                          unsigned long long *stat, hipStream_t stream)
+{
+    int grid = n < 65536 ? n : 65536;
+    size_t lds = sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
+    hipLaunchKernelGGL(k_pso_step, dim3(grid), dim3(64), lds, stream, sc, recs, states, n, Nmax, stat);
+    return hipGetLastError();
+}
 
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
                  unsigned long long *stat, int Kmax, hipStream_t stream)

@@ -1,0 +1,30 @@
+"""Kernel-only throughput of the cost evaluation (k_fitness): evals/s at saturation."""
+import sys, os, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pais_mvs_amd import synth, _lib
+from pais_mvs_amd.config import readme_config
+from pais_mvs_amd.context import Context, make_candidate
+sc = synth.pawn_scene(n_seeds=64, build_edges=False)
+cfg = readme_config()
+ctx = Context(cfg, sc.cameras, 0, 42)
+# refine the seeds on the GPU to get realistic patch states
+cands = []
+from pais_mvs_amd.mvs import MVS
+m = MVS(cfg, sc.cameras, device=0, seed=42)
+for X, vis in sc.seeds: m.add_seed(X, vis)
+m.refineSeedPatches()
+ps = m.patches()
+states = []
+for p in ps:
+    st = _lib.PatchState(); st.ray[:] = p.ray[:]; st.ref_cam = p.ref_cam; st.lod = p.lod; st.num_cam = p.num_cam
+    for k in range(p.num_cam): st.cam_idx[k] = p.cam_idx[k]
+    states.append(st)
+rng = np.random.default_rng(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
+idx = rng.integers(0, len(states), n).astype(np.int32)
+parts = np.array([[ps[i].normalS[0] + rng.normal(0, .05), ps[i].normalS[1] + rng.normal(0, .05), ps[i].depth * (1 + rng.normal(0, 1e-3))] for i in idx])
+K = np.mean([ps[i].num_cam for i in idx])
+for rep in range(3):
+    t0 = time.perf_counter(); out = ctx.fitness_batch(states, idx, parts); dt = time.perf_counter() - t0
+    print("evals %d  K %.2f  %.1f ms  %.1f M evals/s  (%.1f G taps/s) finite %.3f" % (n, K, dt * 1e3, n / dt / 1e6, n * 961 * K / dt / 1e9, np.mean(out < 1e300)), flush=True)
