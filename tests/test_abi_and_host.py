@@ -1,0 +1,86 @@
+"""C ABI surface + host-side pieces that need no GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pais_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pais_mvs_amd import _lib
+    L = _lib.load()
+    names = _declared("pais_hip.h") + _declared("pais_mvs.h")
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "pais_mvs_amd", "csrc", "libpais_hip.so")], text=True)
+    for n in names:
+        assert re.search(r"\bT %s\b" % n, nm), n
+
+
+def test_struct_sizes_match_ctypes_mirrors():
+    from pais_mvs_amd import _lib
+    L = _lib.load()
+    assert L.pais_sizeof_config() == C.sizeof(_lib.Config)
+    assert L.pais_sizeof_camera_desc() == C.sizeof(_lib.CameraDesc)
+    assert L.pais_sizeof_candidate() == C.sizeof(_lib.Candidate)
+    assert L.pais_sizeof_patch_result() == C.sizeof(_lib.PatchResult)
+
+
+def test_no_gpu_means_loud_failure(pawn_small):
+    """Without a HIP device the product refuses to work -- it never computes on the host instead."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import Context
+    with pytest.raises(RuntimeError):
+        Context(readme_config(), pawn_small.cameras, device=0)
+    from pais_mvs_amd.mvs import MVS
+    m = MVS(readme_config(), pawn_small.cameras, device=-1)     # scheduler only
+    m.add_seed(pawn_small.seeds[0][0], pawn_small.seeds[0][1])
+    with pytest.raises(RuntimeError):
+        m.refineSeedPatches()
+    with pytest.raises(RuntimeError):
+        m.expansionPatches(4, 1)
+    m.close()
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product package / headers never import, include or link anything under oracle/."""
+    bad = []
+    for base in ("pais_mvs_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"from\s+oracle|import\s+oracle|oracle/|pais_oracle|libpais_oracle|po_detmath", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    ldd = subprocess.check_output(["ldd", os.path.join(ROOT, "pais_mvs_amd", "csrc", "libpais_hip.so")], text=True)
+    assert "oracle" not in ldd
+
+
+def test_pyramid_and_camera_prep(pawn_small):
+    from pais_mvs_amd.camera import resize_area, sobel_magnitude_normalised, max_lod
+    cam = pawn_small.cameras[0]
+    assert cam.max_lod == max_lod(cam.width, cam.height, 0.8, 15) and len(cam.pyramid) == cam.max_lod + 1
+    for l, img in enumerate(cam.pyramid):
+        assert img.dtype == np.uint8 and img.shape == (int(round(cam.height * 0.8 ** l)), int(round(cam.width * 0.8 ** l)))
+    flat = np.full((40, 60), 77, np.uint8)
+    assert (resize_area(flat, 0.8) == 77).all()
+    e = sobel_magnitude_normalised(cam.pyramid[0])
+    assert e.min() == 0.0 and e.max() == 1.0
+    R = cam.rotation
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+    assert np.allclose(cam.translation, -R @ cam.center) and np.allclose(cam.optical_normal, R[2])
