@@ -1520,12 +1520,16 @@ struct po_mvs {
     int qn, qcap;
     long refineCalls;
     long fitnessEvals;
+    int *born;      /* round in which patch id was inserted (-1: before expansion) */
+    int bornCap;
+    int curRound;
 };
 
 po_mvs *po_mvs_create(po_scene *s)
 {
     po_mvs *m = (po_mvs *)calloc(1, sizeof(po_mvs));
     m->s = s;
+    m->curRound = -1;
     return m;
 }
 
@@ -1548,6 +1552,7 @@ void po_mvs_destroy(po_mvs *m)
     free(m->patches);
     cellmaps_free(m);
     free(m->queue);
+    free(m->born);
     free(m);
 }
 
@@ -1560,6 +1565,12 @@ static int mvs_store(po_mvs *m, const po_patch *p)
     po_patch *q = (po_patch *)malloc(sizeof(po_patch));
     *q = *p;
     q->id = m->nslots;
+    if (m->nslots >= m->bornCap) {
+        m->bornCap = m->bornCap ? m->bornCap * 2 : 1024;
+        if (m->bornCap <= m->nslots) m->bornCap = m->nslots + 1024;
+        m->born = (int *)realloc(m->born, sizeof(int) * (size_t)m->bornCap);
+    }
+    m->born[m->nslots] = m->curRound;
     m->patches[m->nslots++] = q;
     m->nalive++;
     return q->id;
@@ -1818,12 +1829,16 @@ static int q_pop(po_mvs *m)
     }
 }
 
-/* mvs.cpp:792-807 */
-static int skip_neighbor_cell(const po_mvs *m, const po_cell *cell, const po_patch *refPth)
+/* mvs.cpp:792-807.  beforeRound >= 0: evaluate on the state before that round started
+ * (patches inserted during it are ignored) -- used by the cell-claim rule of R(B). */
+static int skip_neighbor_cell(const po_mvs *m, const po_cell *cell, const po_patch *refPth, int beforeRound)
 {
-    const int pthNum = cell->n;
+    int pthNum = 0;
+    for (int k = 0; k < cell->n; k++)
+        if (beforeRound < 0 || m->born[cell->ids[k]] < beforeRound) pthNum++;
     if (pthNum >= m->s->cfg.maxCellPatchNum) return 1;
-    for (int k = 0; k < pthNum; k++) {
+    for (int k = 0; k < cell->n; k++) {
+        if (beforeRound >= 0 && m->born[cell->ids[k]] >= beforeRound) continue;
         const po_patch *pth = po_mvs_get_patch(m, cell->ids[k]);
         if (!pth) continue;
         if (pth->correlation > m->s->cfg.minCorrelation) return 1;
@@ -1871,47 +1886,48 @@ static void mvs_insert_patch(po_mvs *m, po_patch *pth)
     }
 }
 
-/* one camera slot i of MVS::expandNeighborCell (mvs.cpp:535-563) + expandCell :566-577 */
-static void mvs_expand_slot(po_mvs *m, int parentId, int i)
+/* expandCell (mvs.cpp:566-577) for neighbour j of camera slot i of a parent */
+static void mvs_expand_one(po_mvs *m, int parentId, int i, int j)
 {
     const po_scene *s = m->s;
-    /* the reference holds a reference into the map; inserting children does
-     * not invalidate it, and our slots are stable pointers as well */
     const po_patch *pth = m->patches[parentId];
     const int camI = pth->camIdx[i];
-    po_cellmap *map = &m->cellMaps[camI];
     int cx = (int)(pth->imgPoint[i][0] / s->cfg.cellSize);
     int cy = (int)(pth->imgPoint[i][1] / s->cfg.cellSize);
-    int nx[] = {cx - 1, cx, cx + 1, cx};
-    int ny[] = {cy, cy - 1, cy, cy + 1};
-    for (int j = 0; j < 4; ++j) {
-        if (!cm_in_map(map, nx[j], ny[j])) continue;
-        const po_cell *cell = &map->cells[(long)ny[j] * map->width + nx[j]];
-        if (skip_neighbor_cell(m, cell, pth)) continue;
-        double center[3];
-        po_expansion_center(s, camI, pth, nx[j], ny[j], center);
-        po_patch child;
-        po_expand_candidate(s, &child, center, pth->normal, pth->numCam, pth->camIdx,
-                            po_child_key(pth->key, camI, nx[j], ny[j]));
-        m->refineCalls++;
-        m->fitnessEvals += child.psoEvals;
-        mvs_insert_patch(m, &child);
-    }
+    const int nx[] = {cx - 1, cx, cx + 1, cx};
+    const int ny[] = {cy, cy - 1, cy, cy + 1};
+    double center[3];
+    po_expansion_center(s, camI, pth, nx[j], ny[j], center);
+    po_patch child;
+    po_expand_candidate(s, &child, center, pth->normal, pth->numCam, pth->camIdx,
+                        po_child_key(pth->key, camI, nx[j], ny[j]));
+    m->refineCalls++;
+    m->fitnessEvals += child.psoEvals;
+    mvs_insert_patch(m, &child);
 }
 
-/* MVS::expansionPatches (mvs.cpp:233-275) generalised to the slot-synchronous rounds R(B)
- * of DESIGN.md section 6:
- *   - an ordered active set holds up to B popped parents, each with a camera-slot cursor;
- *   - a round first tops the set up from the queue (reference pop policy, setExpanded,
- *     runtimeFiltering/delete, mvs.cpp:245-260), then processes ONE camera slot of every
- *     active parent in activation order, exactly as the body of expandNeighborCell's outer
- *     loop does (skip test, expandCell, insertPatch), then advances the cursors;
- *   - a parent leaves the set after its last visible camera.
- * With B = 1 the sequence of refine()/insertPatch() calls is the reference's own
- * (including its quirk that the parent popped last is not expanded, :241-243,271). */
+typedef struct { int id, slot, j; } po_unit;
+
+/* MVS::expansionPatches (mvs.cpp:233-275) generalised to the rounds R(B) of DESIGN.md section 6:
+ *   - an ordered active set holds up to B popped parents, each with a camera-slot cursor; a round
+ *     first tops the set up from the queue (reference pop policy, setExpanded,
+ *     runtimeFiltering/delete, mvs.cpp:245-260);
+ *   - the round's work list is [units deferred by the previous round] followed by the <= 4
+ *     neighbour cells of the CURRENT camera slot of every active parent, in activation order
+ *     (the body of expandNeighborCell's outer loop, mvs.cpp:535-563);
+ *   - a unit whose target cell is already blocked on the state BEFORE the round is dropped
+ *     (that is skipNeighborCell, :558); of several units of one round that target the same
+ *     (camera, cell) only the first is handled now -- the cell is "claimed" -- the others are
+ *     deferred to the head of the next round;
+ *   - a handled unit re-applies skipNeighborCell on the live state, then expandCell + insertPatch;
+ *   - cursors advance; a parent leaves the set after its last visible camera.
+ * With B = 1 no two units of a round share a cell, nothing is ever deferred and the sequence of
+ * refine()/insertPatch() calls is the reference's own (including its quirk that the parent popped
+ * last is not expanded, :241-243,271). */
 long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
 {
     long before = m->refineCalls;
+    const po_scene *s = m->s;
     mvs_set_cell_maps(m);
     m->qn = 0;
     for (int id = 0; id < m->nslots; ++id)
@@ -1921,6 +1937,11 @@ long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
     int *actId = (int *)malloc(sizeof(int) * (size_t)B);
     int *actSlot = (int *)malloc(sizeof(int) * (size_t)B);
     int nA = 0, rounds = 0, stop = 0;
+    po_unit *deferred = NULL, *nextDef = NULL, *work = NULL;
+    int nDef = 0, nNext = 0, capDef = 0, capNext = 0, capWork = 0;
+    uint64_t *claims = NULL;
+    int capClaims = 0;
+    m->curRound = 0;
     for (;;) {
         while (nA < B && !stop) {
             int id = q_pop(m);
@@ -1933,11 +1954,44 @@ long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
             actSlot[nA] = 0;
             nA++;
         }
-        if (nA == 0) break;
-        for (int a = 0; a < nA; ++a) {
-            mvs_expand_slot(m, actId[a], actSlot[a]);
-            actSlot[a]++;
+        if (nA == 0 && nDef == 0) break;
+        /* work list of the round */
+        int nW = nDef + 4 * nA;
+        if (nW > capWork) { capWork = nW * 2; work = (po_unit *)realloc(work, sizeof(po_unit) * (size_t)capWork); }
+        nW = 0;
+        for (int d = 0; d < nDef; ++d) work[nW++] = deferred[d];
+        for (int a = 0; a < nA; ++a)
+            for (int j = 0; j < 4; ++j) { work[nW].id = actId[a]; work[nW].slot = actSlot[a]; work[nW].j = j; nW++; }
+        if (nW > capClaims) { capClaims = nW * 2; claims = (uint64_t *)realloc(claims, sizeof(uint64_t) * (size_t)capClaims); }
+        int nClaims = 0;
+        nNext = 0;
+        for (int u = 0; u < nW; ++u) {
+            const po_patch *pth = m->patches[work[u].id];
+            const int i = work[u].slot, j = work[u].j;
+            const int camI = pth->camIdx[i];
+            po_cellmap *map = &m->cellMaps[camI];
+            int cx = (int)(pth->imgPoint[i][0] / s->cfg.cellSize);
+            int cy = (int)(pth->imgPoint[i][1] / s->cfg.cellSize);
+            const int nx[] = {cx - 1, cx, cx + 1, cx};
+            const int ny[] = {cy, cy - 1, cy, cy + 1};
+            if (!cm_in_map(map, nx[j], ny[j])) continue;
+            const po_cell *cell = &map->cells[(long)ny[j] * map->width + nx[j]];
+            if (skip_neighbor_cell(m, cell, pth, m->curRound)) continue; /* blocked before the round */
+            const uint64_t key = (((uint64_t)(uint32_t)camI) << 48) ^ (((uint64_t)(uint32_t)nx[j]) << 24) ^ (uint64_t)(uint32_t)ny[j];
+            int taken = 0;
+            for (int q = 0; q < nClaims; ++q)
+                if (claims[q] == key) { taken = 1; break; }
+            if (taken) { /* a cell takes one attempt per round: retry next round */
+                if (nNext == capNext) { capNext = capNext ? capNext * 2 : 256; nextDef = (po_unit *)realloc(nextDef, sizeof(po_unit) * (size_t)capNext); }
+                nextDef[nNext++] = work[u];
+                continue;
+            }
+            claims[nClaims++] = key;
+            if (skip_neighbor_cell(m, cell, pth, -1)) continue; /* mvs.cpp:558 on the live state */
+            mvs_expand_one(m, work[u].id, i, j);
         }
+        /* advance */
+        for (int a = 0; a < nA; ++a) actSlot[a]++;
         int w = 0;
         for (int a = 0; a < nA; ++a) {
             if (actSlot[a] < m->patches[actId[a]]->numCam) {
@@ -1947,11 +2001,19 @@ long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
             }
         }
         nA = w;
+        { po_unit *t = deferred; deferred = nextDef; nextDef = t; int c = capDef; capDef = capNext; capNext = c; }
+        nDef = nNext;
         rounds++;
+        m->curRound++;
         if (maxRounds > 0 && rounds >= maxRounds) break;
     }
     free(actId);
     free(actSlot);
+    free(deferred);
+    free(nextDef);
+    free(work);
+    free(claims);
+    m->curRound = -1;
     po_mvs_set_neighbor_radius(m);
     return m->refineCalls - before;
 }

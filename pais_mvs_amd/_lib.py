@@ -82,7 +82,9 @@ def load(build_if_needed: bool = True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("PAIS_LIB_PATH") or _build.LIB   # PAIS_LIB_PATH: tuning variants (scripts/build_variants.py)
+    if path != _build.LIB:
+        build_if_needed = False
     if build_if_needed and _build.needs_build():
         try:
             _build.build()

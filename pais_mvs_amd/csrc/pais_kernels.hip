@@ -22,6 +22,21 @@
 
 using namespace pais;
 
+// Tuning macros of the cost evaluation (scripts/build_variants.py measures them):
+//   PAIS_TAP_GROUP     cameras whose taps are issued together (4, 2 or 1)
+//   PAIS_EVAL_MIN_WAVES  min waves per SIMD requested from the register allocator (0 = unconstrained)
+#ifndef PAIS_TAP_GROUP
+#define PAIS_TAP_GROUP 2 /* measured best: 104 VGPRs -> 4 waves/SIMD (scripts/variant_sweep.sh) */
+#endif
+#ifndef PAIS_EVAL_MIN_WAVES
+#define PAIS_EVAL_MIN_WAVES 0
+#endif
+#if PAIS_EVAL_MIN_WAVES > 0
+#define PAIS_EVAL_BOUNDS __launch_bounds__(64, PAIS_EVAL_MIN_WAVES)
+#else
+#define PAIS_EVAL_BOUNDS __launch_bounds__(64)
+#endif
+
 // --------------------------------------------------------------- helpers ---
 __device__ __forceinline__ void wave_sync()
 {
@@ -130,7 +145,8 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
         const double rw = 1.0 / w;
         const double ix = nx * rw, iy = ny * rw;
         // patch.cpp:999 -- evaluated without short-circuit branches; NaN fails every comparison
-        const bool ok = (ix >= 2.0) & (ix < cams[c].xmax) & (iy >= 2.0) & (iy < cams[c].ymax) & (w != 0.0);
+        // (w == 0 needs no test of its own: rw = inf makes ix, iy +-inf or NaN, which fail the range test)
+        const bool ok = (ix >= 2.0) & (ix < cams[c].xmax) & (iy >= 2.0) & (iy < cams[c].ymax);
         bad = bad | (act & !ok);
         const int px = ok ? (int)ix : 0, py = ok ? (int)iy : 0;
         bx[u] = ix - (double)px;
@@ -241,9 +257,13 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
         bool bad = false;
         double sum = 0;
         int c0 = 0;
+#if PAIS_TAP_GROUP >= 4
         for (; c0 + 4 <= K; c0 += 4) tap_group<4>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
-        if (c0 + 2 <= K) { tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum); c0 += 2; }
-        if (c0 < K) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
+#endif
+#if PAIS_TAP_GROUP >= 2
+        for (; c0 + 2 <= K; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
+#endif
+        for (; c0 < K; ++c0) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
         if (__any(bad)) return DBL_MAX; // :1001 -- whole call
         const double mean = sum * invK;
         double sad = 0;
@@ -263,7 +283,7 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
 
 // ------------------------------------------------------------- k_fitness ---
 // one wave (= one 64-thread workgroup) per evaluation
-__global__ __launch_bounds__(64) void k_fitness(DevScene sc, const pais_patch_state *states, const int32_t *stateIndex,
+__global__ PAIS_EVAL_BOUNDS void k_fitness(DevScene sc, const pais_patch_state *states, const int32_t *stateIndex,
                                                 const double *particles, double *out, int nEvals, int Kmax)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1031,7 +1051,7 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 }
 
 // one wave per (candidate, particle)
-__global__ __launch_bounds__(64) void k_pso_eval(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax)
+__global__ PAIS_EVAL_BOUNDS void k_pso_eval(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EvalPatch *ep = (EvalPatch *)smem;

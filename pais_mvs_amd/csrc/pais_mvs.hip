@@ -13,6 +13,8 @@
 //     ties resolve to the earliest queued id exactly as its strict '<' scan does.
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -20,6 +22,7 @@
 #include <deque>
 #include <queue>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/pais_mvs.h"
@@ -45,8 +48,8 @@ struct HostCamera { // what the driver needs of PAIS::Camera (camera.h)
 struct HostPatch { // AbstractPatch fields the expansion loop reads (abstractpatch.h:22-53)
     pais_patch_result r;
     int id;
+    int born;    // expansion round in which it was inserted (-1: seed / before expansion)
     bool expanded;
-    bool doomed; // popped this round and failing runtimeFiltering: treated as absent while enumerating
 };
 
 struct CellEntry { int id, next; };
@@ -59,12 +62,12 @@ public:
     bool inMap(int x, int y) const { return !(x < 0 || y < 0 || x >= width || y >= height); } // cellmap.cpp:18-23
 };
 
-struct Candidate { // one (active parent, its current camera slot, 4-neighbour) cell
-    int act;        // index into the round's active list
-    int j;          // neighbour 0..3
+struct Unit { int id, slot, j; };        // expansion attempt: neighbour j of camera slot `slot` of parent `id`
+struct Candidate { // a unit that claimed its target cell this round and was sent to the GPU
+    Unit u;
     int cam, cx, cy;
 };
-struct Active { int id, slot; bool ok; }; // a popped parent and its camera-slot cursor
+struct Active { int id, slot; }; // a popped parent and its camera-slot cursor
 
 struct QItem {
     double pri;
@@ -93,6 +96,9 @@ struct pais_mvs {
     double neighborRadius = 0;
     // round state
     std::vector<Active> active;        // ordered active set of the slot-synchronous rounds
+    std::vector<Unit> deferred, nextDeferred; // cell-claim rule: units retried at the head of the next round
+    std::unordered_set<uint64_t> claims;
+    int curRound = -1;
     bool queueExhausted = false;
     std::vector<Candidate> cands;
     std::vector<pais_candidate> candRecs;
@@ -162,20 +168,21 @@ struct pais_mvs {
         return dist <= neighborRadius;
     }
 
-    // ---- MVS::skipNeighborCell, mvs.cpp:792-807 (ignoreDoomed: enumeration view of the round)
-    bool skipNeighborCell(const CellMap &m, int x, int y, const pais_patch_result &ref, bool ignoreDoomed) const
+    // ---- MVS::skipNeighborCell, mvs.cpp:792-807.  beforeRound >= 0: on the state before that round
+    //      (patches inserted during it are ignored; cell-claim rule of R(B))
+    bool skipNeighborCell(const CellMap &m, int x, int y, const pais_patch_result &ref, int beforeRound) const
     {
         int pthNum = 0;
         for (int e = m.head[(size_t)y * m.width + x]; e >= 0; e = pool[e].next) {
             const HostPatch *p = patches[pool[e].id];
-            if (ignoreDoomed && p && p->doomed) continue;
+            if (beforeRound >= 0 && p && p->born >= beforeRound) continue;
             ++pthNum;
         }
         if (pthNum >= cfg.maxCellPatchNum) return true;
         for (int e = m.head[(size_t)y * m.width + x]; e >= 0; e = pool[e].next) {
             const HostPatch *p = patches[pool[e].id];
             if (!p) continue;
-            if (ignoreDoomed && p->doomed) continue;
+            if (beforeRound >= 0 && p->born >= beforeRound) continue;
             if (p->r.correlation > cfg.minCorrelation) return true;
             if (isNeighbor(ref, p->r)) return true;
         }
@@ -280,7 +287,7 @@ struct pais_mvs {
         hp->r = r;
         hp->id = (int)patches.size();
         hp->expanded = false;
-        hp->doomed = false;
+        hp->born = curRound;
         patches.push_back(hp);
         ++alive;
         return hp->id;
@@ -469,6 +476,9 @@ extern "C" int pais_mvs_reset(pais_mvs *m)
     m->qSeq = 0;
     m->liveQueued = 0;
     m->active.clear();
+    m->deferred.clear();
+    m->nextDeferred.clear();
+    m->curRound = -1;
     m->queueExhausted = false;
     m->cands.clear();
     m->candRecs.clear();
@@ -580,19 +590,24 @@ extern "C" int pais_mvs_expansion_begin(pais_mvs *m)
     m->initPriorityQueue();
     m->setNeighborRadius();
     m->active.clear();
+    m->deferred.clear();
+    m->nextDeferred.clear();
+    m->curRound = 0;
     m->queueExhausted = false;
     return 0;
 }
 
-// One round of the slot-synchronous schedule R(B) (the oracle's
-// po_mvs_expansion_patches states the same schedule sequentially):
+// One round of the schedule R(B) (the oracle's po_mvs_expansion_patches
+// states the same schedule one candidate at a time):
 //   1. top the ordered active set up to B parents from the queue (reference pop policy,
 //      setExpanded, runtimeFiltering/delete: mvs.cpp:245-260);
-//   2. enumerate, for the CURRENT camera slot of every active parent, the <= 4 neighbour
-//      cells that pass skipNeighborCell on the state before this round -- a superset of what
-//      the sequential order evaluates, because insertions can only turn a candidate into a skip;
-//   3. (caller) refine them all in one GPU batch;
-//   4. round_commit replays the sequential order with the skip test re-applied.
+//   2. work list = [units deferred by the previous round] + the <= 4 neighbour cells of the CURRENT
+//      camera slot of every active parent; a unit blocked by skipNeighborCell on the pre-round state
+//      is dropped; of the units that target one (camera, cell) only the first is taken ("claims" the
+//      cell), the others are deferred to the next round;
+//   3. (caller) the claimed units are refined in ONE GPU batch -- a superset of what the sequential
+//      order evaluates, because insertions can only turn a candidate into a skip;
+//   4. round_commit replays the sequential order with the skip test re-applied on the live state.
 extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **cands, int *n)
 {
     if (!m || !cands || !n) return mfail("pais_mvs_round_begin: bad argument");
@@ -610,33 +625,37 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
         p->expanded = true;                                   // :250
         m->st.parents_popped++;
         if (!m->runtimeFiltering(p->r, p->id)) { m->deletePatch(id); continue; } // :255-260
-        m->active.push_back(Active{id, 0, true});
+        m->active.push_back(Active{id, 0});
     }
-    if (m->active.empty()) return 1;
+    if (m->active.empty() && m->deferred.empty()) return 1;
 
     m->cands.clear();
     m->candRecs.clear();
-    for (size_t a = 0; a < m->active.size(); ++a) {
-        const pais_patch_result &pr = m->patches[m->active[a].id]->r;
-        const int i = m->active[a].slot;
-        const int camI = pr.cam_idx[i];
+    m->nextDeferred.clear();
+    m->claims.clear();
+    auto consider = [&](const Unit &u) {
+        const pais_patch_result &pr = m->patches[u.id]->r;
+        const int camI = pr.cam_idx[u.slot];
         const CellMap &map = m->cellMaps[camI];
-        const int cx = (int)(pr.imgPoint[i][0] / m->cfg.cellSize);
-        const int cy = (int)(pr.imgPoint[i][1] / m->cfg.cellSize);
+        const int cx = (int)(pr.imgPoint[u.slot][0] / m->cfg.cellSize);
+        const int cy = (int)(pr.imgPoint[u.slot][1] / m->cfg.cellSize);
         const int nx[4] = {cx - 1, cx, cx + 1, cx};
         const int ny[4] = {cy, cy - 1, cy, cy + 1};
-        for (int j = 0; j < 4; ++j) {
-            if (!map.inMap(nx[j], ny[j])) continue;
-            if (m->skipNeighborCell(map, nx[j], ny[j], pr, false)) continue;
-            Candidate c{(int)a, j, camI, nx[j], ny[j]};
-            double center[3];
-            m->expansionCenter(camI, pr, nx[j], ny[j], center);
-            pais_candidate rec;
-            m->makeExpandCandidate(pr, center, pais_child_key(pr.key, camI, nx[j], ny[j]), &rec);
-            m->cands.push_back(c);
-            m->candRecs.push_back(rec);
-        }
-    }
+        const int x = nx[u.j], y = ny[u.j];
+        if (!map.inMap(x, y)) return;
+        if (m->skipNeighborCell(map, x, y, pr, m->curRound)) return; // blocked before the round (== live: nothing inserted yet)
+        const uint64_t key = (((uint64_t)(uint32_t)camI) << 48) ^ (((uint64_t)(uint32_t)x) << 24) ^ (uint64_t)(uint32_t)y;
+        if (!m->claims.insert(key).second) { m->nextDeferred.push_back(u); return; } // one attempt per cell per round
+        double center[3];
+        m->expansionCenter(camI, pr, x, y, center);
+        pais_candidate rec;
+        m->makeExpandCandidate(pr, center, pais_child_key(pr.key, camI, x, y), &rec);
+        m->cands.push_back(Candidate{u, camI, x, y});
+        m->candRecs.push_back(rec);
+    };
+    for (const Unit &u : m->deferred) consider(u);
+    for (const Active &a : m->active)
+        for (int j = 0; j < 4; ++j) consider(Unit{a.id, a.slot, j});
     *cands = m->candRecs.data();
     *n = (int)m->candRecs.size();
     m->st.host_enumerate_ms += now_ms() - t0;
@@ -647,26 +666,13 @@ extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *resul
 {
     if (!m || n != (int)m->cands.size() || (n && !results)) return mfail("pais_mvs_round_commit: bad argument");
     double t0 = now_ms();
-    size_t ptr = 0;
-    for (size_t a = 0; a < m->active.size(); ++a) {
-        const pais_patch_result pr = m->patches[m->active[a].id]->r;
-        const int i = m->active[a].slot;
-        const int camI = pr.cam_idx[i];
-        const CellMap &map = m->cellMaps[camI];
-        const int cx = (int)(pr.imgPoint[i][0] / m->cfg.cellSize);
-        const int cy = (int)(pr.imgPoint[i][1] / m->cfg.cellSize);
-        const int nx[4] = {cx - 1, cx, cx + 1, cx};
-        const int ny[4] = {cy, cy - 1, cy, cy + 1};
-        for (int j = 0; j < 4; ++j) {
-            if (!map.inMap(nx[j], ny[j])) continue;
-            while (ptr < m->cands.size() && (m->cands[ptr].act < (int)a || (m->cands[ptr].act == (int)a && m->cands[ptr].j < j))) ++ptr;
-            const bool have = ptr < m->cands.size() && m->cands[ptr].act == (int)a && m->cands[ptr].j == j;
-            if (m->skipNeighborCell(map, nx[j], ny[j], pr, false)) continue; // mvs.cpp:558
-            if (!have) return mfail("pais_mvs_round_commit: speculative candidate set is not a superset (internal error)");
-            m->st.candidates_effective++;
-            m->st.pso_evals_effective += results[ptr].pso_evals;
-            m->insertPatch(results[ptr]); // expandCell, mvs.cpp:576
-        }
+    for (int q = 0; q < n; ++q) {
+        const Candidate &c = m->cands[q];
+        const pais_patch_result &pr = m->patches[c.u.id]->r; // stable: patches are heap objects
+        if (m->skipNeighborCell(m->cellMaps[c.cam], c.cx, c.cy, pr, -1)) continue; // mvs.cpp:558 on the live state
+        m->st.candidates_effective++;
+        m->st.pso_evals_effective += results[q].pso_evals;
+        m->insertPatch(results[q]); // expandCell, mvs.cpp:576
     }
     // advance the cursors; parents that have shown all their cameras leave the set
     size_t w = 0;
@@ -676,8 +682,11 @@ extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *resul
         if (e.slot < m->patches[e.id]->r.num_cam) m->active[w++] = e;
     }
     m->active.resize(w);
+    m->deferred.swap(m->nextDeferred);
+    m->nextDeferred.clear();
     m->st.candidates_refined += n;
     m->st.rounds++;
+    m->curRound++;
     m->cands.clear();
     m->st.host_commit_ms += now_ms() - t0;
     return 0;
