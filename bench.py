@@ -169,10 +169,13 @@ def main():
 
     if rank == 0:
         S2 = cfg.patchSize ** 2
+        # k_pso_eval is timed launch by launch with HIP events when the PSO pipeline runs on one stream
+        # (PAIS_PSO_STREAMS=1); with the default 2 overlapping streams individual launches overlap, so the
+        # span of the whole PSO pass (k_pso_init + every k_pso_eval/k_pso_step of all slices) is used instead
         split = ks.eval_launches > 0 and ks.eval_ms > 0
         k_ms = ks.eval_ms if split else ks.pso_ms
-        k_launches = ks.eval_launches if split else ks.pso_launches
-        k_name = "k_pso_eval" if split else "k_pso"
+        k_launches = ks.eval_launches if ks.eval_launches > 0 else ks.pso_launches
+        k_name = "k_pso_eval" if split else ("k_pso_eval (span of the overlapped PSO pass)" if ks.eval_launches > 0 else "k_pso")
         pso_gbs = (ks.pso_algorithmic_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
         out = {
             "metric": "refined+expanded patches/sec",

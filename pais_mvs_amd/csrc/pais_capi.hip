@@ -60,7 +60,15 @@ struct pais_ctx {
     int *h_counters = nullptr;          // pinned
     unsigned char *d_psoStates = nullptr; // split pipeline: one PsoState block per candidate
     size_t psoStateBytes = 0;
-    int psoMode = 1;                    // 1: launch-per-iteration pipeline (default), 0: fused k_pso
+    int psoMode = 1;                    // 1: eval + step kernels per iteration, pipelined over several streams (default),
+                                        // 2: eval launches with last-arriver step, 3: persistent task-queue kernel,
+                                        // 0: fused one-workgroup-per-candidate k_pso  (measured alternatives)
+    int psoStreams = 2;                 // slices of a batch whose eval/step sequences overlap on separate HIP streams
+    std::vector<hipStream_t> sub;       // sub-streams
+    std::vector<hipEvent_t> subDone;
+    hipEvent_t forkEv = nullptr;
+    int *d_queue = nullptr;
+    size_t queueInts = 0;
     bool fineTiming = false;            // HIP events around every k_pso_eval launch (bench.py)
     std::vector<EventPair> evEval;
     double evalMs = 0;
@@ -224,7 +232,17 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     HIPCHK(hipMalloc(&ctx->d_stat, sizeof(unsigned long long) * 8));
     HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
     HIPCHK(hipHostMalloc((void **)&ctx->h_counters, sizeof(int) * 4, hipHostMallocDefault));
-    if (const char *e = getenv("PAIS_PSO_MODE")) ctx->psoMode = (strcmp(e, "fused") == 0) ? 0 : 1;
+    if (const char *e = getenv("PAIS_PSO_MODE"))
+        ctx->psoMode = (strcmp(e, "fused") == 0) ? 0 : (strcmp(e, "laststep") == 0) ? 2 : (strcmp(e, "persist") == 0) ? 3 : 1;
+    if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
+    HIPCHK(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming));
+    for (int i = 0; i < ctx->psoStreams; ++i) {
+        hipStream_t st; hipEvent_t ev;
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->sub.push_back(st);
+        ctx->subDone.push_back(ev);
+    }
     if (const char *e = getenv("PAIS_FINE_TIMING")) ctx->fineTiming = atoi(e) != 0;
     *out = ctx;
     return 0;
@@ -241,6 +259,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     };
     freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evEval); freeEv(ctx->evFree);
     (void)hipFree(ctx->d_psoStates);
+    (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
     (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat);
@@ -402,19 +421,86 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
             }
             const int maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
             HIPCHK(pais_launch::pso_split_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->stream));
-            for (int it = 0; it <= maxIt; ++it) {
+            if (ctx->psoMode == 3) {
+                const size_t qi = pais_launch::pso_queue_ints(n, Nmax, maxIt);
+                if (qi > ctx->queueInts) {
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                    (void)hipFree(ctx->d_queue);
+                    ctx->d_queue = nullptr;
+                    ctx->queueInts = qi + qi / 2;
+                    HIPCHK(hipMalloc(&ctx->d_queue, ctx->queueInts * sizeof(int)));
+                }
                 EventPair ee;
                 if (ctx->fineTiming) {
                     if (get_event_pair(ctx, ee)) return -2;
                     HIPCHK(hipEventRecord(ee.a, ctx->stream));
                 }
-                HIPCHK(pais_launch::pso_split_eval(sc, ctx->d_psoStates, n, Nmax, Kmax, ctx->stream));
+                HIPCHK(pais_launch::pso_persist(sc, ctx->d_psoStates, n, Nmax, Kmax, maxIt, d_out, ctx->d_stat, ctx->d_queue, ctx->numCUs, ctx->stream));
+                if (getenv("PAIS_DEBUG_QUEUE")) {
+                    int hq[4];
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                    HIPCHK(hipMemcpy(hq, ctx->d_queue, sizeof(hq), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[ptrs] states %p (+%zu) queue %p (+%zu) recs %p hp %p (+%zu)\n", (void *)ctx->d_psoStates, ctx->psoStateBytes, (void *)ctx->d_queue, ctx->queueInts * 4, (void *)d_out, (void *)ctx->d_hp, ctx->hpBytes);
+                    fprintf(stderr, "[queue] n %d Nmax %d Kmax %d maxIt %d -> head %d tail %d active %d cap %d (err %s)\n", n, Nmax, Kmax, maxIt, hq[0], hq[1], hq[2], hq[3], hipGetErrorString(hipGetLastError()));
+                    const size_t SB = pais_launch::pso_split_state_bytes(Nmax);
+                    std::vector<unsigned char> hs(SB * (size_t)n);
+                    HIPCHK(hipMemcpy(hs.data(), ctx->d_psoStates, hs.size(), hipMemcpyDeviceToHost));
+                    // PsoState layout: 12 doubles, iw, gBestFitness, streamBase, then ints gIdx,N,maxIt,iteration,active,run,localK,started,arrived
+                    int cnt[4] = {0, 0, 0, 0};
+                    for (int c = 0; c < n && c < 100000; ++c) {
+                        const int *ip = (const int *)(hs.data() + SB * (size_t)c + 15 * 8);
+                        if (c < 6 || (c % 97) == 0) fprintf(stderr, "   cand %d: gIdx %d N %d maxIt %d it %d active %d run %d K %d started %d arrived %d\n", c, ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], ip[7], ip[8]);
+                        cnt[0] += ip[4]; cnt[1] += ip[7]; cnt[2] += (ip[8] != 0); cnt[3] += ip[3];
+                    }
+                    fprintf(stderr, "   still active %d started %d arrived!=0 %d sum(it) %d\n", cnt[0], cnt[1], cnt[2], cnt[3]);
+                }
                 if (ctx->fineTiming) {
                     HIPCHK(hipEventRecord(ee.b, ctx->stream));
                     ctx->evEval.push_back(ee);
                 }
                 ctx->evalLaunches++;
-                HIPCHK(pais_launch::pso_split_step(sc, d_out, ctx->d_psoStates, n, Nmax, ctx->d_stat, ctx->stream));
+            } else if (ctx->psoMode == 2) {
+                for (int it = 0; it <= maxIt; ++it) {
+                    HIPCHK(pais_launch::pso_split_eval(sc, ctx->d_psoStates, n, Nmax, Kmax, d_out, ctx->d_stat, 1, ctx->stream));
+                    ctx->evalLaunches++;
+                }
+            } else {
+                // default: the candidates are cut into contiguous slices; slice s runs its own
+                // (eval, step) x (maxIt+1) sequence on sub-stream s, so the step of one slice (a few
+                // waves, latency bound) overlaps the evaluations of the others and every evaluation
+                // launch fits into one residency pass of the GPU
+                int S = ctx->psoStreams;
+                const int minPer = 64; // slices smaller than this only add launch overhead
+                if (n < S * minPer) S = (n + minPer - 1) / minPer;
+                if (S < 1) S = 1;
+                const size_t SB = pais_launch::pso_split_state_bytes(Nmax);
+                HIPCHK(hipEventRecord(ctx->forkEv, ctx->stream));
+                for (int sI = 0; sI < S; ++sI) {
+                    const int lo = (int)((long)n * sI / S), hi = (int)((long)n * (sI + 1) / S);
+                    if (hi <= lo) continue;
+                    hipStream_t st = (S == 1) ? ctx->stream : ctx->sub[sI];
+                    if (S > 1) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
+                    unsigned char *stp = ctx->d_psoStates + SB * (size_t)lo;
+                    for (int it = 0; it <= maxIt; ++it) {
+                        EventPair ee;
+                        const bool timeIt = ctx->fineTiming && S == 1;
+                        if (timeIt) {
+                            if (get_event_pair(ctx, ee)) return -2;
+                            HIPCHK(hipEventRecord(ee.a, st));
+                        }
+                        HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0, st));
+                        if (timeIt) {
+                            HIPCHK(hipEventRecord(ee.b, st));
+                            ctx->evEval.push_back(ee);
+                        }
+                        ctx->evalLaunches++;
+                        HIPCHK(pais_launch::pso_split_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
+                    }
+                    if (S > 1) {
+                        HIPCHK(hipEventRecord(ctx->subDone[sI], st));
+                        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI], 0));
+                    }
+                }
             }
         }
         HIPCHK(hipEventRecord(ep.b, ctx->stream));

@@ -47,7 +47,11 @@ hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters
 size_t pso_split_state_bytes(int Nmax);
 hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax,
                           hipStream_t stream);
-hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, hipStream_t stream);
+hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
+                          unsigned long long *stat, int fuseStep, hipStream_t stream);
+size_t pso_queue_ints(int n, int Nmax, int maxIt);
+hipError_t pso_persist(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, int maxIt, pais_patch_result *recs,
+                       unsigned long long *stat, int *qmem, int numCUs, hipStream_t stream);
 hipError_t pso_split_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                           unsigned long long *stat, hipStream_t stream);
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,

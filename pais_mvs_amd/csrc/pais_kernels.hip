@@ -949,6 +949,7 @@ struct PsoState { // one per candidate, in global memory; the per-particle array
     double iw, gBestFitness;
     uint64_t streamBase;
     int gIdx, N, maxIt, iteration, active, run, localK, started;
+    int arrived, pad0;  // particles evaluated in the current launch (last arriver runs the step)
     // what the evaluation reads from the patch (patch.cpp:922-944)
     double ray[3];
     int refCam, LOD, K, pad;
@@ -1024,6 +1025,7 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
             hd->gBestFitness = DBL_MAX;
             hd->active = 1;
             hd->started = 0;
+            hd->arrived = 0;
             hd->refCam = P->ref_cam;
             hd->LOD = P->lod;
             hd->K = P->num_cam;
@@ -1050,176 +1052,358 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
     }
 }
 
-// one wave per (candidate, particle)
-__global__ PAIS_EVAL_BOUNDS void k_pso_eval(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax)
+__device__ void pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
+                              unsigned char *smem, unsigned long long *stat, int lane, bool fitShared);
+
+// one wave per (candidate, particle).  fuseStep != 0 (default pipeline): the wave that delivers the
+// last fitness of a candidate runs that candidate's step right away (no separate k_pso_step launch).
+// Cross-wave hand-off (MI355X: per-XCD L2s are not coherent, L1 never refreshed): the fitness is
+// published with an agent-scope (sc1, write-through) atomic store, drained with s_waitcnt vmcnt(0),
+// then the arrival counter is bumped with an agent-scope atomic; the last arriver reads the other
+// particles' fitness with agent-scope atomic loads (cdna_hip_programming.md G16, "8-B agent atomics
+// both sides").  Everything else the step reads was written by a previous launch.
+__global__ PAIS_EVAL_BOUNDS void k_pso_eval(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+                                            pais_patch_result *recs, unsigned long long *stat, int fuseStep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
     double *cbuf = Hbuf + Kmax * 9;
+    unsigned char *stepSmem = (unsigned char *)(cbuf + (size_t)Kmax * 64);
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
     const int total = n * Nmax;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        // particle-major task order: the particles of one candidate run on different CUs at the same time
-        const int i = t / n, c = t - i * n;
+        // candidate-major task order: a candidate's particles are neighbours in the grid, so they finish
+        // together, its step runs early and overlaps with the evaluations of later candidates, and the
+        // waves of one CU gather from the same few image windows
+        const int c = t / Nmax, i = t - c * Nmax;
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         if (!hd->active || i >= hd->N) continue;
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        const int N = hd->N;
         __syncthreads();
         fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
         __syncthreads();
         const double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, A.pos[i][0], A.pos[i][1], A.pos[i][2], lane);
-        if (lane == 0) A.fit[i] = v;
+        if (!fuseStep) {
+            if (lane == 0) A.fit[i] = v;
+            continue;
+        }
+        int last = 0;
+        if (lane == 0) {
+            __hip_atomic_store(&A.fit[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int prev = __hip_atomic_fetch_add(&hd->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (prev == N - 1) ? 1 : 0;
+        }
+        last = __shfl(last, 0, 64);
+        if (last) pso_step_wave(sc, recs, c, hd, Nmax, stepSmem, stat, lane, true);
     }
 }
 
-// one wave per candidate: everything of PsoSolver::run() between two fitness passes
-__global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result *recs, unsigned char *states, int n,
-                                                 int Nmax, unsigned long long *stat)
+// Intra-launch sharing between waves on different CUs / XCDs (per-XCD L2s are not coherent, a CU's L1 is
+// never refreshed): 8-byte / 4-byte agent-scope relaxed atomics on both sides (cdna_hip_programming.md G16).
+template <typename T> __device__ __forceinline__ T ld_agent(const T *p)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const size_t SB = pso_state_bytes(Nmax);
-    // LDS copies of the swarm (the move reads every particle's pBest)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ void st_agent(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// task queue of the persistent PSO kernel: header + `cap` int slots (-1 = not yet produced)
+struct PsoQueue {
+    int head;        // next ticket handed to a consumer
+    int tail;        // next slot a producer reserves
+    int activeCands; // candidates whose PSO run has not ended
+    int cap;
+};
+
+// Everything of PsoSolver::run() between two fitness passes, for ONE candidate, by one wave.
+// smem: Nmax*(3*4+2) doubles of LDS scratch.
+//   MODE 0: state written by a previous launch (k_pso_step)
+//   MODE 1: only fit[] was produced in this launch (k_pso_eval with last-arriver step)
+//   MODE 2: persistent kernel -- the whole swarm state is handed from stepper to stepper inside one
+//           launch; returns 1 if the candidate continues (caller enqueues the next N evaluations)
+template <int MODE>
+__device__ int pso_step_wave_t(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
+                               unsigned char *smem, unsigned long long *stat, int lane)
+{
+    constexpr bool fitShared = MODE >= 1;
+    constexpr bool allShared = MODE == 2;
     double(*pos)[3] = (double(*)[3])smem;
     double(*vec)[3] = pos + Nmax;
     double(*pBest)[3] = vec + Nmax;
     double(*nBest)[3] = pBest + Nmax;
     double *fit = (double *)(nBest + Nmax);
     double *pBestFit = fit + Nmax;
-    for (int c = blockIdx.x; c < n; c += gridDim.x) {
-        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
-        if (!hd->active) continue;
-        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
-        const int N = hd->N, maxIt = hd->maxIt;
+    PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+    const int N = hd->N, maxIt = hd->maxIt;
+    __syncthreads();
+    for (int i = lane; i < N; i += 64) {
+        for (int d = 0; d < 3; ++d) {
+            pos[i][d] = allShared ? ld_agent(&A.pos[i][d]) : A.pos[i][d];
+            vec[i][d] = allShared ? ld_agent(&A.vec[i][d]) : A.vec[i][d];
+            pBest[i][d] = allShared ? ld_agent(&A.pBest[i][d]) : A.pBest[i][d];
+            nBest[i][d] = allShared ? ld_agent(&A.nBest[i][d]) : A.nBest[i][d];
+        }
+        fit[i] = fitShared ? ld_agent(&A.fit[i]) : A.fit[i];
+        pBestFit[i] = allShared ? ld_agent(&A.pBestFit[i]) : A.pBestFit[i];
+    }
+    __syncthreads();
+    int it = allShared ? ld_agent(&hd->iteration) : hd->iteration;
+    int g = allShared ? ld_agent(&hd->gIdx) : hd->gIdx;
+    double gf = allShared ? ld_agent(&hd->gBestFitness) : hd->gBestFitness;
+    double iw = allShared ? ld_agent(&hd->iw) : hd->iw;
+    const int started = allShared ? ld_agent(&hd->started) : hd->started;
+    if (!started) {
+        // initFitness (:112-119) + run(): gBest = particles[0].pBest; updateGbest (:137-149)
+        for (int i = lane; i < N; i += 64) pBestFit[i] = fit[i];
+        __syncthreads();
+        g = 0;
+        gf = pBestFit[0];
+        for (int j = 0; j < N; ++j)
+            if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
+        it = 0;
+    } else {
+        // updateFitness (:121-135): pBest on strict '<'
+        for (int i = lane; i < N; i += 64) {
+            if (fit[i] < pBestFit[i]) {
+                pBestFit[i] = fit[i];
+                pBest[i][0] = pos[i][0];
+                pBest[i][1] = pos[i][1];
+                pBest[i][2] = pos[i][2];
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < N; ++j)
+            if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
+        const double niw = iw - 1.0 / maxIt; // :304
+        iw = niw > 0.4 ? niw : 0.4;
+        it += 1;
+    }
+    // loop head of run(): `iteration < maxIteration`, then the convergence break (:293-297)
+    bool finished = it >= maxIt;
+    if (!finished) {
+        const double g0 = pBest[g][0], g1 = pBest[g][1], g2 = pBest[g][2];
+        double disp = 0;
+        for (int i = 0; i < N; ++i) {
+            disp += fabs(pos[i][0] - g0);
+            disp += fabs(pos[i][1] - g1);
+            disp += fabs(pos[i][2] - g2);
+        }
+        disp /= (double)(3 * N);
+        if (disp < 0.01) {
+            double vel = 0;
+            for (int i = 0; i < N; ++i) {
+                vel += fabs(vec[i][0]);
+                vel += fabs(vec[i][1]);
+                vel += fabs(vec[i][2]);
+            }
+            vel /= (double)(3 * N);
+            finished = vel < 0.01;
+        }
+    }
+    if (!finished) {
+        // moveParticles (:220-265) for iteration `it`
+        const double gB[3] = {pBest[g][0], pBest[g][1], pBest[g][2]};
+        const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
+        const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
+        const uint64_t sb = hd->streamBase;
+        const uint32_t run = (uint32_t)hd->run;
+        const int localK = hd->localK;
+        for (int i = lane; i < N; i += 64) {
+            double u[4];
+            const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
+            for (int q = 0; q < 4; ++q) u[q] = uniform_from(sb, run, k0 + q);
+            pso_move_particle(i, N, localK, iw, u, pos, vec, pBest, nBest, fit, pBestFit, gB, rl, ru);
+        }
         __syncthreads();
         for (int i = lane; i < N; i += 64) {
             for (int d = 0; d < 3; ++d) {
-                pos[i][d] = A.pos[i][d];
-                vec[i][d] = A.vec[i][d];
-                pBest[i][d] = A.pBest[i][d];
-                nBest[i][d] = A.nBest[i][d];
-            }
-            fit[i] = A.fit[i];
-            pBestFit[i] = A.pBestFit[i];
-        }
-        __syncthreads();
-        int it = hd->iteration;
-        int g = hd->gIdx;
-        double gf = hd->gBestFitness;
-        double iw = hd->iw;
-        if (!hd->started) {
-            // initFitness (:112-119) + run(): gBest = particles[0].pBest; updateGbest (:137-149)
-            for (int i = lane; i < N; i += 64) pBestFit[i] = fit[i];
-            __syncthreads();
-            g = 0;
-            gf = pBestFit[0];
-            for (int j = 0; j < N; ++j)
-                if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
-            it = 0;
-        } else {
-            // updateFitness (:121-135): pBest on strict '<'
-            for (int i = lane; i < N; i += 64) {
-                if (fit[i] < pBestFit[i]) {
-                    pBestFit[i] = fit[i];
-                    pBest[i][0] = pos[i][0];
-                    pBest[i][1] = pos[i][1];
-                    pBest[i][2] = pos[i][2];
-                }
-            }
-            __syncthreads();
-            for (int j = 0; j < N; ++j)
-                if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
-            const double niw = iw - 1.0 / maxIt; // :304
-            iw = niw > 0.4 ? niw : 0.4;
-            it += 1;
-        }
-        // loop head of run(): `iteration < maxIteration`, then the convergence break (:293-297)
-        bool finished = it >= maxIt;
-        if (!finished) {
-            const double g0 = pBest[g][0], g1 = pBest[g][1], g2 = pBest[g][2];
-            double disp = 0;
-            for (int i = 0; i < N; ++i) {
-                disp += fabs(pos[i][0] - g0);
-                disp += fabs(pos[i][1] - g1);
-                disp += fabs(pos[i][2] - g2);
-            }
-            disp /= (double)(3 * N);
-            if (disp < 0.01) {
-                double vel = 0;
-                for (int i = 0; i < N; ++i) {
-                    vel += fabs(vec[i][0]);
-                    vel += fabs(vec[i][1]);
-                    vel += fabs(vec[i][2]);
-                }
-                vel /= (double)(3 * N);
-                finished = vel < 0.01;
-            }
-        }
-        if (!finished) {
-            // moveParticles (:220-265) for iteration `it`
-            const double gB[3] = {pBest[g][0], pBest[g][1], pBest[g][2]};
-            const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
-            const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
-            const uint64_t sb = hd->streamBase;
-            const uint32_t run = (uint32_t)hd->run;
-            const int localK = hd->localK;
-            for (int i = lane; i < N; i += 64) {
-                double u[4];
-                const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
-                for (int q = 0; q < 4; ++q) u[q] = uniform_from(sb, run, k0 + q);
-                pso_move_particle(i, N, localK, iw, u, pos, vec, pBest, nBest, fit, pBestFit, gB, rl, ru);
-            }
-            __syncthreads();
-            for (int i = lane; i < N; i += 64) {
-                for (int d = 0; d < 3; ++d) {
+                if (allShared) {
+                    st_agent(&A.pos[i][d], pos[i][d]);
+                    st_agent(&A.vec[i][d], vec[i][d]);
+                    st_agent(&A.pBest[i][d], pBest[i][d]);
+                    st_agent(&A.nBest[i][d], nBest[i][d]);
+                } else {
                     A.pos[i][d] = pos[i][d];
                     A.vec[i][d] = vec[i][d];
                     A.pBest[i][d] = pBest[i][d];
                     A.nBest[i][d] = nBest[i][d];
                 }
-                A.pBestFit[i] = pBestFit[i];
             }
-            if (lane == 0) {
+            if (allShared) st_agent(&A.pBestFit[i], pBestFit[i]); else A.pBestFit[i] = pBestFit[i];
+        }
+        if (lane == 0) {
+            if (allShared) {
+                st_agent(&hd->iteration, it);
+                st_agent(&hd->gIdx, g);
+                st_agent(&hd->gBestFitness, gf);
+                st_agent(&hd->iw, iw);
+                st_agent(&hd->started, 1);
+                st_agent(&hd->arrived, 0);
+            } else {
                 hd->iteration = it;
                 hd->gIdx = g;
                 hd->gBestFitness = gf;
                 hd->iw = iw;
                 hd->started = 1;
+                hd->arrived = 0;
             }
-        } else if (lane == 0) {
-            // write back (patch.cpp:208-213) and the maxFitness gate (:156-159)
-            pais_patch_result *P = &recs[c];
-            const double th = pBest[g][0], ph = pBest[g][1], dp = pBest[g][2];
-            double nn[3];
-            spherical2normal(th, ph, nn);
-            P->fitness = gf;
-            P->normalS[0] = th;
-            P->normalS[1] = ph;
-            for (int q = 0; q < 3; ++q) P->normal[q] = nn[q];
-            P->depth = dp;
-            const DevCamera &rc = sc.cams[hd->refCam];
-            for (int q = 0; q < 3; ++q) P->center[q] = hd->ray[q] * dp + rc.C[q];
-            P->pso_runs += 1;
-            P->pso_iterations += it;
-            const int evals = N * (1 + it);
-            P->pso_evals += evals;
-            if (gf > sc.cfg.maxFitness) {
-                P->dropped = 1;
-                P->stage = PAIS_STAGE_DONE;
-            } else {
-                P->stage = PAIS_STAGE_AFTER;
-            }
-            hd->active = 0;
-            const int K = hd->K;
-            const unsigned long long perEval = (unsigned long long)(4 * K + 1 + (sc.cfg.adaptiveDistanceEnable ? 8 : 0) +
-                                                                    (sc.cfg.adaptiveGradientEnable ? 8 : 0));
-            atomicAdd(&stat[0], (unsigned long long)evals);
-            atomicAdd(&stat[1], (unsigned long long)evals * perEval);
-            atomicAdd(&stat[2], 1ULL);
         }
+        return 1;
+    } else if (lane == 0) {
+        // write back (patch.cpp:208-213) and the maxFitness gate (:156-159)
+        pais_patch_result *P = &recs[c];
+        const double th = pBest[g][0], ph = pBest[g][1], dp = pBest[g][2];
+        double nn[3];
+        spherical2normal(th, ph, nn);
+        P->fitness = gf;
+        P->normalS[0] = th;
+        P->normalS[1] = ph;
+        for (int q = 0; q < 3; ++q) P->normal[q] = nn[q];
+        P->depth = dp;
+        const DevCamera &rc = sc.cams[hd->refCam];
+        for (int q = 0; q < 3; ++q) P->center[q] = hd->ray[q] * dp + rc.C[q];
+        P->pso_runs += 1;
+        P->pso_iterations += it;
+        const int evals = N * (1 + it);
+        P->pso_evals += evals;
+        if (gf > sc.cfg.maxFitness) {
+            P->dropped = 1;
+            P->stage = PAIS_STAGE_DONE;
+        } else {
+            P->stage = PAIS_STAGE_AFTER;
+        }
+        hd->active = 0;
+        hd->arrived = 0;
+        const int K = hd->K;
+        const unsigned long long perEval = (unsigned long long)(4 * K + 1 + (sc.cfg.adaptiveDistanceEnable ? 8 : 0) +
+                                                                (sc.cfg.adaptiveGradientEnable ? 8 : 0));
+        atomicAdd(&stat[0], (unsigned long long)evals);
+        atomicAdd(&stat[1], (unsigned long long)evals * perEval);
+        atomicAdd(&stat[2], 1ULL);
+    }
+    return 0;
+}
+__device__ void pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
+                              unsigned char *smem, unsigned long long *stat, int lane, bool fitShared)
+{
+    if (fitShared) pso_step_wave_t<1>(sc, recs, c, hd, Nmax, smem, stat, lane);
+    else pso_step_wave_t<0>(sc, recs, c, hd, Nmax, smem, stat, lane);
+}
+
+// ----------------------------------------------------------- persistent PSO ---
+// Resident waves pull (candidate, particle) evaluations from a global FIFO.  The wave that delivers a
+// candidate's last fitness of an iteration runs its step and appends the next N evaluations (or ends
+// the run).  No per-iteration launches, no fill/drain per iteration; every candidate advances at its
+// own pace and the machine stays full until the round's last few candidates finish.
+// Hand-offs: slot value (task id) published only after the producer drained its state stores
+// (s_waitcnt vmcnt(0)); consumers poll with agent-scope loads and read pos[] with agent-scope loads.
+__global__ PAIS_EVAL_BOUNDS void k_pso_persist(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+                                               pais_patch_result *recs, unsigned long long *stat, int *qmem)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    EvalPatch *ep = (EvalPatch *)smem;
+    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
+    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
+    double *cbuf = Hbuf + Kmax * 9;
+    unsigned char *stepSmem = (unsigned char *)(cbuf + (size_t)Kmax * 64);
+    PsoQueue *q = (PsoQueue *)qmem;
+    int *slots = qmem + (sizeof(PsoQueue) / sizeof(int));
+    const int lane = threadIdx.x;
+    const size_t SB = pso_state_bytes(Nmax);
+    const int cap = q->cap;
+    for (;;) {
+        int h = 0;
+        if (lane == 0) h = __hip_atomic_fetch_add(&q->head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h = __shfl(h, 0, 64);
+        if (h >= cap) break; // cannot happen for a correctly sized queue; never spin on memory we do not own
+        int task = -1;
+        for (;;) {
+            if (lane == 0) {
+                task = ld_agent(&slots[h]);
+                if (task < 0 && ld_agent(&q->activeCands) <= 0) task = -2;
+            }
+            task = __shfl(task, 0, 64);
+            if (task != -1) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (task == -3) continue; // placeholder of an inactive candidate / unused particle index
+        if (task < 0) break;      // every run has ended: no task will ever be written to this slot
+        const int c = task / Nmax, i = task - c * Nmax;
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        const int N = hd->N;
+        __syncthreads();
+        fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
+        __syncthreads();
+        const double p0 = ld_agent(&A.pos[i][0]), p1 = ld_agent(&A.pos[i][1]), p2 = ld_agent(&A.pos[i][2]);
+        const double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane);
+        int last = 0;
+        if (lane == 0) {
+            st_agent(&A.fit[i], v);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int prev = __hip_atomic_fetch_add(&hd->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (prev == N - 1) ? 1 : 0;
+        }
+        last = __shfl(last, 0, 64);
+        if (!last) continue;
+        const int more = pso_step_wave_t<2>(sc, recs, c, hd, Nmax, stepSmem, stat, lane);
+        // every lane drains its own state stores before the new tasks become visible
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int moreU = __shfl(more, 0, 64); // `more` is wave-uniform by construction; keep the compiler honest
+        if (moreU) {
+            int t0 = 0;
+            if (lane == 0) t0 = __hip_atomic_fetch_add(&q->tail, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t0 = __shfl(t0, 0, 64);
+            for (int k = lane; k < N; k += 64)
+                if (t0 + k < cap) st_agent(&slots[t0 + k], c * Nmax + k);
+        } else if (lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&q->activeCands, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// seeds the queue (slots were memset to -1): task ids of every active candidate's particles, -3 for
+// slots of inactive candidates / unused particle indices (consumers skip those)
+__global__ __launch_bounds__(256) void k_pso_enqueue_initial(unsigned char *states, int n, int Nmax, int *qmem, int cap)
+{
+    PsoQueue *q = (PsoQueue *)qmem;
+    int *slots = qmem + (sizeof(PsoQueue) / sizeof(int));
+    const size_t SB = pso_state_bytes(Nmax);
+    const int total = n * Nmax;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int c = t / Nmax, i = t - c * Nmax;
+        const PsoState *hd = (const PsoState *)(states + SB * (size_t)c);
+        const bool on = hd->active && i < hd->N;
+        slots[t] = on ? t : -3;
+        if (on && i == 0) atomicAdd(&q->activeCands, 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        q->head = 0;
+        q->tail = total;
+        q->cap = cap;
+    }
+}
+
+// stand-alone step kernel (PAIS_PSO_MODE=split): one wave per candidate
+__global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result *recs, unsigned char *states, int n,
+                                                 int Nmax, unsigned long long *stat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const size_t SB = pso_state_bytes(Nmax);
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        if (!hd->active) continue;
+        pso_step_wave(sc, recs, c, hd, Nmax, smem, stat, lane, false);
     }
 }
 
@@ -1391,9 +1575,10 @@ hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int
     hipLaunchKernelGGL(k_pso_init, dim3(grid), dim3(64), 0, stream, sc, recs, n, states, Nmax);
     return hipGetLastError();
 }
-hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, hipStream_t stream)
+hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
+                          unsigned long long *stat, int fuseStep, hipStream_t stream)
 {
-    size_t lds = fitness_lds_bytes(Kmax);
+    size_t lds = fitness_lds_bytes(Kmax) + sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
     static bool attrSet = false;
     if (lds > 64 * 1024 && !attrSet) {
         hipError_t e = hipFuncSetAttribute((const void *)k_pso_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1402,7 +1587,40 @@ hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int 
     }
     long total = (long)n * Nmax;
     int grid = (int)(total < 262144 ? total : 262144);
-    hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax);
+    hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, fuseStep);
+    return hipGetLastError();
+}
+size_t pso_queue_ints(int n, int Nmax, int maxIt) { return sizeof(PsoQueue) / sizeof(int) + (size_t)n * Nmax * (size_t)(maxIt + 2); }
+hipError_t pso_persist(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, int maxIt, pais_patch_result *recs,
+                       unsigned long long *stat, int *qmem, int numCUs, hipStream_t stream)
+{
+    const size_t ints = pso_queue_ints(n, Nmax, maxIt);
+    const int cap = (int)(ints - sizeof(PsoQueue) / sizeof(int));
+    hipError_t e = hipMemsetAsync(qmem, 0xFF, ints * sizeof(int), stream); // slots = -1
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(qmem, 0, sizeof(PsoQueue), stream);
+    if (e != hipSuccess) return e;
+    const int total = n * Nmax;
+    int g0 = (total + 255) / 256;
+    hipLaunchKernelGGL(k_pso_enqueue_initial, dim3(g0 < 1024 ? g0 : 1024), dim3(256), 0, stream, states, n, Nmax, qmem, cap);
+    size_t lds = fitness_lds_bytes(Kmax) + sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
+    static int blocksPerCU = 0;
+    static size_t ldsFor = 0;
+    if (blocksPerCU == 0 || ldsFor != lds) {
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute((const void *)k_pso_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pso_persist, 64, lds);
+        if (e != hipSuccess || nb <= 0) nb = 8;
+        blocksPerCU = nb;
+        ldsFor = lds;
+    }
+    long resident = (long)numCUs * blocksPerCU;
+    int grid = (int)(total < resident ? total : resident);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_pso_persist, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, qmem);
     return hipGetLastError();
 }
 hipError_t pso_split_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,

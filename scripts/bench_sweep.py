@@ -5,7 +5,7 @@ pts = [tuple(map(int, a.split(":"))) for a in sys.argv[1:]] or [(512, 0)]
 for B, W in pts:
     env = dict(os.environ)
     if W: env["PAIS_PSO_WAVES"] = str(W); env["PAIS_PSO_MODE"] = "fused"
-    else: env.pop("PAIS_PSO_WAVES", None); env["PAIS_PSO_MODE"] = "split"
+    else: env.pop("PAIS_PSO_WAVES", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                         "--parents-per-round", str(B)], env=env, capture_output=True, text=True)
     try:
