@@ -43,3 +43,10 @@ def pawn_small():
 def pawn_full():
     from pais_mvs_amd import synth
     return synth.pawn_scene(n_seeds=60)
+
+
+@pytest.fixture(scope="session")
+def ring_small():
+    """24 cameras on a ring (15 degrees apart), 480x360: K = 7..11 visible cameras per patch."""
+    from pais_mvs_amd import synth
+    return synth.ring_scene(n_cams=24, width=480, height=360, focal=450.0, radius=3.0, n_seeds=30)

@@ -261,3 +261,88 @@ def test_full_size_properties(pawn_full):
         m.close()
     # bit-reproducible run to run
     assert clouds[0].shape == clouds[1].shape and np.array_equal(clouds[0], clouds[1])
+
+
+def test_ring_all_weights_many_cameras(ring_small):
+    """Config-2-like rig (ring of cameras, all three adaptive weights on, K = 7..11): cost, seed refinement
+    and expansion rounds against the oracle, bit for bit."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    cfg = readme_config(adaptiveGradientEnable=True, particleNum=8, maxIteration=12)
+    S = common.oracle_scene(cfg, ring_small)
+    S.set_kernel_arithmetic(True)
+    L = po.lib()
+    # cost
+    ctx = _ctx(cfg, ring_small)
+    rng = np.random.default_rng(3)
+    states, pats, idx, parts = _states_and_particles(S, ring_small, rng, n_per=12)
+    assert max(p.numCam for p in pats) >= 7
+    got = ctx.fitness_batch(states, idx, parts)
+    nfin = 0
+    for e, (si, pos) in enumerate(zip(idx, parts)):
+        want = S.fitness(pats[si], pos)
+        assert common.same_value(got[e], want, RTOL_EXACT), (e, got[e], want)
+        nfin += int(want != DBL_MAX)
+    assert nfin > 30
+    ctx.close()
+    # reconstruction rounds
+    S.set_omp(True)
+    mo = L.po_mvs_create(S.ptr)
+    for X, vis in ring_small.seeds:
+        L.po_mvs_add_seed(mo, po.darr(X), len(vis), po.iarr(vis))
+    L.po_mvs_refine_seed_patches(mo)
+    L.po_mvs_expansion_patches(mo, 8, 6, 1)
+    want = []
+    for i in range(L.po_mvs_num_slots(mo)):
+        pp = L.po_mvs_get_patch(mo, i)
+        if pp:
+            p = pp.contents
+            want.append((list(p.center[:]), list(p.normal[:]), p.cams(), p.fitness, p.correlation, p.priority, p.LOD))
+    L.po_mvs_destroy(mo)
+    m = MVS(cfg, ring_small.cameras, device=0, seed=42)
+    for X, vis in ring_small.seeds:
+        m.add_seed(X, vis)
+    m.refineSeedPatches()
+    m.expansionPatches(8, 6)
+    got = [(list(p.center[:]), list(p.normal[:]), p.cams(), p.fitness, p.correlation, p.priority, p.lod) for p in m.patches()]
+    assert len(got) == len(want) and len(got) > len(ring_small.seeds) // 2, (len(got), len(want))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (i, a, b)
+    m.close()
+
+
+def test_distributed_path_single_rank_on_gpu(pawn_small, tmp_path):
+    """The multi-GPU code path (device-resident shard refinement + all_gather_into_tensor over RCCL) with a
+    world of one rank must give the cloud of the direct path."""
+    import subprocess, sys, os, textwrap
+    script = tmp_path / "dist1.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, hashlib
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from pais_mvs_amd import synth, distributed as D
+        from pais_mvs_amd.config import readme_config
+        from pais_mvs_amd.mvs import MVS
+        scene = synth.pawn_scene(width=320, height=240, n_seeds=24)
+        cfg = readme_config()
+        clouds = []
+        for mode in ("direct", "dist"):
+            m = MVS(cfg, scene.cameras, device=0, seed=42)
+            for X, vis in scene.seeds: m.add_seed(X, vis)
+            if mode == "direct":
+                m.refineSeedPatches(); m.expansionPatches(16, 8)
+            else:
+                D.reconstruct(m, 16, D.torch_gpu_exchange(m, 0, 1), max_rounds=8)
+            clouds.append(hashlib.sha1(m.cloud().tobytes()).hexdigest() + " %%d" %% m.num_patches())
+            m.close()
+        print("CLOUDS", clouds[0], "|", clouds[1])
+        assert clouds[0] == clouds[1]
+        dist.destroy_process_group()
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "CLOUDS" in r.stdout
