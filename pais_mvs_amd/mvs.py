@@ -163,3 +163,41 @@ class MVS:
         """(N, 6) array of patch centres and normals in id order."""
         ps = self.patches()
         return np.array([[*p.center[:], *p.normal[:]] for p in ps], dtype=np.float64).reshape(-1, 6)
+
+    # ---- writers (MVS::writeMVS / writePLY / writePSR, mvs.cpp:174-184 -> io/filewriter.cpp)
+    def _io_cameras(self):
+        from . import io
+        return [io.io_camera(c.name or ("cam%04d" % i), c.focal, c.principle_point, c.quaternion, c.center, c.radial_distortion)
+                for i, c in enumerate(self.cameras)]
+
+    def colors_bgr(self) -> np.ndarray:
+        """Patch colour as Patch::setImagePoint picks it (patch.cpp:649-652): the reference camera's pixel at
+        the rounded projection of the centre (gray pipelines replicate the gray value)."""
+        out = []
+        for p in self.patches():
+            cam = self.cameras[p.ref_cam]
+            k = p.cams().index(p.ref_cam) if p.ref_cam in p.cams() else 0
+            x, y = int(np.rint(p.imgPoint[k][0])), int(np.rint(p.imgPoint[k][1]))
+            x = min(max(x, 0), cam.width - 1); y = min(max(y, 0), cam.height - 1)
+            if cam.rgb is not None:
+                out.append(cam.rgb[y, x, ::-1] if cam.rgb.shape[-1] == 3 else [cam.rgb[y, x]] * 3)
+            else:
+                out.append([cam.image[y, x]] * 3)
+        return np.asarray(out, dtype=np.uint8).reshape(-1, 3)
+
+    def writeMVS(self, path: str):
+        from . import io
+        cfg = self.cfg
+        cfg.neighborRadius = self.neighbor_radius()
+        pats = [io.io_patch(p.center[:], p.normalS[:], p.cams(), p.fitness, p.correlation) for p in self.patches()]
+        io.write_mvs(path, cfg, self._io_cameras(), pats)
+
+    def writePLY(self, path: str):
+        from . import io
+        c = self.cloud()
+        io.write_ply(path, c[:, :3], c[:, 3:], self.colors_bgr())
+
+    def writePSR(self, path: str):
+        from . import io
+        c = self.cloud()
+        io.write_psr(path, c[:, :3], c[:, 3:])
