@@ -1133,7 +1133,9 @@ __device__ int pso_step_wave_t(const DevScene &sc, pais_patch_result *recs, int 
                                unsigned char *smem, unsigned long long *stat, int lane)
 {
     constexpr bool fitShared = MODE >= 1;
-    constexpr bool allShared = MODE == 2;
+    // MODE 2: the caller brackets this function with agent-scope acquire / release fences, so the swarm state
+    // handed from the previous stepper can be read and written with plain (wide, cached) accesses
+    constexpr bool allShared = false;
     double(*pos)[3] = (double(*)[3])smem;
     double(*vec)[3] = pos + Nmax;
     double(*pBest)[3] = vec + Nmax;
@@ -1297,6 +1299,12 @@ __device__ void pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c
     else pso_step_wave_t<0>(sc, recs, c, hd, Nmax, smem, stat, lane);
 }
 
+__device__ __forceinline__ int pso_step_wave_noinline(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd,
+                                                               int Nmax, unsigned char *smem, unsigned long long *stat, int lane)
+{
+    return pso_step_wave_t<2>(sc, recs, c, hd, Nmax, smem, stat, lane);
+}
+
 // ----------------------------------------------------------- persistent PSO ---
 // Resident waves pull (candidate, particle) evaluations from a global FIFO.  The wave that delivers a
 // candidate's last fitness of an iteration runs its step and appends the next N evaluations (or ends
@@ -1331,7 +1339,8 @@ __global__ PAIS_EVAL_BOUNDS void k_pso_persist(DevScene sc, unsigned char *state
             }
             task = __shfl(task, 0, 64);
             if (task != -1) break;
-            __builtin_amdgcn_s_sleep(8);
+            // back off: thousands of pollers would eat the memory system (MI355X_MICROARCH polling-cost)
+            __builtin_amdgcn_s_sleep(100);
         }
         if (task == -3) continue; // placeholder of an inactive candidate / unused particle index
         if (task < 0) break;      // every run has ended: no task will ever be written to this slot
@@ -1353,8 +1362,11 @@ __global__ PAIS_EVAL_BOUNDS void k_pso_persist(DevScene sc, unsigned char *state
         }
         last = __shfl(last, 0, 64);
         if (!last) continue;
-        const int more = pso_step_wave_t<2>(sc, recs, c, hd, Nmax, stepSmem, stat, lane);
-        // every lane drains its own state stores before the new tasks become visible
+        // acquire: drop this CU's L1 (and stale remote L2 lines) before reading what the previous stepper wrote
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int more = pso_step_wave_noinline(sc, recs, c, hd, Nmax, stepSmem, stat, lane);
+        // release: write the new swarm state back before the next iteration's tasks become visible
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int moreU = __shfl(more, 0, 64); // `more` is wave-uniform by construction; keep the compiler honest

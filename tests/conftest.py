@@ -50,3 +50,10 @@ def ring_small():
     """24 cameras on a ring (15 degrees apart), 480x360: K = 7..11 visible cameras per patch."""
     from pais_mvs_amd import synth
     return synth.ring_scene(n_cams=24, width=480, height=360, focal=450.0, radius=3.0, n_seeds=30)
+
+
+@pytest.fixture(scope="session")
+def dome_small():
+    """40 cameras on a Fibonacci hemisphere, 400x300: config-4-like rig with K up to ~20 visible cameras."""
+    from pais_mvs_amd import synth
+    return synth.dome_scene(n_cams=40, width=400, height=300, focal=420.0, radius=4.0, n_seeds=24)

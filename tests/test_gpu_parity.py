@@ -346,3 +346,97 @@ def test_distributed_path_single_rank_on_gpu(pawn_small, tmp_path):
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "CLOUDS" in r.stdout
+
+
+def test_dome_radius25_many_cameras(dome_small):
+    """Config-4-like parameters: patchRadius 25 (S^2 = 2601), reduceNormalRange 4, all weights, many visible
+    cameras per patch (large per-wave LDS carve).  Cost + seeds + a few expansion rounds, bit for bit."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    cfg = readme_config(patchRadius=25, distWeighting=25 / 3.0, reduceNormalRange=4.0, adaptiveGradientEnable=True,
+                        particleNum=6, maxIteration=8, visibleCorrelation=0.6)
+    S = common.oracle_scene(cfg, dome_small)
+    S.set_kernel_arithmetic(True)
+    S.set_omp(True)
+    L = po.lib()
+    ctx = _ctx(cfg, dome_small)
+    rng = np.random.default_rng(9)
+    states, pats, idx, parts = _states_and_particles(S, dome_small, rng, n_per=6)
+    kmax = max(p.numCam for p in pats)
+    assert kmax >= 12, kmax
+    got = ctx.fitness_batch(states, idx, parts)
+    nfin = 0
+    for e, (si, pos) in enumerate(zip(idx, parts)):
+        want = S.fitness(pats[si], pos)
+        assert common.same_value(got[e], want, RTOL_EXACT), (e, got[e], want)
+        nfin += int(want != DBL_MAX)
+    assert nfin > 10
+    ctx.close()
+    mo = L.po_mvs_create(S.ptr)
+    for X, vis in dome_small.seeds:
+        L.po_mvs_add_seed(mo, po.darr(X), len(vis), po.iarr(vis))
+    L.po_mvs_refine_seed_patches(mo)
+    L.po_mvs_expansion_patches(mo, 8, 3, 1)
+    want = []
+    for i in range(L.po_mvs_num_slots(mo)):
+        pp = L.po_mvs_get_patch(mo, i)
+        if pp:
+            p = pp.contents
+            want.append((list(p.center[:]), list(p.normal[:]), p.cams(), p.fitness, p.correlation, p.priority, p.LOD))
+    L.po_mvs_destroy(mo)
+    m = MVS(cfg, dome_small.cameras, device=0, seed=42)
+    for X, vis in dome_small.seeds:
+        m.add_seed(X, vis)
+    m.refineSeedPatches()
+    m.expansionPatches(8, 3)
+    got = [(list(p.center[:]), list(p.normal[:]), p.cams(), p.fitness, p.correlation, p.priority, p.lod) for p in m.patches()]
+    assert len(got) == len(want) and len(got) >= 8, (len(got), len(want))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (i, a, b)
+    m.close()
+
+
+def test_edge_cases(pawn_small):
+    """Empty batch, too few cameras (patch.cpp:118-123), a seed whose window leaves every image (whole-call
+    DBL_MAX, drop by maxFitness), bad arguments."""
+    from oracle import po
+    from pais_mvs_amd import _lib
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import make_candidate
+    cfg = readme_config()
+    S = common.oracle_scene(cfg, pawn_small)
+    S.set_kernel_arithmetic(True)
+    L = po.lib()
+    ctx = _ctx(cfg, pawn_small)
+    assert len(ctx.refine_batch([])) == 0
+    assert len(ctx.fitness_batch([], [], np.zeros((0, 3)))) == 0
+    X, vis = pawn_small.seeds[0]
+    cases = []
+    p = S.seed_patch(X, vis[:2], key=7)                       # 2 < minCamNum cameras
+    cases.append((p, make_candidate(p.center[:], [0, 0, 1], vis[:2], 7, 0, normalS=[0.0, 0.0])))
+    far = np.array(X) + np.array([5.0, 5.0, 5.0])             # projects outside every image
+    p = S.seed_patch(far, vis, key=8)
+    cases.append((p, make_candidate(p.center[:], p.normal[:], p.cams(), 8, 0, normalS=p.normalS[:])))
+    p = S.expand_patch(X, [0.0, 0.0, 1.0], vis, key=9)       # normal facing away from most cameras
+    cases.append((p, make_candidate(p.center[:], p.normal[:], p.cams(), 9, 1, normalS=p.normalS[:])))
+    res = ctx.refine_batch([c for _, c in cases])
+    for i, (p, _) in enumerate(cases):
+        if p.type == 0:
+            L.po_refine_seed(S.ptr, C.byref(p))
+        else:
+            if p.numCam < cfg.minCamNum:
+                p.drop = 1
+            L.po_refine(S.ptr, C.byref(p)); L.po_remove_invisible_camera(S.ptr, C.byref(p))
+        assert bool(res[i].dropped) == bool(p.drop), (i, res[i].dropped, p.drop)
+        if not p.drop:
+            assert list(res[i].center[:]) == list(p.center[:])
+    assert res[0].dropped and res[1].dropped
+    # argument validation: errors, not crashes
+    bad = make_candidate(X, [0, 0, 1], [0, 1, 99], 1, 1)
+    with pytest.raises(RuntimeError):
+        ctx.refine_batch([bad])
+    st = _lib.PatchState(); st.ref_cam = 0; st.lod = 0; st.num_cam = 0
+    with pytest.raises(RuntimeError):
+        ctx.fitness_batch([st], [0], [[0.0, 0.0, 1.0]])
+    ctx.close()
