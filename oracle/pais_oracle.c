@@ -607,25 +607,46 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
          * Differs from the literal branch in the last bits only. */
         const double invK = 1.0 / (double)camNum, invDiffW = 1.0 / s->cfg.diffWeighting;
         double sum = 0;
-        for (int i = 0; i < camNum; ++i) {
-            const po_camera *cam = &s->cams[patch->camIdx[i]];
-            const uint8_t *img = cam->img[LOD];
-            const int cols = cam->width[LOD], rows = cam->height[LOD];
-            const double *Hi = f->H + 9 * i;
-            const double ww = fma(Hi[7], y, fma(Hi[6], x, Hi[8]));
-            const double nx = fma(Hi[1], y, fma(Hi[0], x, Hi[2]));
-            const double ny = fma(Hi[4], y, fma(Hi[3], x, Hi[5]));
-            const double rw = 1.0 / ww;
-            const double jx = nx * rw, jy = ny * rw;
-            if (!((jx >= 2 && jx < cols - 3 && jy >= 2 && jy < rows - 3) && (ww != 0))) return -1;
-            const int qx = (int)jx, qy = (int)jy;
-            const double bx = jx - (double)qx, by = jy - (double)qy;
-            const double ax = 1.0 - bx, ay = 1.0 - by;
-            const uint8_t *r0 = img + (size_t)qy * cols + qx, *r1 = r0 + cols;
-            const double t0 = fma((double)r0[1], bx, (double)r0[0] * ax);
-            const double t1 = fma((double)r1[1], bx, (double)r1[0] * ax);
-            c[i] = fma(t1, by, t0 * ay);
-            sum += c[i];
+        for (int i0 = 0; i0 < camNum; i0 += 2) {
+            /* cameras are handled in pairs with ONE reciprocal per pair (1/w0 = w1/(w0 w1), 1/w1 = w0/(w0 w1));
+             * an odd camera count leaves a single camera with its own reciprocal */
+            const int g = (i0 + 1 < camNum) ? 2 : 1;
+            double ww[2], nx[2], ny[2], rw[2];
+            for (int u = 0; u < g; ++u) {
+                const double *Hi = f->H + 9 * (i0 + u);
+                ww[u] = fma(Hi[7], y, fma(Hi[6], x, Hi[8]));
+                nx[u] = fma(Hi[1], y, fma(Hi[0], x, Hi[2]));
+                ny[u] = fma(Hi[4], y, fma(Hi[3], x, Hi[5]));
+            }
+            if (g == 2) {
+                const double r = 1.0 / (ww[0] * ww[1]);
+                rw[0] = r * ww[1];
+                rw[1] = r * ww[0];
+            } else {
+                rw[0] = 1.0 / ww[0];
+            }
+            /* the kernel flags every bad tap of the pair before giving up: same result, DBL_MAX */
+            for (int u = 0; u < g; ++u) {
+                const po_camera *cam = &s->cams[patch->camIdx[i0 + u]];
+                const int cols = cam->width[LOD], rows = cam->height[LOD];
+                const double jx = nx[u] * rw[u], jy = ny[u] * rw[u];
+                if (!(jx >= 2 && jx < cols - 3 && jy >= 2 && jy < rows - 3)) return -1;
+            }
+            for (int u = 0; u < g; ++u) {
+                const int i = i0 + u;
+                const po_camera *cam = &s->cams[patch->camIdx[i]];
+                const uint8_t *img = cam->img[LOD];
+                const int cols = cam->width[LOD];
+                const double jx = nx[u] * rw[u], jy = ny[u] * rw[u];
+                const int qx = (int)jx, qy = (int)jy;
+                const double bx = jx - (double)qx, by = jy - (double)qy;
+                const double ax = 1.0 - bx, ay = 1.0 - by;
+                const uint8_t *r0 = img + (size_t)qy * cols + qx, *r1 = r0 + cols;
+                const double t0 = fma((double)r0[1], bx, (double)r0[0] * ax);
+                const double t1 = fma((double)r1[1], bx, (double)r1[0] * ax);
+                c[i] = fma(t1, by, t0 * ay);
+                sum += c[i];
+            }
         }
         mean = sum * invK;
         for (int i = 0; i < camNum; i++) avgSad += fabs(c[i] - mean);

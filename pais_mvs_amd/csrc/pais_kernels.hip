@@ -22,12 +22,10 @@
 
 using namespace pais;
 
-// Tuning macros of the cost evaluation (scripts/build_variants.py measures them):
-//   PAIS_TAP_GROUP     cameras whose taps are issued together (4, 2 or 1)
+// Tuning macro of the cost evaluation:
 //   PAIS_EVAL_MIN_WAVES  min waves per SIMD requested from the register allocator (0 = unconstrained)
-#ifndef PAIS_TAP_GROUP
-#define PAIS_TAP_GROUP 2 /* measured best: 104 VGPRs -> 4 waves/SIMD (scripts/variant_sweep.sh) */
-#endif
+// Taps are issued per camera PAIR (measured best of groups of 1/2/4: 104 VGPRs -> 4 waves/SIMD); the
+// pairing is part of the kernel arithmetic (one reciprocal per pair), mirrored by the oracle.
 #ifndef PAIS_EVAL_MIN_WAVES
 #define PAIS_EVAL_MIN_WAVES 0
 #endif
@@ -132,20 +130,32 @@ template <int G>
 __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
                                           int c0, double x, double y, bool act, bool &bad, double &sum)
 {
-    double bx[G], by[G];
+    static_assert(G == 1 || G == 2, "kernel arithmetic is defined for camera pairs + one leftover");
+    double bx[G], by[G], nx[G], ny[G], w[G], rw[G];
     const uint8_t *base[G];
     uint32_t off[G], cwv[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
+        const double *H = Hbuf + 9 * (c0 + u);
+        w[u] = fma(H[7], y, fma(H[6], x, H[8]));
+        nx[u] = fma(H[1], y, fma(H[0], x, H[2]));
+        ny[u] = fma(H[4], y, fma(H[3], x, H[5]));
+    }
+    if (G == 2) {
+        // one reciprocal for the pair (Montgomery batch inversion): 1/w0 = w1 * 1/(w0 w1), 1/w1 = w0 * 1/(w0 w1).
+        // A zero / non-finite w poisons both, which is right: any overflowing tap makes the whole call DBL_MAX.
+        const double r = 1.0 / (w[0] * w[G - 1]);
+        rw[0] = r * w[G - 1];
+        rw[G - 1] = r * w[0];
+    } else {
+        rw[0] = 1.0 / w[0];
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
         const int c = c0 + u;
-        const double *H = Hbuf + 9 * c;
-        const double w = fma(H[7], y, fma(H[6], x, H[8]));
-        const double nx = fma(H[1], y, fma(H[0], x, H[2]));
-        const double ny = fma(H[4], y, fma(H[3], x, H[5]));
-        const double rw = 1.0 / w;
-        const double ix = nx * rw, iy = ny * rw;
+        const double ix = nx[u] * rw[u], iy = ny[u] * rw[u];
         // patch.cpp:999 -- evaluated without short-circuit branches; NaN fails every comparison
-        // (w == 0 needs no test of its own: rw = inf makes ix, iy +-inf or NaN, which fail the range test)
+        // (w == 0 needs no test of its own: the reciprocal is inf / NaN, so ix, iy fail the range test)
         const bool ok = (ix >= 2.0) & (ix < cams[c].xmax) & (iy >= 2.0) & (iy < cams[c].ymax);
         bad = bad | (act & !ok);
         const int px = ok ? (int)ix : 0, py = ok ? (int)iy : 0;
@@ -257,13 +267,8 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
         bool bad = false;
         double sum = 0;
         int c0 = 0;
-#if PAIS_TAP_GROUP >= 4
-        for (; c0 + 4 <= K; c0 += 4) tap_group<4>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
-#endif
-#if PAIS_TAP_GROUP >= 2
-        for (; c0 + 2 <= K; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
-#endif
-        for (; c0 < K; ++c0) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);
+        for (; c0 + 2 <= K; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum); // camera pairs
+        if (c0 < K) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);                  // odd leftover
         if (__any(bad)) return DBL_MAX; // :1001 -- whole call
         const double mean = sum * invK;
         double sad = 0;
