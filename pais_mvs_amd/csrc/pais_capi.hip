@@ -60,9 +60,11 @@ struct pais_ctx {
     int *h_counters = nullptr;          // pinned
     unsigned char *d_psoStates = nullptr; // split pipeline: one PsoState block per candidate
     size_t psoStateBytes = 0;
-    int psoMode = 1;                    // 1: eval + step kernels per iteration, pipelined over several streams (default),
+    int psoMode = 4;                    // 4: one k_pso_iter launch per iteration, pipelined over several streams (default),
+                                        // 1: eval + step kernels per iteration (PAIS_PSO_MODE=split),
                                         // 2: eval launches with last-arriver step, 3: persistent task-queue kernel,
                                         // 0: fused one-workgroup-per-candidate k_pso  (measured alternatives)
+    int psoMinPer = 64;
     int psoStreams = 2;                 // slices of a batch whose eval/step sequences overlap on separate HIP streams
     std::vector<hipStream_t> sub;       // sub-streams
     std::vector<hipEvent_t> subDone;
@@ -233,7 +235,8 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
     HIPCHK(hipHostMalloc((void **)&ctx->h_counters, sizeof(int) * 4, hipHostMallocDefault));
     if (const char *e = getenv("PAIS_PSO_MODE"))
-        ctx->psoMode = (strcmp(e, "fused") == 0) ? 0 : (strcmp(e, "laststep") == 0) ? 2 : (strcmp(e, "persist") == 0) ? 3 : 1;
+        ctx->psoMode = (strcmp(e, "fused") == 0) ? 0 : (strcmp(e, "laststep") == 0) ? 2 : (strcmp(e, "persist") == 0) ? 3 : (strcmp(e, "split") == 0) ? 1 : 4;
+    if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     HIPCHK(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming));
     for (int i = 0; i < ctx->psoStreams; ++i) {
@@ -470,10 +473,13 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 // waves, latency bound) overlaps the evaluations of the others and every evaluation
                 // launch fits into one residency pass of the GPU
                 int S = ctx->psoStreams;
-                const int minPer = 64; // slices smaller than this only add launch overhead
+                const int minPer = ctx->psoMinPer; // slices smaller than this only add launch overhead
                 if (n < S * minPer) S = (n + minPer - 1) / minPer;
                 if (S < 1) S = 1;
                 const size_t SB = pais_launch::pso_split_state_bytes(Nmax);
+                // psoMode 4: one k_pso_iter launch per iteration (step folded into the evaluation waves);
+                // needs the swarm of a candidate in the lanes of one wave
+                const bool useIter = ctx->psoMode == 4 && Nmax <= 64;
                 HIPCHK(hipEventRecord(ctx->forkEv, ctx->stream));
                 for (int sI = 0; sI < S; ++sI) {
                     const int lo = (int)((long)n * sI / S), hi = (int)((long)n * (sI + 1) / S);
@@ -488,14 +494,19 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                             if (get_event_pair(ctx, ee)) return -2;
                             HIPCHK(hipEventRecord(ee.a, st));
                         }
-                        HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0, st));
+                        if (useIter)
+                            HIPCHK(pais_launch::pso_iter(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, it, 0, st));
+                        else
+                            HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0, st));
                         if (timeIt) {
                             HIPCHK(hipEventRecord(ee.b, st));
                             ctx->evEval.push_back(ee);
                         }
                         ctx->evalLaunches++;
-                        HIPCHK(pais_launch::pso_split_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
+                        if (!useIter) HIPCHK(pais_launch::pso_split_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
                     }
+                    // the launch after the last possible iteration only ends the runs still active
+                    if (useIter) HIPCHK(pais_launch::pso_iter(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, maxIt + 1, 1, st));
                     if (S > 1) {
                         HIPCHK(hipEventRecord(ctx->subDone[sI], st));
                         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI], 0));

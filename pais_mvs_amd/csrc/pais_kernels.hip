@@ -34,6 +34,8 @@ using namespace pais;
 #else
 #define PAIS_EVAL_BOUNDS __launch_bounds__(64)
 #endif
+// k_pso_iter / k_fitness: 4 waves per SIMD (<= 128 VGPRs) without spilling
+#define PAIS_ITER_BOUNDS __launch_bounds__(64, 4)
 
 // --------------------------------------------------------------- helpers ---
 __device__ __forceinline__ void wave_sync()
@@ -65,6 +67,8 @@ struct EvalCam {
     int w, h;
     int cam;
     int pad;
+    int qxmax, qymax;  // w - 4, h - 4: largest truncated tap coordinate that passes patch.cpp:999
+    int pad2[2];
 };
 struct EvalPatch {
     double ray[3], Cref[3], optNref[3], Rref[9], Tref[3], fref[2], ppref[2], KRref[9], KTref[3];
@@ -87,6 +91,8 @@ __device__ void fill_eval_patch(const DevScene &sc, EvalPatch *ep, EvalCam *cams
         cams[c].h = dc.h[LOD];
         cams[c].xmax = (double)(dc.w[LOD] - 3);
         cams[c].ymax = (double)(dc.h[LOD] - 3);
+        cams[c].qxmax = dc.w[LOD] - 4;
+        cams[c].qymax = dc.h[LOD] - 4;
         cams[c].cam = camIdx[c];
     }
     if (tid == 0) {
@@ -115,6 +121,14 @@ __device__ void fill_eval_patch(const DevScene &sc, EvalPatch *ep, EvalCam *cams
     }
 }
 
+// median of three == clamp(v, lo, hi) for lo <= hi, one instruction
+__device__ __forceinline__ int clamp_i32(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+
 // two adjacent bytes with one (unaligned) 16-bit global load
 __device__ __forceinline__ uint32_t load_pair(const uint8_t *p)
 {
@@ -128,7 +142,7 @@ __device__ __forceinline__ uint32_t load_pair(const uint8_t *p)
 // are independent so they overlap.
 template <int G>
 __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
-                                          int c0, double x, double y, bool act, bool &bad, double &sum)
+                                          int c0, double x, double y, uint32_t &badBits, double &sum)
 {
     static_assert(G == 1 || G == 2, "kernel arithmetic is defined for camera pairs + one leftover");
     double bx[G], by[G], nx[G], ny[G], w[G], rw[G];
@@ -154,13 +168,15 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
     for (int u = 0; u < G; ++u) {
         const int c = c0 + u;
         const double ix = nx[u] * rw[u], iy = ny[u] * rw[u];
-        // patch.cpp:999 -- evaluated without short-circuit branches; NaN fails every comparison
-        // (w == 0 needs no test of its own: the reciprocal is inf / NaN, so ix, iy fail the range test)
-        const bool ok = (ix >= 2.0) & (ix < cams[c].xmax) & (iy >= 2.0) & (iy < cams[c].ymax);
-        bad = bad | (act & !ok);
-        const int px = ok ? (int)ix : 0, py = ok ? (int)iy : 0;
-        bx[u] = ix - (double)px;
-        by[u] = iy - (double)py;
+        // patch.cpp:999 in the integer domain, without branches: for the truncated q = (int)ix,
+        // 2 <= ix < w-3  <=>  2 <= q <= w-4 (NaN converts to 0, +-inf / overflow saturate: all rejected;
+        // w == 0 needs no test of its own: the reciprocal is inf / NaN).  The clamped q addresses the tap,
+        // q != clamp(q) flags the overflow.  frac(ix) == ix - (double)q exactly for an accepted ix.
+        const int qx = (int)ix, qy = (int)iy;
+        const int px = clamp_i32(qx, 2, cams[c].qxmax), py = clamp_i32(qy, 2, cams[c].qymax);
+        badBits |= (uint32_t)((px ^ qx) | (py ^ qy));
+        bx[u] = __builtin_amdgcn_fract(ix);
+        by[u] = __builtin_amdgcn_fract(iy);
         const uint32_t cw = (uint32_t)cams[c].w;
         base[u] = sc.imgBlob + cams[c].imgOff; // wave-uniform
         off[u] = (uint32_t)py * cw + (uint32_t)px;
@@ -264,12 +280,12 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
         const double x = a0 + (double)xi, y = b0 + (double)yi; // == the reference's ++x / ++y walk
         const int rx = cv_round(x), ry = cv_round(y);
         const bool act = valid && (refImg[ry * refW + rx] != 0); // :986
-        bool bad = false;
+        uint32_t badBits = 0; // != 0: some tap of this pixel left [2, w-3) x [2, h-3)
         double sum = 0;
         int c0 = 0;
-        for (; c0 + 2 <= K; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum); // camera pairs
-        if (c0 < K) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, act, bad, sum);                  // odd leftover
-        if (__any(bad)) return DBL_MAX; // :1001 -- whole call
+        for (; c0 + 2 <= K; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // camera pairs
+        if (c0 < K) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);                  // odd leftover
+        if (__any(act && badBits != 0)) return DBL_MAX; // :1001 -- whole call
         const double mean = sum * invK;
         double sad = 0;
         for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
@@ -288,7 +304,7 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
 
 // ------------------------------------------------------------- k_fitness ---
 // one wave (= one 64-thread workgroup) per evaluation
-__global__ PAIS_EVAL_BOUNDS void k_fitness(DevScene sc, const pais_patch_state *states, const int32_t *stateIndex,
+__global__ PAIS_ITER_BOUNDS void k_fitness(DevScene sc, const pais_patch_state *states, const int32_t *stateIndex,
                                                 const double *particles, double *out, int nEvals, int Kmax)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -959,19 +975,25 @@ struct PsoState { // one per candidate, in global memory; the per-particle array
     double ray[3];
     int refCam, LOD, K, pad;
     int camIdx[PAIS_MAX_VIS];
+    // k_pso_iter: the loop-carried scalars of PsoSolver::run(), double buffered by launch parity
+    struct IterDyn {
+        double iw, gBestFitness;
+        int gIdx, iteration, started, pad;
+    } dyn[2];
 };
 __host__ __device__ inline size_t pso_state_bytes(int Nmax)
 {
-    return ((sizeof(PsoState) + 15) & ~(size_t)15) + sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
+    // header + two swarm buffers (k_pso_iter reads one and writes the other; the other pipelines use buffer 0)
+    return ((sizeof(PsoState) + 15) & ~(size_t)15) + 2 * sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
 }
 struct PsoArrays {
     double (*pos)[3], (*vec)[3], (*pBest)[3], (*nBest)[3];
     double *fit, *pBestFit;
 };
-__device__ __forceinline__ PsoArrays pso_arrays(unsigned char *base, int Nmax)
+__device__ __forceinline__ PsoArrays pso_arrays(unsigned char *base, int Nmax, int buf = 0)
 {
     PsoArrays a;
-    unsigned char *q = base + ((sizeof(PsoState) + 15) & ~(size_t)15);
+    unsigned char *q = base + ((sizeof(PsoState) + 15) & ~(size_t)15) + (size_t)buf * sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
     a.pos = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
     a.vec = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
     a.pBest = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
@@ -1031,6 +1053,11 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
             hd->active = 1;
             hd->started = 0;
             hd->arrived = 0;
+            hd->dyn[0].iw = 0.8;
+            hd->dyn[0].gBestFitness = DBL_MAX;
+            hd->dyn[0].gIdx = 0;
+            hd->dyn[0].iteration = 0;
+            hd->dyn[0].started = 0;
             hd->refCam = P->ref_cam;
             hd->LOD = P->lod;
             hd->K = P->num_cam;
@@ -1117,6 +1144,257 @@ template <typename T> __device__ __forceinline__ T ld_agent(const T *p)
 template <typename T> __device__ __forceinline__ void st_agent(T *p, T v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------- k_pso_iter ---
+// Default PSO pipeline: ONE launch per PSO iteration.  The wave of (candidate c, particle i) first replays
+// everything PsoSolver::run() does between two fitness passes (updateFitness, updateGbest, the convergence
+// test, the inertia update: psosolver.cpp:121-149, 286-306) from the previous launch's swarm buffer -- the N
+// particles of the candidate sit in lanes 0..N-1, so this costs a few hundred instructions instead of a
+// dependent k_pso_step launch -- then moves ITS OWN particle (getLocalBest / setNearNeighborBest / moveParticles,
+// :151-265), stores it into the other swarm buffer and evaluates the cost there.  Every wave of a candidate
+// derives the same loop-carried scalars from the same inputs; particle 0's wave stores them (and, when the run
+// ends, the result).  Comparisons and selections are reorganised over lanes, arithmetic is not: each value
+// is produced by the same operation sequence as in pso_step_wave_t / oracle po_pso_run.
+
+// lexicographic wave arg-min over (key, tie) of the lanes with valid != 0; returns the winner's tie or -1
+__device__ __forceinline__ int wave_argmin_lex(bool valid, double key, int tie)
+{
+    double k = key;
+    int t = tie;
+    int v = valid ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ok = __shfl_xor(k, m, 64);
+        const int ot = __shfl_xor(t, m, 64);
+        const int ov = __shfl_xor(v, m, 64);
+        const bool take = ov && (!v || ok < k || (ok == k && ot < t));
+        k = take ? ok : k;
+        t = take ? ot : t;
+        v = take ? 1 : v;
+    }
+    return v ? t : -1;
+}
+
+// moveParticles for particle i with the swarm in lanes (lane j = particle j, N <= 64): same selections as
+// pso_move_particle (pais_dev.hpp), evaluated across lanes
+__device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw, const double *u, const double *pos,
+                                             const double *pb, double fitj, double pbf, int lane, const double *gB,
+                                             const double *rl, const double *ru, const double *vecI, const double *nbI,
+                                             double *outP, double *outV, double *outNb)
+{
+    const double pw = 1.2, gw = 1.5, lw = 1.0, nw = 1.0; // psosolver.h:110
+    const double pVecW = pw * u[0], gVecW = gw * u[1], lVecW = lw * u[2], nVecW = nw * u[3];
+    const bool pv = lane < N;
+    const double pp0 = __shfl(pb[0], i, 64), pp1 = __shfl(pb[1], i, 64), pp2 = __shfl(pb[2], i, 64);
+    // getLocalBest: the localK nearest pBests by (squared distance, index); among them the first strict minimum
+    // of pBestFitness in selection order
+    double dj;
+    if (lane == i) {
+        dj = DBL_MAX;
+    } else {
+        const double d0 = pp0 - pb[0], d1 = pp1 - pb[1], d2 = pp2 - pb[2];
+        dj = 0;
+        dj += d0 * d0;
+        dj += d1 * d1;
+        dj += d2 * d2;
+    }
+    int rank = 0;
+    for (int j = 0; j < N; ++j) {
+        const double o = __shfl(dj, j, 64);
+        rank += (o < dj || (o == dj && j < lane)) ? 1 : 0;
+    }
+    const bool sel = pv && rank < localK;
+    const int w = wave_argmin_lex(sel && pbf < DBL_MAX, pbf, rank * 64 + lane);
+    const int lIdx = (w < 0) ? i : (w & 63);
+    // setNearNeighborBest: per dimension the first maximum of the fitness-distance ratio
+    const double fitI = __shfl(fitj, i, 64);
+    for (int d = 0; d < 3; ++d) {
+        const double pd = __shfl(pos[d], i, 64);
+        const double FDR = (fitI - pbf) / fabs(pd - pb[d]);
+        const bool cand = pv && lane != i && FDR > -DBL_MAX;
+        const int wn = wave_argmin_lex(cand, -FDR, lane);
+        const double o = __shfl(pb[d], wn < 0 ? 0 : wn, 64);
+        outNb[d] = (wn < 0) ? nbI[d] : o;
+    }
+    for (int d = 0; d < 3; ++d) {
+        double p = __shfl(pos[d], i, 64);
+        const double pbi = __shfl(pb[d], i, 64), pbl = __shfl(pb[d], lIdx, 64);
+        double v = iw * vecI[d] + pVecW * (pbi - p) + gVecW * (gB[d] - p) + lVecW * (pbl - p) + nVecW * (outNb[d] - p);
+        outV[d] = v;
+        p += v;
+        if (p > ru[d]) p = ru[d];
+        if (p < rl[d]) p = rl[d];
+        outP[d] = p;
+    }
+}
+
+// launch L = 0: cost of the initial swarm.  L >= 1: step (L-1) + cost of the moved particle.  finishOnly: one
+// wave per candidate that only replays the step (the launch after the last possible iteration: every run ends).
+__global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+                                            pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    EvalPatch *ep = (EvalPatch *)smem;
+    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
+    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
+    double *cbuf = Hbuf + Kmax * 9;
+    const int lane = threadIdx.x;
+    const size_t SB = pso_state_bytes(Nmax);
+    const int per = finishOnly ? 1 : Nmax;
+    const int total = n * per;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int c = t / per, i = t - c * per;
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        if (!hd->active || i >= hd->N) continue;
+        const int N = hd->N;
+        PsoArrays Wb = pso_arrays((unsigned char *)hd, Nmax, L & 1);
+        double p0, p1, p2;
+        if (L == 0) {
+            p0 = Wb.pos[i][0];
+            p1 = Wb.pos[i][1];
+            p2 = Wb.pos[i][2];
+        } else {
+            PsoArrays Rb = pso_arrays((unsigned char *)hd, Nmax, (L - 1) & 1);
+            const PsoState::IterDyn dr = hd->dyn[(L - 1) & 1];
+            const int maxIt = hd->maxIt;
+            const int jl = lane < N ? lane : 0;
+            double pos[3], pb[3];
+            for (int d = 0; d < 3; ++d) {
+                pos[d] = Rb.pos[jl][d];
+                pb[d] = Rb.pBest[jl][d];
+            }
+            const double fitj = Rb.fit[jl];
+            double pbf = Rb.pBestFit[jl];
+            int it, g;
+            double gf, iw;
+            if (!dr.started) {
+                // initFitness (:112-119) + run(): gBest = particles[0].pBest; updateGbest (:137-149)
+                pbf = fitj;
+                g = 0;
+                gf = __shfl(pbf, 0, 64);
+                iw = dr.iw;
+                it = 0;
+            } else {
+                // updateFitness (:121-135): pBest on strict '<'
+                if (fitj < pbf) {
+                    pbf = fitj;
+                    pb[0] = pos[0];
+                    pb[1] = pos[1];
+                    pb[2] = pos[2];
+                }
+                g = dr.gIdx;
+                gf = dr.gBestFitness;
+                const double niw = dr.iw - 1.0 / maxIt; // :304
+                iw = niw > 0.4 ? niw : 0.4;
+                it = dr.iteration + 1;
+            }
+            for (int j = 0; j < N; ++j) {
+                const double v = __shfl(pbf, j, 64);
+                if (v <= gf) {
+                    gf = v;
+                    g = j;
+                }
+            }
+            const double gB[3] = {__shfl(pb[0], g, 64), __shfl(pb[1], g, 64), __shfl(pb[2], g, 64)};
+            // loop head of run(): `iteration < maxIteration`, then the convergence break (:293-297)
+            bool finished = it >= maxIt;
+            if (!finished) {
+                const double a0 = fabs(pos[0] - gB[0]), a1 = fabs(pos[1] - gB[1]), a2 = fabs(pos[2] - gB[2]);
+                double disp = 0;
+                for (int j = 0; j < N; ++j) {
+                    disp += __shfl(a0, j, 64);
+                    disp += __shfl(a1, j, 64);
+                    disp += __shfl(a2, j, 64);
+                }
+                disp /= (double)(3 * N);
+                if (disp < 0.01) {
+                    const double v0 = fabs(Rb.vec[jl][0]), v1 = fabs(Rb.vec[jl][1]), v2 = fabs(Rb.vec[jl][2]);
+                    double vel = 0;
+                    for (int j = 0; j < N; ++j) {
+                        vel += __shfl(v0, j, 64);
+                        vel += __shfl(v1, j, 64);
+                        vel += __shfl(v2, j, 64);
+                    }
+                    vel /= (double)(3 * N);
+                    finished = vel < 0.01;
+                }
+            }
+            if (finished) {
+                if (i == 0 && lane == 0) {
+                    // write back (patch.cpp:208-213) and the maxFitness gate (:156-159)
+                    pais_patch_result *P = &recs[c];
+                    double nn[3];
+                    spherical2normal(gB[0], gB[1], nn);
+                    P->fitness = gf;
+                    P->normalS[0] = gB[0];
+                    P->normalS[1] = gB[1];
+                    for (int q = 0; q < 3; ++q) P->normal[q] = nn[q];
+                    P->depth = gB[2];
+                    const DevCamera &rc = sc.cams[hd->refCam];
+                    for (int q = 0; q < 3; ++q) P->center[q] = hd->ray[q] * gB[2] + rc.C[q];
+                    P->pso_runs += 1;
+                    P->pso_iterations += it;
+                    const int evals = N * (1 + it);
+                    P->pso_evals += evals;
+                    if (gf > sc.cfg.maxFitness) {
+                        P->dropped = 1;
+                        P->stage = PAIS_STAGE_DONE;
+                    } else {
+                        P->stage = PAIS_STAGE_AFTER;
+                    }
+                    hd->active = 0;
+                    const int K = hd->K;
+                    const unsigned long long perEval = (unsigned long long)(4 * K + 1 + (sc.cfg.adaptiveDistanceEnable ? 8 : 0) +
+                                                                            (sc.cfg.adaptiveGradientEnable ? 8 : 0));
+                    atomicAdd(&stat[0], (unsigned long long)evals);
+                    atomicAdd(&stat[1], (unsigned long long)evals * perEval);
+                    atomicAdd(&stat[2], 1ULL);
+                }
+                continue;
+            }
+            // moveParticles (:220-265) for iteration `it`, own particle only
+            const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
+            const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
+            const double vecI[3] = {Rb.vec[i][0], Rb.vec[i][1], Rb.vec[i][2]};
+            const double nbI[3] = {Rb.nBest[i][0], Rb.nBest[i][1], Rb.nBest[i][2]};
+            double u[4];
+            const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
+            for (int q = 0; q < 4; ++q) u[q] = uniform_from(hd->streamBase, (uint32_t)hd->run, k0 + q);
+            double nP[3], nV[3], nNb[3];
+            pso_move_own(i, N, hd->localK, iw, u, pos, pb, fitj, pbf, lane, gB, rl, ru, vecI, nbI, nP, nV, nNb);
+            const double pbI[3] = {__shfl(pb[0], i, 64), __shfl(pb[1], i, 64), __shfl(pb[2], i, 64)};
+            const double pbfI = __shfl(pbf, i, 64);
+            if (lane == 0) {
+                for (int d = 0; d < 3; ++d) {
+                    Wb.pos[i][d] = nP[d];
+                    Wb.vec[i][d] = nV[d];
+                    Wb.pBest[i][d] = pbI[d];
+                    Wb.nBest[i][d] = nNb[d];
+                }
+                Wb.pBestFit[i] = pbfI;
+                if (i == 0) {
+                    PsoState::IterDyn dw;
+                    dw.iw = iw;
+                    dw.gBestFitness = gf;
+                    dw.gIdx = g;
+                    dw.iteration = it;
+                    dw.started = 1;
+                    dw.pad = 0;
+                    hd->dyn[L & 1] = dw;
+                }
+            }
+            p0 = nP[0];
+            p1 = nP[1];
+            p2 = nP[2];
+        }
+        if (finishOnly) continue; // unreachable for a well-formed schedule: every run has ended by now
+        __syncthreads();
+        fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
+        __syncthreads();
+        const double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane);
+        if (lane == 0) Wb.fit[i] = v;
+    }
 }
 
 // task queue of the persistent PSO kernel: header + `cap` int slots (-1 = not yet produced)
@@ -1605,6 +1883,21 @@ hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int 
     long total = (long)n * Nmax;
     int grid = (int)(total < 262144 ? total : 262144);
     hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, fuseStep);
+    return hipGetLastError();
+}
+hipError_t pso_iter(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
+                    unsigned long long *stat, int L, int finishOnly, hipStream_t stream)
+{
+    size_t lds = fitness_lds_bytes(Kmax);
+    static bool attrSet = false;
+    if (lds > 64 * 1024 && !attrSet) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_pso_iter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    long total = (long)n * (finishOnly ? 1 : Nmax);
+    int grid = (int)(total < 262144 ? total : 262144);
+    hipLaunchKernelGGL(k_pso_iter, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, L, finishOnly);
     return hipGetLastError();
 }
 size_t pso_queue_ints(int n, int Nmax, int maxIt) { return sizeof(PsoQueue) / sizeof(int) + (size_t)n * Nmax * (size_t)(maxIt + 2); }
