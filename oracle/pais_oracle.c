@@ -754,21 +754,26 @@ double po_get_fitness(const po_scene *s, const po_patch *patch, const double pos
         }
         return fitness / sumWeight;
     } else {
-        /* the HIP kernels' order: pixel k = yi*S + xi goes to lane k%64, lanes add
-         * their pixels in increasing k, then the wave64 butterfly */
+        /* the HIP kernels' order: pixel k = yi*S + xi goes to lane k%64 of
+         * sub-accumulator (k/64)%4; every (sub-accumulator, lane) adds its pixels in increasing k;
+         * each sub-accumulator is reduced with the wave64 butterfly and the four are added as
+         * ((a0 + a1) + a2) + a3 -- the shape is the same whether one wave or several share a call */
         const int S = s->cfg.patchSize;
         const double a0 = pt[0] - patchRadius, b0 = pt[1] - patchRadius;
-        double pf[64] = {0}, pw[64] = {0};
+        double pf[4][64] = {{0}}, pw[4][64] = {{0}};
         for (int k = 0; k < S * S; ++k) {
             const int yi = k / S, xi = k - yi * S;
             const double x = a0 + (double)xi, y = b0 + (double)yi;
             int st = fit_pixel(&fx, x, y, s->gauss[xi * S + yi], &weight, &avgSad);
             if (st < 0) return DBL_MAX;
             if (st == 0) continue;
-            pw[k & 63] += weight;
-            pf[k & 63] = s->detMath ? fma(weight, avgSad, pf[k & 63]) : pf[k & 63] + weight * avgSad;
+            const int a = (k >> 6) & 3, l = k & 63;
+            pw[a][l] += weight;
+            pf[a][l] = s->detMath ? fma(weight, avgSad, pf[a][l]) : pf[a][l] + weight * avgSad;
         }
-        return tree64(pf) / tree64(pw);
+        const double F = ((tree64(pf[0]) + tree64(pf[1])) + tree64(pf[2])) + tree64(pf[3]);
+        const double W = ((tree64(pw[0]) + tree64(pw[1])) + tree64(pw[2])) + tree64(pw[3]);
+        return F / W;
     }
 }
 

@@ -65,6 +65,8 @@ struct pais_ctx {
                                         // 2: eval launches with last-arriver step, 3: persistent task-queue kernel,
                                         // 0: fused one-workgroup-per-candidate k_pso  (measured alternatives)
     int psoMinPer = 64;
+    int evalParts = 0;                  // waves per cost evaluation in k_pso_iter (1, 2, 4); 0 = chosen per slice
+    double partFill = 1.0;              // ... such that parts * waves <= partFill * resident wave slots
     int psoStreams = 2;                 // slices of a batch whose eval/step sequences overlap on separate HIP streams
     std::vector<hipStream_t> sub;       // sub-streams
     std::vector<hipEvent_t> subDone;
@@ -236,6 +238,8 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     HIPCHK(hipHostMalloc((void **)&ctx->h_counters, sizeof(int) * 4, hipHostMallocDefault));
     if (const char *e = getenv("PAIS_PSO_MODE"))
         ctx->psoMode = (strcmp(e, "fused") == 0) ? 0 : (strcmp(e, "laststep") == 0) ? 2 : (strcmp(e, "persist") == 0) ? 3 : (strcmp(e, "split") == 0) ? 1 : 4;
+    if (const char *e = getenv("PAIS_EVAL_PARTS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) ctx->evalParts = v; }
+    if (const char *e = getenv("PAIS_PART_FILL")) { double v = atof(e); if (v > 0) ctx->partFill = v; }
     if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     HIPCHK(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming));
@@ -487,6 +491,13 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                     hipStream_t st = (S == 1) ? ctx->stream : ctx->sub[sI];
                     if (S > 1) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
                     unsigned char *stp = ctx->d_psoStates + SB * (size_t)lo;
+                    // waves per evaluation: a slice that leaves the GPU mostly empty is bound by the latency of
+                    // one evaluation wave, so share each evaluation among 4 (2) waves while they all stay resident
+                    int parts = 1;
+                    if (useIter) {
+                        const long waves = (long)(hi - lo) * Nmax, resident = (long)((double)ctx->numCUs * 16 * ctx->partFill);
+                        parts = ctx->evalParts > 0 ? ctx->evalParts : (waves * 4 <= resident ? 4 : (waves * 2 <= resident ? 2 : 1));
+                    }
                     for (int it = 0; it <= maxIt; ++it) {
                         EventPair ee;
                         const bool timeIt = ctx->fineTiming && S == 1;
@@ -495,7 +506,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                             HIPCHK(hipEventRecord(ee.a, st));
                         }
                         if (useIter)
-                            HIPCHK(pais_launch::pso_iter(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, it, 0, st));
+                            HIPCHK(pais_launch::pso_iter(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, it, 0, parts, st));
                         else
                             HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0, st));
                         if (timeIt) {
@@ -506,7 +517,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                         if (!useIter) HIPCHK(pais_launch::pso_split_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
                     }
                     // the launch after the last possible iteration only ends the runs still active
-                    if (useIter) HIPCHK(pais_launch::pso_iter(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, maxIt + 1, 1, st));
+                    if (useIter) HIPCHK(pais_launch::pso_iter(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, maxIt + 1, 1, parts, st));
                     if (S > 1) {
                         HIPCHK(hipEventRecord(ctx->subDone[sI], st));
                         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI], 0));

@@ -50,7 +50,7 @@ hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int
 hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
                           unsigned long long *stat, int fuseStep, hipStream_t stream);
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
-                    unsigned long long *stat, int L, int finishOnly, hipStream_t stream);
+                    unsigned long long *stat, int L, int finishOnly, int nparts, hipStream_t stream);
 size_t pso_queue_ints(int n, int Nmax, int maxIt);
 hipError_t pso_persist(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, int maxIt, pais_patch_result *recs,
                        unsigned long long *stat, int *qmem, int numCUs, hipStream_t stream);

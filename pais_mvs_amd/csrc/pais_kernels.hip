@@ -36,6 +36,8 @@ using namespace pais;
 #endif
 // k_pso_iter / k_fitness: 4 waves per SIMD (<= 128 VGPRs) without spilling
 #define PAIS_ITER_BOUNDS __launch_bounds__(64, 4)
+// rows of 64 doubles in a wave's colour buffer: one per camera + the 8 lane accumulators of eval_fitness_parts
+#define PAIS_CBUF_ROWS(K) ((K) + 8)
 
 // --------------------------------------------------------------- helpers ---
 __device__ __forceinline__ void wave_sync()
@@ -204,19 +206,29 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 // PAIS::getFitness for one particle, executed by ONE wave (all 64 lanes enter
 // with identical arguments and leave with the identical result).
 //   Hbuf : this wave's LDS scratch, K*9 doubles   (homographies, patch.cpp:290-330)
-//   cbuf : this wave's LDS scratch, K*64 doubles  (per-camera colour of the lane's pixel)
+//   cbuf : this wave's LDS scratch, (K+8)*64 doubles (per-camera colour of the lane's pixel; rows K..K+7:
+//          the lane's 4 x (fitness, weight) sub-accumulators -- in LDS, not registers, to stay at 4 waves/SIMD)
 // Arithmetic ("kernel arithmetic"; mirrored bit for bit by the oracle's
 // detMath/treeSum mode): homography rows with fma, ONE reciprocal per tap, bilinear as
 // two fma lerps, mean/SAD scaled by 1/K, exp/sin/cos from pais_detmath.hpp, lane partial
 // sums in increasing pixel index followed by the wave64 xor butterfly.
-__device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf,
-                               double *cbuf, double theta, double phi, double depth, int lane)
+// Reduction shape (canonical, independent of how many waves share one evaluation): the 64-pixel steps of the
+// window are dealt round-robin to FOUR sub-accumulators (step mod 4); each is summed per lane over its steps,
+// butterfly-reduced over the 64 lanes, and the four results are added as ((a0 + a1) + a2) + a3.  One wave
+// computes all four (nparts = 1), or `nparts` (2 / 4) waves compute the sub-accumulators a with
+// a mod nparts == part and whoever consumes the fitness adds them -- the same bits either way.
+// Returns 0 and fills f4/w4 (zeros for the sub-accumulators of other parts), or 1 if the call is DBL_MAX.
+__device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf,
+                                  double *cbuf, double theta, double phi, double depth, int lane, int part, int nparts,
+                                  double *f4, double *w4)
 {
+    f4[0] = f4[1] = f4[2] = f4[3] = 0;
+    w4[0] = w4[1] = w4[2] = w4[3] = 0;
     double n[3];
     spherical2normal(theta, phi, n);
     {
         double on[3] = {ep->optNref[0], ep->optNref[1], ep->optNref[2]};
-        if (dot3(n, on) > 0) return DBL_MAX; // patch.cpp:939
+        if (dot3(n, on) > 0) return 1; // patch.cpp:939
     }
     double center[3];
     for (int i = 0; i < 3; ++i) center[i] = ep->ray[i] * depth + ep->Cref[i]; // :944
@@ -254,9 +266,9 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
         project_raw(R, T, f, pp, s, center, pt);
     }
     const int refW = ep->refW, refH = ep->refH;
-    if (!in_image_d(pt, refW, refH)) return DBL_MAX; // :952
+    if (!in_image_d(pt, refW, refH)) return 1; // :952
     const int r = sc.cfg.patchRadius;
-    if (pt[0] - r < 2 || pt[0] + r >= refW - 3 || pt[1] - r < 2 || pt[1] + r >= refH - 3) return DBL_MAX; // :957
+    if (pt[0] - r < 2 || pt[0] + r >= refW - 3 || pt[1] - r < 2 || pt[1] + r >= refH - 3) return 1; // :957
 
     const int S = sc.cfg.patchSize, S2 = S * S;
     const double a0 = pt[0] - r, b0 = pt[1] - r;
@@ -266,13 +278,17 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
     const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useDiff = sc.cfg.adaptiveDifferenceEnable != 0,
                useGrad = sc.cfg.adaptiveGradientEnable != 0;
     const double invK = 1.0 / (double)K;
-    double fsum = 0, wsum = 0;
     double *myc = cbuf + lane;
+    double *myacc = cbuf + (size_t)K * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
+#pragma unroll
+    for (int a = 0; a < 8; ++a) myacc[a * 64] = 0;
 
     // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel
     // index / clamped addresses for lanes that have no pixel, a masked pixel or an overflowing
     // tap); only wave-uniform conditions branch.  Contributions are selected at the end.
-    for (int base = 0; base < S2; base += 64) {
+    for (int base = 0, step = 0; base < S2; base += 64, ++step) {
+        const int acc = step & 3;             // wave-uniform
+        if ((acc & (nparts - 1)) != part) continue; // another wave's share (nparts is 1, 2 or 4)
         const int k = base + lane;
         const bool valid = k < S2;
         const int kk = valid ? k : (S2 - 1);
@@ -285,7 +301,7 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
         int c0 = 0;
         for (; c0 + 2 <= K; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // camera pairs
         if (c0 < K) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);                  // odd leftover
-        if (__any(act && badBits != 0)) return DBL_MAX; // :1001 -- whole call
+        if (__any(act && badBits != 0)) return 1; // :1001 -- whole call
         const double mean = sum * invK;
         double sad = 0;
         for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
@@ -294,12 +310,31 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
         if (useDist) weight *= sc.gauss[xi * S + yi];
         if (useDiff) weight *= det_exp(-(sad * sad) * invDiffW);
         if (useGrad) weight *= det_exp(-1.0 / (refEdge[ry * refW + rx] * gradW));
-        wsum = act ? (wsum + weight) : wsum;
-        fsum = act ? fma(weight, sad, fsum) : fsum;
+        double *pa = myacc + acc * 128;
+        const double w0 = pa[64], f0 = pa[0];
+        pa[64] = act ? (w0 + weight) : w0;
+        pa[0] = act ? fma(weight, sad, f0) : f0;
     }
-    fsum = wave_sum(fsum);
-    wsum = wave_sum(wsum);
-    return fsum / wsum; // NaN when every pixel was masked, as in the reference
+    // butterflies only for this wave's sub-accumulators (uniform conditions)
+    for (int a = part; a < 4; a += nparts) {
+        f4[a] = wave_sum(myacc[a * 128]);
+        w4[a] = wave_sum(myacc[a * 128 + 64]);
+    }
+    return 0;
+}
+__device__ __forceinline__ double combine_parts(const double *f4, const double *w4)
+{
+    const double F = ((f4[0] + f4[1]) + f4[2]) + f4[3];
+    const double W = ((w4[0] + w4[1]) + w4[2]) + w4[3];
+    return F / W; // NaN when every pixel was masked, as in the reference
+}
+// one wave evaluates the whole call
+__device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf,
+                               double *cbuf, double theta, double phi, double depth, int lane)
+{
+    double f4[4], w4[4];
+    if (eval_fitness_parts(sc, ep, cams, Hbuf, cbuf, theta, phi, depth, lane, 0, 1, f4, w4)) return DBL_MAX;
+    return combine_parts(f4, w4);
 }
 
 // ------------------------------------------------------------- k_fitness ---
@@ -767,7 +802,7 @@ __global__ __launch_bounds__(512) void k_pso(DevScene sc, pais_patch_result *rec
     double *Hall = (double *)(smem + off); off += sizeof(double) * 9 * Kmax * W;
     double *call = (double *)(smem + off);
     double *Hbuf = Hall + (size_t)wave * 9 * Kmax;
-    double *cbuf = call + (size_t)wave * 64 * Kmax;
+    double *cbuf = call + (size_t)wave * 64 * PAIS_CBUF_ROWS(Kmax);
 
     for (;;) {
         __syncthreads();
@@ -981,25 +1016,29 @@ struct PsoState { // one per candidate, in global memory; the per-particle array
         int gIdx, iteration, started, pad;
     } dyn[2];
 };
+#define PSO_DOUBLES_PER_PARTICLE (3 * 4 + 2 + 8)
 __host__ __device__ inline size_t pso_state_bytes(int Nmax)
 {
-    // header + two swarm buffers (k_pso_iter reads one and writes the other; the other pipelines use buffer 0)
-    return ((sizeof(PsoState) + 15) & ~(size_t)15) + 2 * sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
+    // header + two swarm buffers (k_pso_iter reads one and writes the other; the other pipelines use buffer 0);
+    // per particle 14 doubles of swarm state + 8 partial sums (evaluations shared by several waves)
+    return ((sizeof(PsoState) + 15) & ~(size_t)15) + 2 * sizeof(double) * (size_t)Nmax * PSO_DOUBLES_PER_PARTICLE;
 }
 struct PsoArrays {
     double (*pos)[3], (*vec)[3], (*pBest)[3], (*nBest)[3];
     double *fit, *pBestFit;
+    double (*part)[8]; // (f, w) of the 4 canonical sub-accumulators when an evaluation is shared by several waves
 };
 __device__ __forceinline__ PsoArrays pso_arrays(unsigned char *base, int Nmax, int buf = 0)
 {
     PsoArrays a;
-    unsigned char *q = base + ((sizeof(PsoState) + 15) & ~(size_t)15) + (size_t)buf * sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
+    unsigned char *q = base + ((sizeof(PsoState) + 15) & ~(size_t)15) + (size_t)buf * sizeof(double) * (size_t)Nmax * PSO_DOUBLES_PER_PARTICLE;
     a.pos = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
     a.vec = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
     a.pBest = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
     a.nBest = (double(*)[3])q; q += sizeof(double) * 3 * Nmax;
     a.fit = (double *)q; q += sizeof(double) * Nmax;
-    a.pBestFit = (double *)q;
+    a.pBestFit = (double *)q; q += sizeof(double) * Nmax;
+    a.part = (double(*)[8])q;
     return a;
 }
 
@@ -1102,7 +1141,7 @@ __global__ PAIS_EVAL_BOUNDS void k_pso_eval(DevScene sc, unsigned char *states, 
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
     double *cbuf = Hbuf + Kmax * 9;
-    unsigned char *stepSmem = (unsigned char *)(cbuf + (size_t)Kmax * 64);
+    unsigned char *stepSmem = (unsigned char *)(cbuf + (size_t)PAIS_CBUF_ROWS(Kmax) * 64);
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
     const int total = n * Nmax;
@@ -1231,6 +1270,7 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 
 // launch L = 0: cost of the initial swarm.  L >= 1: step (L-1) + cost of the moved particle.  finishOnly: one
 // wave per candidate that only replays the step (the launch after the last possible iteration: every run ends).
+template <int nparts>
 __global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly)
 {
@@ -1241,10 +1281,15 @@ __global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, 
     double *cbuf = Hbuf + Kmax * 9;
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
-    const int per = finishOnly ? 1 : Nmax;
+    // nparts (1, 2, 4) consecutive waves share one evaluation: small rounds are bound by the latency of a
+    // single evaluation wave, not by throughput.  Every part replays the step (identical results), part 0
+    // stores the moved particle, each part stores its sub-accumulators; the consumer -- the step replay of
+    // the next launch -- adds them in the canonical order.
+    const int per = finishOnly ? 1 : Nmax * nparts;
     const int total = n * per;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const int c = t / per, i = t - c * per;
+        const int c = t / per, ip = t - c * per;
+        const int i = ip / nparts, part = ip - i * nparts;
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         if (!hd->active || i >= hd->N) continue;
         const int N = hd->N;
@@ -1264,7 +1309,19 @@ __global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, 
                 pos[d] = Rb.pos[jl][d];
                 pb[d] = Rb.pBest[jl][d];
             }
-            const double fitj = Rb.fit[jl];
+            double fitj;
+            if (nparts == 1) {
+                fitj = Rb.fit[jl];
+            } else {
+                double f4[4], w4[4];
+                bool bad = false;
+                for (int a = 0; a < 4; ++a) {
+                    f4[a] = Rb.part[jl][2 * a];
+                    w4[a] = Rb.part[jl][2 * a + 1];
+                    bad = bad || (w4[a] < 0); // a part's call overflowed: DBL_MAX
+                }
+                fitj = bad ? DBL_MAX : combine_parts(f4, w4);
+            }
             double pbf = Rb.pBestFit[jl];
             int it, g;
             double gf, iw;
@@ -1321,7 +1378,7 @@ __global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, 
                 }
             }
             if (finished) {
-                if (i == 0 && lane == 0) {
+                if (i == 0 && part == 0 && lane == 0) {
                     // write back (patch.cpp:208-213) and the maxFitness gate (:156-159)
                     pais_patch_result *P = &recs[c];
                     double nn[3];
@@ -1365,7 +1422,7 @@ __global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, 
             pso_move_own(i, N, hd->localK, iw, u, pos, pb, fitj, pbf, lane, gB, rl, ru, vecI, nbI, nP, nV, nNb);
             const double pbI[3] = {__shfl(pb[0], i, 64), __shfl(pb[1], i, 64), __shfl(pb[2], i, 64)};
             const double pbfI = __shfl(pbf, i, 64);
-            if (lane == 0) {
+            if (lane == 0 && part == 0) {
                 for (int d = 0; d < 3; ++d) {
                     Wb.pos[i][d] = nP[d];
                     Wb.vec[i][d] = nV[d];
@@ -1392,8 +1449,18 @@ __global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, 
         __syncthreads();
         fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
         __syncthreads();
-        const double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane);
-        if (lane == 0) Wb.fit[i] = v;
+        double f4[4], w4[4];
+        const int st = eval_fitness_parts(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane, part, nparts, f4, w4);
+        if (lane == 0) {
+            if (nparts == 1) {
+                Wb.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
+            } else {
+                for (int a = part; a < 4; a += nparts) {
+                    Wb.part[i][2 * a] = st ? 0.0 : f4[a];
+                    Wb.part[i][2 * a + 1] = st ? -1.0 : w4[a];
+                }
+            }
+        }
     }
 }
 
@@ -1603,7 +1670,7 @@ __global__ PAIS_EVAL_BOUNDS void k_pso_persist(DevScene sc, unsigned char *state
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
     double *cbuf = Hbuf + Kmax * 9;
-    unsigned char *stepSmem = (unsigned char *)(cbuf + (size_t)Kmax * 64);
+    unsigned char *stepSmem = (unsigned char *)(cbuf + (size_t)PAIS_CBUF_ROWS(Kmax) * 64);
     PsoQueue *q = (PsoQueue *)qmem;
     int *slots = qmem + (sizeof(PsoQueue) / sizeof(int));
     const int lane = threadIdx.x;
@@ -1791,7 +1858,7 @@ static size_t pso_lds_bytes(int W, int Kmax, int Nmax)
     off += sizeof(double) * Nmax * 2;
     off += sizeof(EvalCam) * Kmax;
     off += sizeof(double) * 9 * Kmax * W;
-    off += sizeof(double) * 64 * Kmax * W;
+    off += sizeof(double) * 64 * PAIS_CBUF_ROWS(Kmax) * W;
     return off;
 }
 static size_t after_lds_bytes(int Kmax)
@@ -1804,7 +1871,7 @@ static size_t after_lds_bytes(int Kmax)
 }
 static size_t fitness_lds_bytes(int Kmax)
 {
-    return sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * Kmax;
+    return sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * PAIS_CBUF_ROWS(Kmax);
 }
 
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, const int32_t *idx, const double *particles,
@@ -1886,18 +1953,25 @@ hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int 
     return hipGetLastError();
 }
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
-                    unsigned long long *stat, int L, int finishOnly, hipStream_t stream)
+                    unsigned long long *stat, int L, int finishOnly, int nparts, hipStream_t stream)
 {
     size_t lds = fitness_lds_bytes(Kmax);
     static bool attrSet = false;
     if (lds > 64 * 1024 && !attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_pso_iter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_pso_iter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_pso_iter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_pso_iter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attrSet = true;
     }
-    long total = (long)n * (finishOnly ? 1 : Nmax);
+    long total = (long)n * (finishOnly ? 1 : Nmax * nparts);
     int grid = (int)(total < 262144 ? total : 262144);
-    hipLaunchKernelGGL(k_pso_iter, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, L, finishOnly);
+    if (nparts == 4)
+        hipLaunchKernelGGL(k_pso_iter<4>, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, L, finishOnly);
+    else if (nparts == 2)
+        hipLaunchKernelGGL(k_pso_iter<2>, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, L, finishOnly);
+    else
+        hipLaunchKernelGGL(k_pso_iter<1>, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, L, finishOnly);
     return hipGetLastError();
 }
 size_t pso_queue_ints(int n, int Nmax, int maxIt) { return sizeof(PsoQueue) / sizeof(int) + (size_t)n * Nmax * (size_t)(maxIt + 2); }
