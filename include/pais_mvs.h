@@ -68,6 +68,14 @@ int  pais_mvs_refine_seed_patches(pais_mvs *m);
  * parents; max_rounds <= 0: until the queue is empty. */
 int  pais_mvs_expansion_patches(pais_mvs *m, int parents_per_round, int max_rounds);
 
+/* Round rule for the tail of the expansion: a round whose active set holds <= thin_front parents handles
+ * ALL remaining camera slots of each of them instead of one (0 = never).  Thin rounds are pure latency on
+ * the GPU, so taking the whole parent costs a few speculative refines and saves 4-5 rounds per generation.
+ * With one parent per round this is exactly MVS::expandNeighborCell's loop over the visible cameras
+ * (mvs.cpp:529-563).  Part of the schedule definition R(B): the oracle applies the same rule. */
+#define PAIS_DEFAULT_THIN_FRONT 64
+int  pais_mvs_set_thin_front(pais_mvs *m, int thin_front);
+
 /* ---- stepwise (multi-GPU) --------------------------------------------- */
 /* seeds: candidates of all seeds with camNum >= minCamNum (others are deleted) */
 int  pais_mvs_seed_begin(pais_mvs *m, const pais_candidate **cands, int *n);

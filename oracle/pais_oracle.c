@@ -1549,6 +1549,7 @@ struct po_mvs {
     int *born;      /* round in which patch id was inserted (-1: before expansion) */
     int bornCap;
     int curRound;
+    int thinFront; /* R(B): rounds whose active set has <= thinFront parents take ALL remaining camera slots of every parent */
 };
 
 po_mvs *po_mvs_create(po_scene *s)
@@ -1556,6 +1557,7 @@ po_mvs *po_mvs_create(po_scene *s)
     po_mvs *m = (po_mvs *)calloc(1, sizeof(po_mvs));
     m->s = s;
     m->curRound = -1;
+    m->thinFront = PO_DEFAULT_THIN_FRONT;
     return m;
 }
 
@@ -1981,13 +1983,20 @@ long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
             nA++;
         }
         if (nA == 0 && nDef == 0) break;
-        /* work list of the round */
-        int nW = nDef + 4 * nA;
+        /* work list of the round: one camera slot of every active parent; a thin front (few active
+         * parents -- the long tail of the expansion) takes all remaining slots of its parents at once */
+        const int thin = nA <= m->thinFront;
+        int nW = nDef;
+        for (int a = 0; a < nA; ++a) nW += 4 * (thin ? m->patches[actId[a]]->numCam - actSlot[a] : 1);
         if (nW > capWork) { capWork = nW * 2; work = (po_unit *)realloc(work, sizeof(po_unit) * (size_t)capWork); }
         nW = 0;
         for (int d = 0; d < nDef; ++d) work[nW++] = deferred[d];
-        for (int a = 0; a < nA; ++a)
-            for (int j = 0; j < 4; ++j) { work[nW].id = actId[a]; work[nW].slot = actSlot[a]; work[nW].j = j; nW++; }
+        for (int a = 0; a < nA; ++a) {
+            const int sEnd = thin ? m->patches[actId[a]]->numCam : actSlot[a] + 1;
+            for (int sl = actSlot[a]; sl < sEnd; ++sl)
+                for (int j = 0; j < 4; ++j) { work[nW].id = actId[a]; work[nW].slot = sl; work[nW].j = j; nW++; }
+            actSlot[a] = sEnd - 1; /* advanced past sEnd below */
+        }
         if (nW > capClaims) { capClaims = nW * 2; claims = (uint64_t *)realloc(claims, sizeof(uint64_t) * (size_t)capClaims); }
         int nClaims = 0;
         nNext = 0;
@@ -2043,6 +2052,8 @@ long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
     po_mvs_set_neighbor_radius(m);
     return m->refineCalls - before;
 }
+
+void po_mvs_set_thin_front(po_mvs *m, int thinFront) { m->thinFront = thinFront < 0 ? 0 : thinFront; }
 
 size_t po_sizeof_patch(void) { return sizeof(po_patch); }
 size_t po_sizeof_config(void) { return sizeof(po_config); }

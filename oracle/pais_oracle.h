@@ -217,6 +217,10 @@ void    po_mvs_refine_seed_patches(po_mvs *m);          /* mvs.cpp:196-231 */
  * activation order, exactly as the body of MVS::expandNeighborCell does.  B=1 is the
  * reference loop.  maxRounds<=0: run to convergence.  Returns number of refine() calls. */
 long    po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail);
+/* R(B): a round whose active set has <= thinFront parents handles ALL remaining camera slots of each
+ * parent instead of one (0 = never).  Same rule and default as pais_mvs_set_thin_front (include/pais_mvs.h). */
+#define PO_DEFAULT_THIN_FRONT 64
+void    po_mvs_set_thin_front(po_mvs *m, int thinFront);
 int     po_mvs_num_patches(const po_mvs *m);
 int     po_mvs_num_slots(const po_mvs *m);              /* ids are 0..slots-1 */
 const po_patch *po_mvs_get_patch(const po_mvs *m, int id); /* NULL if deleted */

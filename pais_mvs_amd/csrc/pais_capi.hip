@@ -304,6 +304,7 @@ extern "C" int pais_ctx_synchronize(pais_ctx *ctx)
 }
 
 // ------------------------------------------------------------ fitness batch --
+static int get_event_pair(pais_ctx *ctx, EventPair &p);
 extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_state *states, int n_evals,
                                   const int32_t *state_index, const double *particles, double *out)
 {
@@ -337,7 +338,17 @@ extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_
     HIPCHK(hipMemcpyAsync(ctx->d_states, states, sizeof(pais_patch_state) * (size_t)n_states, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_idx, state_index, sizeof(int32_t) * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_particles, particles, sizeof(double) * 3 * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
+    EventPair ef;
+    if (ctx->fineTiming) {
+        if (get_event_pair(ctx, ef)) return -2;
+        HIPCHK(hipEventRecord(ef.a, ctx->stream));
+    }
     HIPCHK(pais_launch::fitness(ctx->sc, ctx->d_states, ctx->d_idx, ctx->d_particles, ctx->d_out, n_evals, Kmax, ctx->stream));
+    if (ctx->fineTiming) { // kernel-only time of k_fitness, reported as eval_ms / eval_launches
+        HIPCHK(hipEventRecord(ef.b, ctx->stream));
+        ctx->evEval.push_back(ef);
+        ctx->evalLaunches++;
+    }
     HIPCHK(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)n_evals, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;

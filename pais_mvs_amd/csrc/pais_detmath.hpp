@@ -97,6 +97,36 @@ PAIS_HD double det_exp(double x)
     return u2d(d2u(y) + ((uint64_t)(int64_t)(k + 1000) << 52)) * twom1000;
 }
 
+// det_exp without lane-divergent branches, bit-identical to det_exp for every input (tests/test_detmath_and_devmath.py).
+// fdlibm special-cases k = 0 (|x| <= 0.5 ln2) and k = +-1 (|x| < 1.5 ln2); both are instances of the general
+// formula: with t = (double)k, hi = x - t*ln2HI and lo = t*ln2LO reproduce their hi / lo exactly (t = 0, +-1 multiply
+// exactly), and for k = 0 the result 1 - ((x*c)/(c-2) - x) equals 1 - ((lo - (x*c)/(2-c)) - hi) because negating a
+// divisor negates the correctly rounded quotient.  Only k itself needs fdlibm's threshold on the high word (the band
+// just above 0.5 ln2 where the rounding formula would already give +-1) -- a select, not a branch.  |x| >= 700
+// (denormal scaling, overflow, inf, NaN) takes the reference routine; the cost never gets there.
+PAIS_HD double det_exp_bf(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    const uint32_t hx0 = (uint32_t)hi_word(x);
+    const uint32_t hx = hx0 & 0x7fffffff;
+    if (hx >= 0x4085E000) return det_exp(x); // |x| >= 700, inf, NaN
+    const double half = (hx0 >> 31) ? -0.5 : 0.5;
+    const int32_t kr = (int32_t)(invln2 * x + half);
+    const int32_t k = (hx > 0x3fd62e42) ? kr : 0;
+    const double t = (double)k;
+    const double hi = x - t * ln2HI;
+    const double lo = t * ln2LO;
+    const double xr = hi - lo;
+    const double tt = xr * xr;
+    const double c = xr - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+    const double y = 1.0 - ((lo - (xr * c) / (2.0 - c)) - hi);
+    const double scaled = u2d(d2u(y) + ((uint64_t)(int64_t)k << 52));
+    return (hx < 0x3e300000) ? (1.0 + x) : scaled;
+}
+
 PAIS_HD double det_ksin(double x, double y, int iy)
 {
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,

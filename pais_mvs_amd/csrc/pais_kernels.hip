@@ -286,30 +286,36 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel
     // index / clamped addresses for lanes that have no pixel, a masked pixel or an overflowing
     // tap); only wave-uniform conditions branch.  Contributions are selected at the end.
-    for (int base = 0, step = 0; base < S2; base += 64, ++step) {
-        const int acc = step & 3;             // wave-uniform
+    // Window pixel of this lane, advanced by 64 pixels per step without a division.
+    const int q64 = 64 / S, r64 = 64 - q64 * S; // uniform
+    int yw = lane / S, xw = lane - yw * S;
+    for (int base = 0, step = 0; base < S2;
+         base += 64, ++step, xw += r64, yw += q64, yw += (xw >= S) ? 1 : 0, xw -= (xw >= S) ? S : 0) {
+        const int acc = step & 3;                   // wave-uniform
         if ((acc & (nparts - 1)) != part) continue; // another wave's share (nparts is 1, 2 or 4)
-        const int k = base + lane;
-        const bool valid = k < S2;
-        const int kk = valid ? k : (S2 - 1);
-        const int yi = kk / S, xi = kk - yi * S;
+        const bool valid = base + lane < S2;
+        const int yi = valid ? yw : (S - 1), xi = valid ? xw : (S - 1); // lanes past the window redo its last pixel
         const double x = a0 + (double)xi, y = b0 + (double)yi; // == the reference's ++x / ++y walk
         const int rx = cv_round(x), ry = cv_round(y);
-        const bool act = valid && (refImg[ry * refW + rx] != 0); // :986
+        // per-pixel operands, requested before the taps so that their latency hides behind them
+        const uint8_t refMask = refImg[ry * refW + rx]; // :986
+        const double wDist = useDist ? sc.gauss[xi * S + yi] : 1.0;
+        const double eGrad = useGrad ? refEdge[ry * refW + rx] : 1.0;
         uint32_t badBits = 0; // != 0: some tap of this pixel left [2, w-3) x [2, h-3)
         double sum = 0;
         int c0 = 0;
         for (; c0 + 2 <= K; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // camera pairs
         if (c0 < K) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);                  // odd leftover
+        const bool act = valid && (refMask != 0);
         if (__any(act && badBits != 0)) return 1; // :1001 -- whole call
         const double mean = sum * invK;
         double sad = 0;
         for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
         sad *= invK;
         double weight = 1;
-        if (useDist) weight *= sc.gauss[xi * S + yi];
-        if (useDiff) weight *= det_exp(-(sad * sad) * invDiffW);
-        if (useGrad) weight *= det_exp(-1.0 / (refEdge[ry * refW + rx] * gradW));
+        if (useDist) weight *= wDist;
+        if (useDiff) weight *= det_exp_bf(-(sad * sad) * invDiffW);
+        if (useGrad) weight *= det_exp_bf(-1.0 / (eGrad * gradW));
         double *pa = myacc + acc * 128;
         const double w0 = pa[64], f0 = pa[0];
         pa[64] = act ? (w0 + weight) : w0;

@@ -99,6 +99,7 @@ struct pais_mvs {
     std::vector<Unit> deferred, nextDeferred; // cell-claim rule: units retried at the head of the next round
     std::unordered_set<uint64_t> claims;
     int curRound = -1;
+    int thinFront = PAIS_DEFAULT_THIN_FRONT; // rounds with <= thinFront active parents take all remaining slots of each parent
     bool queueExhausted = false;
     std::vector<Candidate> cands;
     std::vector<pais_candidate> candRecs;
@@ -427,6 +428,7 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
 {
     if (!cfg || !cams || !out || num_cams <= 0) return mfail("pais_mvs_create: bad argument");
     pais_mvs *m = new pais_mvs();
+    if (const char *e = getenv("PAIS_THIN_FRONT")) m->thinFront = atoi(e) < 0 ? 0 : atoi(e); // tuning sweeps (scripts/)
     memset(&m->st, 0, sizeof(m->st));
     m->cfg = *cfg;
     m->cfg.patchSize = (cfg->patchRadius << 1) + 1;
@@ -654,8 +656,15 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
         m->candRecs.push_back(rec);
     };
     for (const Unit &u : m->deferred) consider(u);
-    for (const Active &a : m->active)
-        for (int j = 0; j < 4; ++j) consider(Unit{a.id, a.slot, j});
+    // one camera slot of every active parent; a thin front (few active parents: the long tail of the
+    // expansion, where a round is pure latency) takes all remaining slots of its parents at once
+    const bool thin = (int)m->active.size() <= m->thinFront;
+    for (Active &a : m->active) {
+        const int sEnd = thin ? m->patches[a.id]->r.num_cam : a.slot + 1;
+        for (int sl = a.slot; sl < sEnd; ++sl)
+            for (int j = 0; j < 4; ++j) consider(Unit{a.id, sl, j});
+        a.slot = sEnd - 1; // round_commit advances past it
+    }
     *cands = m->candRecs.data();
     *n = (int)m->candRecs.size();
     m->st.host_enumerate_ms += now_ms() - t0;
@@ -689,6 +698,13 @@ extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *resul
     m->curRound++;
     m->cands.clear();
     m->st.host_commit_ms += now_ms() - t0;
+    return 0;
+}
+
+extern "C" int pais_mvs_set_thin_front(pais_mvs *m, int thin_front)
+{
+    if (!m) return mfail("pais_mvs_set_thin_front: bad argument");
+    m->thinFront = thin_front < 0 ? 0 : thin_front;
     return 0;
 }
 

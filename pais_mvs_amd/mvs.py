@@ -101,6 +101,10 @@ class MVS:
     def refineSeedPatches(self):
         self._check(self.L.pais_mvs_refine_seed_patches(self.h), "pais_mvs_refine_seed_patches")
 
+    def set_thin_front(self, thin_front: int):
+        """Rounds with <= thin_front active parents take all remaining camera slots of each parent (0 = never)."""
+        self._check(self.L.pais_mvs_set_thin_front(self.h, int(thin_front)), "pais_mvs_set_thin_front")
+
     def expansionPatches(self, parents_per_round: int = 1, max_rounds: int = 0):
         self._check(self.L.pais_mvs_expansion_patches(self.h, parents_per_round, max_rounds), "pais_mvs_expansion_patches")
 

@@ -1,5 +1,6 @@
 """Kernel-only throughput of the cost evaluation (k_fitness): evals/s at saturation."""
 import sys, os, time, ctypes as C
+os.environ["PAIS_FINE_TIMING"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pais_mvs_amd import synth, _lib
@@ -27,4 +28,6 @@ parts = np.array([[ps[i].normalS[0] + rng.normal(0, .05), ps[i].normalS[1] + rng
 K = np.mean([ps[i].num_cam for i in idx])
 for rep in range(3):
     t0 = time.perf_counter(); out = ctx.fitness_batch(states, idx, parts); dt = time.perf_counter() - t0
-    print("evals %d  K %.2f  %.1f ms  %.1f M evals/s  (%.1f G taps/s) finite %.3f" % (n, K, dt * 1e3, n / dt / 1e6, n * 961 * K / dt / 1e9, np.mean(out < 1e300)), flush=True)
+    ks = _lib.KernelStats(); ctx.L.pais_get_kernel_stats(ctx.h, C.byref(ks), 1)
+    kt = ks.eval_ms / 1e3
+    print("evals %d  K %.2f  call %.1f ms  kernel %.2f ms  %.1f M evals/s  (%.1f G taps/s) finite %.3f" % (n, K, dt * 1e3, kt * 1e3, n / kt / 1e6, n * 961 * K / kt / 1e9, np.mean(out < 1e300)), flush=True)

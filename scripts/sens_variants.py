@@ -1,0 +1,39 @@
+"""Sensitivity variants of the cost kernel (NOT products: each breaks the arithmetic on purpose to show what a
+component costs).  Builds pais_mvs_amd/csrc/variants/libpais_<name>.so from patched temp copies of the sources."""
+import os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "pais_mvs_amd", "csrc")
+OUT = os.path.join(SRC, "variants")
+VARS = {
+    "base": [],
+    "noload": [("r0[u] = load_pair(base[u] + off[u]);", "r0[u] = off[u] & 0xffffu;"),
+               ("r1[u] = load_pair(base[u] + (off[u] + cwv[u]));", "r1[u] = (off[u] >> 3) & 0xffffu;")],
+    "nodiv": [("const double r = 1.0 / (w[0] * w[G - 1]);", "const double r = __builtin_amdgcn_rcp(w[0] * w[G - 1]);")],
+    "noexp": [("if (useDiff) weight *= det_exp_bf(-(sad * sad) * invDiffW);", "if (useDiff) weight *= (1.0 - (sad * sad) * invDiffW);")],
+    "waves5": [("#define PAIS_ITER_BOUNDS __launch_bounds__(64, 4)", "#define PAIS_ITER_BOUNDS __launch_bounds__(64, 5)")],
+    "waves3": [("#define PAIS_ITER_BOUNDS __launch_bounds__(64, 4)", "#define PAIS_ITER_BOUNDS __launch_bounds__(64, 3)")],
+    "nolds_acc": [("pa[64] = act ? (w0 + weight) : w0;", "if (step == 99) pa[64] = act ? (w0 + weight) : w0;"),
+                  ("pa[0] = act ? fma(weight, sad, f0) : f0;", "if (step == 99) pa[0] = act ? fma(weight, sad, f0) : f0;")],
+}
+def main(names):
+    os.makedirs(OUT, exist_ok=True)
+    for name in names:
+        tmp = "/tmp/sens/%s/x/y/csrc" % name
+        shutil.rmtree("/tmp/sens/%s" % name, ignore_errors=True)
+        os.makedirs(tmp)
+        for f in os.listdir(SRC):
+            if f.endswith((".hip", ".hpp", ".h")):
+                shutil.copy(os.path.join(SRC, f), tmp)
+        shutil.copytree(os.path.join(ROOT, "include"), "/tmp/sens/%s/x/include" % name)
+        p = os.path.join(tmp, "pais_kernels.hip")
+        s = open(p).read()
+        for a, b in VARS[name]:
+            assert a in s, (name, a)
+            s = s.replace(a, b)
+        open(p, "w").write(s)
+        so = os.path.join(OUT, "libpais_%s.so" % name)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unused-result"] + [os.path.join(tmp, f) for f in ("pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip")] + ["-o", so])
+        print("built", so)
+if __name__ == "__main__":
+    main(sys.argv[1:] or list(VARS))

@@ -7,6 +7,14 @@
 
 extern "C" {
 double shim_exp(double x) { return pais::det_exp(x); }
+double shim_exp_bf(double x) { return pais::det_exp_bf(x); }
+// number of inputs where the branch-free statement differs in any bit from det_exp (NaN payloads compared as bits)
+long shim_exp_bf_mismatches(const double *x, long n)
+{
+    long bad = 0;
+    for (long i = 0; i < n; ++i) bad += pais::d2u(pais::det_exp_bf(x[i])) != pais::d2u(pais::det_exp(x[i]));
+    return bad;
+}
 double shim_sin(double x) { return pais::det_sin(x); }
 double shim_cos(double x) { return pais::det_cos(x); }
 unsigned shim_rand31(unsigned long long seed, unsigned long long key, unsigned run, unsigned k) { return pais::rand31(seed, key, run, k); }

@@ -22,7 +22,9 @@ def shim():
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
     S = C.CDLL(so)
-    for n in ("shim_exp", "shim_sin", "shim_cos"):
+    S.shim_exp_bf_mismatches.restype = C.c_long
+    S.shim_exp_bf_mismatches.argtypes = [C.POINTER(C.c_double), C.c_long]
+    for n in ("shim_exp", "shim_exp_bf", "shim_sin", "shim_cos"):
         getattr(S, n).restype = C.c_double
         getattr(S, n).argtypes = [C.c_double]
     S.shim_rand31.restype = C.c_uint32
@@ -59,6 +61,29 @@ def test_detmath_accuracy_and_agreement(shim):
     assert shim.shim_exp(float("-inf")) == 0.0 and shim.shim_exp(float("inf")) == float("inf")
     assert math.isnan(shim.shim_exp(float("nan"))) and math.isnan(shim.shim_sin(float("inf")))
     assert shim.shim_exp(-800.0) == 0.0 and shim.shim_exp(710.0) == float("inf")
+
+
+def test_branch_free_exp_is_bit_identical(shim):
+    """det_exp_bf (what the cost kernel calls) == det_exp for every input: dense random sweeps, every fdlibm
+    threshold with its neighbours, the high-word band edges, specials."""
+    rng = np.random.default_rng(7)
+    ln2 = math.log(2)
+    parts = [rng.uniform(-60, 0, 2_000_000), rng.uniform(-1.2, 1.2, 2_000_000), rng.uniform(-800, 800, 500_000),
+             -np.exp(rng.uniform(-80, 7, 500_000)), np.exp(rng.uniform(-80, 7, 200_000))]
+    edges = []
+    for hw in (0x3fd62e42, 0x3fd62e43, 0x3FF0A2B1, 0x3FF0A2B2, 0x3e300000, 0x3e2fffff, 0x4085E000, 0x4085DFFF, 0x40862E42,
+               0x40862E41, 0x7ff00000, 0x7fefffff, 0x00100000, 0x000fffff, 0):
+        for lo in (0, 1, 0x7fffffff, 0xffffffff, 0x80000000):
+            for sign in (0, 1 << 63):
+                edges.append(np.frombuffer(np.uint64(sign | (hw << 32) | lo).tobytes(), dtype=np.float64)[0])
+    for v in (0.5 * ln2, 1.5 * ln2, 708.3964, 709.78, 745.13, 700.0):
+        for s_ in (1, -1):
+            e = np.float64(s_ * v)
+            edges += [e, np.nextafter(e, np.inf), np.nextafter(e, -np.inf)]
+    edges += [np.nan, np.inf, -np.inf, 0.0, -0.0]
+    xs = np.ascontiguousarray(np.concatenate(parts + [np.array(edges, dtype=np.float64)]))
+    bad = shim.shim_exp_bf_mismatches(xs.ctypes.data_as(C.POINTER(C.c_double)), len(xs))
+    assert bad == 0, bad
 
 
 def test_rng_stream_identical(shim):
