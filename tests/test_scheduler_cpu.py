@@ -55,10 +55,12 @@ def _oracle_records(S, cands_ptr, n, is_seed):
     return out
 
 
-def _run_product_with_oracle_records(cfg, scene, B, max_rounds):
+def _run_product_with_oracle_records(cfg, scene, B, max_rounds, thin=None):
     from pais_mvs_amd.mvs import MVS
     S = common.oracle_scene(cfg, scene)
     m = MVS(cfg, scene.cameras, device=-1, seed=42)
+    if thin is not None:
+        m.set_thin_front(thin)
     for X, vis in scene.seeds:
         m.add_seed(X, vis)
     cands, n = m.seed_begin()
@@ -79,7 +81,7 @@ def _run_product_with_oracle_records(cfg, scene, B, max_rounds):
     return m
 
 
-def _run_oracle(cfg, scene, B, max_rounds):
+def _run_oracle(cfg, scene, B, max_rounds, thin=None):
     from oracle import po
     S = common.oracle_scene(cfg, scene)
     L = po.lib()
@@ -87,6 +89,8 @@ def _run_oracle(cfg, scene, B, max_rounds):
     for X, vis in scene.seeds:
         L.po_mvs_add_seed(mo, po.darr(X), len(vis), po.iarr(vis))
     L.po_mvs_refine_seed_patches(mo)
+    if thin is not None:
+        L.po_mvs_set_thin_front(mo, thin)
     L.po_mvs_expansion_patches(mo, B, max_rounds, 1)
     pats = []
     for i in range(L.po_mvs_num_slots(mo)):
@@ -99,12 +103,14 @@ def _run_oracle(cfg, scene, B, max_rounds):
     return pats, calls, S
 
 
-@pytest.mark.parametrize("B,max_rounds", [(1, 60), (8, 25)])
-def test_scheduler_reproduces_oracle_rounds(pawn_small, B, max_rounds):
+# thin: the thin-front threshold of the round rule (None = the shared default, 0 = one camera slot per round
+# always, 3 = switches between both kinds of round with B = 8, 10**6 = whole parents always)
+@pytest.mark.parametrize("B,max_rounds,thin", [(1, 60, None), (8, 25, None), (1, 60, 0), (8, 25, 0), (8, 25, 3), (8, 12, 10 ** 6)])
+def test_scheduler_reproduces_oracle_rounds(pawn_small, B, max_rounds, thin):
     from pais_mvs_amd.config import readme_config
     cfg = readme_config(particleNum=6, maxIteration=8)   # small swarm: this test is about the scheduler
-    want, oracle_calls, _S = _run_oracle(cfg, pawn_small, B, max_rounds)
-    m = _run_product_with_oracle_records(cfg, pawn_small, B, max_rounds)
+    want, oracle_calls, _S = _run_oracle(cfg, pawn_small, B, max_rounds, thin)
+    m = _run_product_with_oracle_records(cfg, pawn_small, B, max_rounds, thin)
     got = [(list(p.center[:]), list(p.normal[:]), p.cams(), p.fitness, p.priority) for p in m.patches()]
     assert len(got) == len(want) and len(got) > len(pawn_small.seeds) // 2
     for a, b in zip(got, want):
@@ -114,3 +120,13 @@ def test_scheduler_reproduces_oracle_rounds(pawn_small, B, max_rounds):
     assert st.candidates_effective + st.seeds_refined == oracle_calls
     assert st.candidates_refined >= st.candidates_effective
     m.close()
+
+
+def test_one_parent_per_round_is_the_reference_order_for_any_thin_front(pawn_small):
+    """B = 1: taking a parent's camera slots one round at a time or all in one round is the same sequential
+    loop (mvs.cpp:529-563), so the cloud must not depend on the thin-front threshold."""
+    from pais_mvs_amd.config import readme_config
+    cfg = readme_config(particleNum=6, maxIteration=8)
+    a, calls_a, _ = _run_oracle(cfg, pawn_small, 1, 0, 0)
+    b, calls_b, _ = _run_oracle(cfg, pawn_small, 1, 0, 64)
+    assert a == b and calls_a == calls_b and len(a) > len(pawn_small.seeds)
