@@ -116,7 +116,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    os.environ.setdefault("PAIS_FINE_TIMING", "1")   # HIP events around every k_pso_eval launch
     from pais_mvs_amd import _lib
     from pais_mvs_amd.mvs import MVS
     from pais_mvs_amd import distributed as D
@@ -165,18 +164,27 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # Roofline leg (not part of `value`): ONE more step of the same workload with every k_pso_iter launch
+    # bracketed by HIP events on the stream it is launched on (two overlapping sub-streams by default).
+    m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 1)
+    m.L.pais_ctx_set_fine_timing(m.ctx_handle, 1)
+    step()
+    fence()
+    m.L.pais_ctx_set_fine_timing(m.ctx_handle, 0)
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
 
     if rank == 0:
-        S2 = cfg.patchSize ** 2
-        # k_pso_eval is timed launch by launch with HIP events when the PSO pipeline runs on one stream
-        # (PAIS_PSO_STREAMS=1); with the default 2 overlapping streams individual launches overlap, so the
-        # span of the whole PSO pass (k_pso_init + every k_pso_eval/k_pso_step of all slices) is used instead
-        split = ks.eval_launches > 0 and ks.eval_ms > 0
-        k_ms = ks.eval_ms if split else ks.pso_ms
-        k_launches = ks.eval_launches if ks.eval_launches > 0 else ks.pso_launches
-        k_name = "k_pso_eval" if split else ("k_pso_eval (span of the overlapped PSO pass)" if ks.eval_launches > 0 else "k_pso")
+        k_ms = ks.eval_ms                      # sum of the launch durations of the dominant kernel
+        k_launches = max(int(ks.eval_launches), 1)
         pso_gbs = (ks.pso_algorithmic_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        traffic = None
+        tnote = "no PMC summary found under profiles/"
+        try:   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same command
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pj["k_pso_iter_hbm_read_bytes_per_launch"]
+            tnote = pj.get("note", "")
+        except Exception:
+            pass
         out = {
             "metric": "refined+expanded patches/sec",
             "value": units / dt,
@@ -197,15 +205,20 @@ def main():
                        "rounds_per_step": int(last.rounds) if last else 0,
                        "pso_evals_per_patch": evals_eff / max(units, 1),
                        "parallelism": "candidates sharded over %d GPU(s), 1 all-gather per round" % world},
-            "roofline": {"bound": "hbm", "kernel": k_name, "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": pso_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "launches": int(k_launches), "avg_launch_ms": k_ms / max(k_launches, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_pso_iter", "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": pso_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches": k_launches, "avg_launch_ms": k_ms / k_launches,
+                         "algorithmic_bytes_per_launch": ks.pso_algorithmic_bytes / k_launches,
                          "evals": int(ks.pso_evals),
                          "algorithmic_bytes_per_eval": (ks.pso_algorithmic_bytes / ks.pso_evals) if ks.pso_evals else 0,
-                         "note": "rank-0 kernel; bytes = S^2*(4K+1+8[dist]+8[grad]) per cost evaluation (SURVEY 8d)"},
-            "kernel_ms": {"pso_pass": ks.pso_ms, "k_pso_eval": ks.eval_ms, "k_begin": ks.begin_ms, "k_after": ks.after_ms,
-                          "host_enumerate": last.host_enumerate_ms if last else 0,
-                          "host_commit": last.host_commit_ms if last else 0},
+                         "note": "rank-0, one extra instrumented step; bytes = S^2*(4K+1+8[dist]+8[grad]) per cost evaluation "
+                                 "(SURVEY 8d) x evaluations of the launch; durations from HIP events on the launching sub-stream "
+                                 "(launches of the two sub-streams overlap).  The kernel is FP64-VALU bound, not HBM bound "
+                                 "(DESIGN.md 4): the window taps hit L1/L2.  traffic: " + tnote},
+            "kernel_ms_per_step": {"pso_pass": ks.pso_ms, "k_pso_iter_sum_of_launches": ks.eval_ms, "k_begin": ks.begin_ms,
+                                   "k_after": ks.after_ms,
+                                   "host_enumerate": last.host_enumerate_ms if last else 0,
+                                   "host_commit": last.host_commit_ms if last else 0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, scene, args.cpu_seconds)

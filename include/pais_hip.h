@@ -207,6 +207,10 @@ typedef struct pais_kernel_stats {
     int64_t  eval_launches;
 } pais_kernel_stats;
 int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
+/* on != 0: bracket every cost-evaluation launch (k_pso_iter / k_fitness) with HIP events on the stream it is
+ * launched on; their durations accumulate in eval_ms / eval_launches.  Off by default (two event records per
+ * launch are not free); the environment variable PAIS_FINE_TIMING=1 turns it on at context creation. */
+int  pais_ctx_set_fine_timing(pais_ctx *ctx, int on);
 
 /* Deterministic stream helpers (shared by host scheduler and tests). */
 uint32_t pais_rand31(uint64_t seed, uint64_t key, uint32_t run, uint32_t k);

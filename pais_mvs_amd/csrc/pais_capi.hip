@@ -305,6 +305,13 @@ extern "C" int pais_ctx_synchronize(pais_ctx *ctx)
 
 // ------------------------------------------------------------ fitness batch --
 static int get_event_pair(pais_ctx *ctx, EventPair &p);
+extern "C" int pais_ctx_set_fine_timing(pais_ctx *ctx, int on)
+{
+    if (!ctx) return fail_msg("pais_ctx_set_fine_timing: bad argument");
+    ctx->fineTiming = on != 0;
+    return 0;
+}
+
 extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_state *states, int n_evals,
                                   const int32_t *state_index, const double *particles, double *out)
 {
@@ -511,7 +518,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                     }
                     for (int it = 0; it <= maxIt; ++it) {
                         EventPair ee;
-                        const bool timeIt = ctx->fineTiming && S == 1;
+                        const bool timeIt = ctx->fineTiming; // events on the stream the kernel is launched on
                         if (timeIt) {
                             if (get_event_pair(ctx, ee)) return -2;
                             HIPCHK(hipEventRecord(ee.a, st));

@@ -34,6 +34,7 @@ def _bind(L):
     L.pais_mvs_add_seed.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32)]
     L.pais_mvs_refine_seed_patches.argtypes = [vp]
     L.pais_mvs_expansion_patches.argtypes = [vp, C.c_int, C.c_int]
+    L.pais_mvs_set_thin_front.argtypes = [vp, C.c_int]
     L.pais_mvs_seed_begin.argtypes = [vp, C.POINTER(C.POINTER(_lib.Candidate)), C.POINTER(C.c_int)]
     L.pais_mvs_seed_commit.argtypes = [vp, C.POINTER(_lib.PatchResult), C.c_int]
     L.pais_mvs_expansion_begin.argtypes = [vp]

@@ -1,0 +1,52 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun): produces the rocprofv3 evidence that is then copied into profiles/.
+#   bash scripts/make_profiles.sh <tag>       e.g. r01d
+# 1. kernel-trace + stats of the default bench command   -> gpurun_out/<tag>_kernel_stats.txt, <tag>_bench_under_rocprof.json
+# 2. PMC passes (kernel-trace only, one rocprofv3 run per counter set) of `bench.py --steps 1 --warmup 0`
+#                                                          -> gpurun_out/<tag>_pmc.txt, <tag>_pmc_traffic.json
+tag=${1:-r01x}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/prof_$tag
+rm -rf $out; mkdir -p $out
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 2 --warmup 1 --cpu-seconds 4 > $out/bench.log 2>&1
+grep '^{"metric"' $out/bench.log | tail -1 > gpurun_out/${tag}_bench_under_rocprof.json
+python scripts/rocprof_summary.py $(ls $out/kt/*.db | head -1) gpurun_out/${tag}_kernel_stats.txt gpurun_out/${tag}_bench_under_rocprof.json "python bench.py --steps 2 --warmup 1 ($tag)" > /dev/null
+i=0
+: > gpurun_out/${tag}_pmc.txt
+echo "# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of: python bench.py --steps 1 --warmup 0 --no-cpu-baseline" >> gpurun_out/${tag}_pmc.txt
+echo "# (1 timed step + the instrumented roofline step = 2 reconstructions).  Sums over all dispatches of a kernel." >> gpurun_out/${tag}_pmc.txt
+for set in \
+ "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+ "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
+ "FETCH_SIZE" \
+ "WRITE_SIZE" ; do
+  i=$((i+1))
+  timeout 900 rocprofv3 --kernel-trace --pmc $set -d $out/p$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/p$i.log 2>&1
+  python - >> gpurun_out/${tag}_pmc.txt << PY
+import sqlite3,glob,json
+f=glob.glob("$out/p$i/*.db")
+print("\n## pass $i: $set")
+if f:
+    cur=sqlite3.connect(f[0]).cursor()
+    sums={}
+    for k,c,v,n in cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"):
+        kn=k.split("(")[0].replace("void ","")
+        print("%-18s %-28s %16.6g (%d dispatches)"%(kn[:18],c,v,n))
+        sums[(kn,c)]=(v,n)
+    for n_,c_,t_ in cur.execute("select name,count(*),sum(duration)/1e6 from kernels group by name"):
+        print("   dur_ms %-22s calls %6d total %.3f"%(n_.split("(")[0].replace("void ","")[:22],c_,t_))
+    if "$set"=="FETCH_SIZE":
+        tot=sum(v for (k,c),(v,n) in sums.items() if k.startswith("k_pso_iter")); nl=sum(n for (k,c),(v,n) in sums.items() if k.startswith("k_pso_iter"))
+        if nl:
+            raw=tot*1024.0/nl
+            json.dump({"k_pso_iter_hbm_read_bytes_per_launch": 2.0*raw, "raw_fetch_size_bytes_per_launch": raw, "launches": nl,
+                       "note": "rocprofv3 --pmc FETCH_SIZE (KiB) summed over the k_pso_iter dispatches of 'bench.py --steps 1 --warmup 0' / launches, x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated for wide coalesced reads only, so an upper bound for these 2-byte gathers)"},
+                      open("gpurun_out/${tag}_pmc_traffic.json","w"))
+else:
+    print("no db (see log)")
+PY
+done
+rm -rf $out/kt $out/p1 $out/p2 $out/p3 $out/p4   # raw dbs stay on the box (gpurun_out is capped at 64 MiB)
+cat gpurun_out/${tag}_kernel_stats.txt | head -30
+cat gpurun_out/${tag}_pmc.txt | grep -E "k_pso_iter|##" | head -60
+cat gpurun_out/${tag}_pmc_traffic.json

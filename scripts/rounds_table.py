@@ -1,0 +1,20 @@
+"""Per-round table (candidates, duration, kernel counts) of the second reconstruction in a rocprofv3 kernel-trace db."""
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
+rows = [(r[0].split('(')[0], r[1], r[2], r[3], r[4]) for r in cur.execute("select name,start,end,grid_x,queue_id from kernels order by start")]
+begins = [i for i, r in enumerate(rows) if r[0].startswith('k_begin')]
+# the second half of the k_begin launches belongs to the timed step (warmup 1, steps 1)
+half = len(begins) // 2
+tot = 0
+print("round      n   dur_us  iter_kernels  iter_us  after_us  streams  kinds")
+for k, (a, b) in enumerate(zip(begins[half:], begins[half + 1:] + [len(rows)])):
+    seg = rows[a:b]
+    n = seg[0][3] // 64
+    dur = ((rows[b][1] if b < len(rows) else seg[-1][2]) - seg[0][1]) / 1e3
+    it = [r for r in seg if 'k_pso_iter' in r[0]]
+    af = sum((r[2] - r[1]) for r in seg if r[0] == 'k_after') / 1e3
+    itus = sum((r[2] - r[1]) for r in it) / 1e3
+    kinds = sorted(set(r[0].replace('void ', '') for r in it))
+    tot += dur
+    print("%3d %8d %8.0f %6d %10.0f %8.0f %6d   %s" % (k, n, dur, len(it), itus, af, len(set(r[4] for r in it)), ",".join(kinds)))
+print("total ms %.1f" % (tot / 1e3))
