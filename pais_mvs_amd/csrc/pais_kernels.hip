@@ -147,6 +147,9 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
                                           int c0, double x, double y, uint32_t &badBits, double &sum)
 {
     static_assert(G == 1 || G == 2, "kernel arithmetic is defined for camera pairs + one leftover");
+    // opaque re-definition of the pixel coordinates per group: without it the register allocator splits the live
+    // ranges of x and y around the camera loop into one copy per use (20 v_mov + 16 VGPRs per window step)
+    asm volatile("" : "+v"(x), "+v"(y));
     double bx[G], by[G], nx[G], ny[G], w[G], rw[G];
     const uint8_t *base[G];
     uint32_t off[G], cwv[G];
