@@ -55,7 +55,9 @@ struct pais_ctx {
     size_t recCap = 0;
     double *d_hp = nullptr;
     size_t hpBytes = 0;
-    int *d_counters = nullptr;          // [0] PSO work counter, [1] "needs another pass" count
+    int *d_counters = nullptr;          // [0] PSO work counter, [1] "needs another pass" count, [2] active-list length
+    int *d_active = nullptr;            // compacted indices of the candidates that run a PSO in the current pass
+    size_t activeCap = 0;
     unsigned long long *d_stat = nullptr; // [0] evals [1] evals*bytesPerPixel [2] patches [3] ncc tables [4] tables*K
     int *h_counters = nullptr;          // pinned
     unsigned char *d_psoStates = nullptr; // split pipeline: one PsoState block per candidate
@@ -269,7 +271,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
-    (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat);
+    (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active);
     (void)hipFree(ctx->d_states); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_particles); (void)hipFree(ctx->d_out);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -427,9 +429,17 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     HIPCHK(hipEventRecord(eb.b, ctx->stream));
     ctx->evBegin.push_back(eb);
 
+    if ((size_t)n > ctx->activeCap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_active);
+        ctx->d_active = nullptr;
+        ctx->activeCap = (size_t)n + (size_t)n / 2 + 64;
+        HIPCHK(hipMalloc(&ctx->d_active, sizeof(int) * ctx->activeCap));
+    }
+    int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
     const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
     for (int pass = 0; pass < maxPass; ++pass) {
-        HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 2, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 3, ctx->stream)); // [2]: length of the active list
         if (get_event_pair(ctx, ep)) return -2;
         HIPCHK(hipEventRecord(ep.a, ctx->stream));
         if (ctx->psoMode == 0) {
@@ -445,7 +455,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 HIPCHK(hipMalloc(&ctx->d_psoStates, ctx->psoStateBytes));
             }
             const int maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
-            HIPCHK(pais_launch::pso_split_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->stream));
+            HIPCHK(pais_launch::pso_split_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, ctx->d_counters + 2, ctx->stream));
             if (ctx->psoMode == 3) {
                 const size_t qi = pais_launch::pso_queue_ints(n, Nmax, maxIt);
                 if (qi > ctx->queueInts) {
@@ -494,17 +504,20 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 // (eval, step) x (maxIt+1) sequence on sub-stream s, so the step of one slice (a few
                 // waves, latency bound) overlaps the evaluations of the others and every evaluation
                 // launch fits into one residency pass of the GPU
-                int S = ctx->psoStreams;
-                const int minPer = ctx->psoMinPer; // slices smaller than this only add launch overhead
-                if (n < S * minPer) S = (n + minPer - 1) / minPer;
-                if (S < 1) S = 1;
                 const size_t SB = pais_launch::pso_split_state_bytes(Nmax);
                 // psoMode 4: one k_pso_iter launch per iteration (step folded into the evaluation waves);
                 // needs the swarm of a candidate in the lanes of one wave
                 const bool useIter = ctx->psoMode == 4 && Nmax <= 64;
+                // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
+                // its length is n at most in the first pass and exactly the "again" count afterwards
+                const int nRun = useIter ? (pass == 0 ? n : againCount) : n;
+                int S = ctx->psoStreams;
+                const int minPer = ctx->psoMinPer; // slices smaller than this only add launch overhead
+                if (nRun < S * minPer) S = (nRun + minPer - 1) / minPer;
+                if (S < 1) S = 1;
                 HIPCHK(hipEventRecord(ctx->forkEv, ctx->stream));
                 for (int sI = 0; sI < S; ++sI) {
-                    const int lo = (int)((long)n * sI / S), hi = (int)((long)n * (sI + 1) / S);
+                    const int lo = (int)((long)nRun * sI / S), hi = (int)((long)nRun * (sI + 1) / S);
                     if (hi <= lo) continue;
                     hipStream_t st = (S == 1) ? ctx->stream : ctx->sub[sI];
                     if (S > 1) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
@@ -524,7 +537,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                             HIPCHK(hipEventRecord(ee.a, st));
                         }
                         if (useIter)
-                            HIPCHK(pais_launch::pso_iter(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, it, 0, parts, st));
+                            HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, it, 0, parts, st));
                         else
                             HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0, st));
                         if (timeIt) {
@@ -535,7 +548,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                         if (!useIter) HIPCHK(pais_launch::pso_split_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
                     }
                     // the launch after the last possible iteration only ends the runs still active
-                    if (useIter) HIPCHK(pais_launch::pso_iter(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, maxIt + 1, 1, parts, st));
+                    if (useIter) HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, maxIt + 1, 1, parts, st));
                     if (S > 1) {
                         HIPCHK(hipEventRecord(ctx->subDone[sI], st));
                         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI], 0));
@@ -555,6 +568,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ctx->h_counters[1] == 0) break;
+        againCount = ctx->h_counters[1];
     }
     return 0;
 }

@@ -1051,8 +1051,10 @@ __device__ __forceinline__ PsoArrays pso_arrays(unsigned char *base, int Nmax, i
     return a;
 }
 
+// activeList / activeCount (optional): compacted indices of the candidates that run a PSO in this pass, so that
+// the per-iteration launches create waves only for them (k_pso_iter)
 __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_result *recs, int n, unsigned char *states,
-                                                 int Nmax)
+                                                 int Nmax, int *activeList, int *activeCount)
 {
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
@@ -1109,6 +1111,7 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
             hd->refCam = P->ref_cam;
             hd->LOD = P->lod;
             hd->K = P->num_cam;
+            if (activeList) activeList[atomicAdd(activeCount, 1)] = c;
         }
         for (int k = lane; k < P->num_cam; k += 64) hd->camIdx[k] = P->cam_idx[k];
         // initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
@@ -1279,8 +1282,10 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 
 // launch L = 0: cost of the initial swarm.  L >= 1: step (L-1) + cost of the moved particle.  finishOnly: one
 // wave per candidate that only replays the step (the launch after the last possible iteration: every run ends).
+// Tasks: positions [listLo, min(listHi, *activeCount)) of the active list written by k_pso_init.
 template <int nparts>
-__global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+__global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
+                                            const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1295,9 +1300,11 @@ __global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, 
     // stores the moved particle, each part stores its sub-accumulators; the consumer -- the step replay of
     // the next launch -- adds them in the canonical order.
     const int per = finishOnly ? 1 : Nmax * nparts;
-    const int total = n * per;
+    const int nAct = *activeCount;
+    const int total = ((listHi < nAct ? listHi : nAct) - listLo) * per;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const int c = t / per, ip = t - c * per;
+        const int lp = t / per, ip = t - lp * per;
+        const int c = activeList[listLo + lp];
         const int i = ip / nparts, part = ip - i * nparts;
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         if (!hd->active || i >= hd->N) continue;
@@ -1940,10 +1947,10 @@ size_t pso_lds(int W, int Kmax, int Nmax) { return pso_lds_bytes(W, Kmax, Nmax);
 
 size_t pso_split_state_bytes(int Nmax) { return pso_state_bytes(Nmax); }
 hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax,
-                          hipStream_t stream)
+                          int *activeList, int *activeCount, hipStream_t stream)
 {
     int grid = n < 65536 ? n : 65536;
-    hipLaunchKernelGGL(k_pso_init, dim3(grid), dim3(64), 0, stream, sc, recs, n, states, Nmax);
+    hipLaunchKernelGGL(k_pso_init, dim3(grid), dim3(64), 0, stream, sc, recs, n, states, Nmax, activeList, activeCount);
     return hipGetLastError();
 }
 hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
@@ -1961,9 +1968,11 @@ hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int 
     hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, fuseStep);
     return hipGetLastError();
 }
-hipError_t pso_iter(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
-                    unsigned long long *stat, int L, int finishOnly, int nparts, hipStream_t stream)
+hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
+                    int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
+                    int nparts, hipStream_t stream)
 {
+    const int n = listHi - listLo;
     size_t lds = fitness_lds_bytes(Kmax);
     static bool attrSet = false;
     if (lds > 64 * 1024 && !attrSet) {
@@ -1976,11 +1985,14 @@ hipError_t pso_iter(const DevScene &sc, unsigned char *states, int n, int Nmax, 
     long total = (long)n * (finishOnly ? 1 : Nmax * nparts);
     int grid = (int)(total < 262144 ? total : 262144);
     if (nparts == 4)
-        hipLaunchKernelGGL(k_pso_iter<4>, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, L, finishOnly);
+        hipLaunchKernelGGL(k_pso_iter<4>, dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L,
+                           finishOnly);
     else if (nparts == 2)
-        hipLaunchKernelGGL(k_pso_iter<2>, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, L, finishOnly);
+        hipLaunchKernelGGL(k_pso_iter<2>, dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L,
+                           finishOnly);
     else
-        hipLaunchKernelGGL(k_pso_iter<1>, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, L, finishOnly);
+        hipLaunchKernelGGL(k_pso_iter<1>, dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L,
+                           finishOnly);
     return hipGetLastError();
 }
 size_t pso_queue_ints(int n, int Nmax, int maxIt) { return sizeof(PsoQueue) / sizeof(int) + (size_t)n * Nmax * (size_t)(maxIt + 2); }
