@@ -603,29 +603,37 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
     if (s->detMath) {
         /* "kernel arithmetic" (DESIGN.md 5.3): the same quantities as the literal branch
          * below, evaluated the way the HIP kernel does -- homography rows with fma, one
-         * reciprocal per tap, bilinear as two fma lerps, mean/SAD scaled by 1/K, fdlibm exp.
+         * reciprocal per camera group, bilinear as three fma lerps, mean/SAD scaled by 1/K, fdlibm exp.
          * Differs from the literal branch in the last bits only. */
         const double invK = 1.0 / (double)camNum, invDiffW = 1.0 / s->cfg.diffWeighting;
         double sum = 0;
-        for (int i0 = 0; i0 < camNum; i0 += 2) {
-            /* cameras are handled in pairs with ONE reciprocal per pair (1/w0 = w1/(w0 w1), 1/w1 = w0/(w0 w1));
-             * an odd camera count leaves a single camera with its own reciprocal */
-            const int g = (i0 + 1 < camNum) ? 2 : 1;
-            double ww[2], nx[2], ny[2], rw[2];
+        for (int i0 = 0; i0 < camNum;) {
+            /* cameras are handled in groups with ONE reciprocal per group (batch inversion): pairs, and one
+             * triple at the end when the camera count is odd (a single camera only for camNum == 1) */
+            const int left = camNum - i0;
+            const int g = (left >= 4 || left == 2) ? 2 : (left == 3 ? 3 : 1);
+            double ww[3], nx[3], ny[3], rw[3];
             for (int u = 0; u < g; ++u) {
                 const double *Hi = f->H + 9 * (i0 + u);
                 ww[u] = fma(Hi[7], y, fma(Hi[6], x, Hi[8]));
                 nx[u] = fma(Hi[1], y, fma(Hi[0], x, Hi[2]));
                 ny[u] = fma(Hi[4], y, fma(Hi[3], x, Hi[5]));
             }
-            if (g == 2) {
+            if (g == 3) {
+                const double p01 = ww[0] * ww[1];
+                const double r = 1.0 / (p01 * ww[2]);
+                rw[2] = r * p01;
+                const double r01 = r * ww[2];
+                rw[0] = r01 * ww[1];
+                rw[1] = r01 * ww[0];
+            } else if (g == 2) {
                 const double r = 1.0 / (ww[0] * ww[1]);
                 rw[0] = r * ww[1];
                 rw[1] = r * ww[0];
             } else {
                 rw[0] = 1.0 / ww[0];
             }
-            /* the kernel flags every bad tap of the pair before giving up: same result, DBL_MAX */
+            /* the kernel flags every bad tap of the group before giving up: same result, DBL_MAX */
             for (int u = 0; u < g; ++u) {
                 const po_camera *cam = &s->cams[patch->camIdx[i0 + u]];
                 const int cols = cam->width[LOD], rows = cam->height[LOD];
@@ -640,13 +648,14 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
                 const double jx = nx[u] * rw[u], jy = ny[u] * rw[u];
                 const int qx = (int)jx, qy = (int)jy;
                 const double bx = jx - (double)qx, by = jy - (double)qy;
-                const double ax = 1.0 - bx, ay = 1.0 - by;
                 const uint8_t *r0 = img + (size_t)qy * cols + qx, *r1 = r0 + cols;
-                const double t0 = fma((double)r0[1], bx, (double)r0[0] * ax);
-                const double t1 = fma((double)r1[1], bx, (double)r1[0] * ax);
-                c[i] = fma(t1, by, t0 * ay);
+                /* three lerps a + f (b - a); the pixel differences are exact */
+                const double t0 = fma(bx, (double)((int)r0[1] - (int)r0[0]), (double)r0[0]);
+                const double t1 = fma(bx, (double)((int)r1[1] - (int)r1[0]), (double)r1[0]);
+                c[i] = fma(by, t1 - t0, t0);
                 sum += c[i];
             }
+            i0 += g;
         }
         mean = sum * invK;
         for (int i = 0; i < camNum; i++) avgSad += fabs(c[i] - mean);

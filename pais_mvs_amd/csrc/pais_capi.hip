@@ -46,6 +46,7 @@ struct pais_ctx {
     DevScene sc;
     DevCamera *d_cams = nullptr;
     uint8_t *d_img = nullptr;
+    float *d_imgF = nullptr;            // float copy of d_img (element offsets identical)
     double *d_edge = nullptr;
     double *d_gauss = nullptr;
     size_t imgBytes = 0, edgeBytes = 0;
@@ -195,6 +196,12 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     HIPCHK(hipMalloc(&ctx->d_img, imgBytes));
     HIPCHK(hipMemcpy(ctx->d_img, himg.data(), imgBytes, hipMemcpyHostToDevice));
     ctx->imgBytes = imgBytes;
+    {
+        std::vector<float> hf(imgBytes);
+        for (size_t i = 0; i < imgBytes; ++i) hf[i] = (float)himg[i];
+        HIPCHK(hipMalloc(&ctx->d_imgF, imgBytes * sizeof(float)));
+        HIPCHK(hipMemcpy(ctx->d_imgF, hf.data(), imgBytes * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (wantEdge && edgeBytes) {
         HIPCHK(hipMalloc(&ctx->d_edge, edgeBytes));
         for (int c = 0; c < num_cams; ++c) {
@@ -231,6 +238,7 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     HIPCHK(hipMemcpy(ctx->d_cams, hc.data(), sizeof(DevCamera) * (size_t)num_cams, hipMemcpyHostToDevice));
     ctx->sc.cams = ctx->d_cams;
     ctx->sc.imgBlob = ctx->d_img;
+    ctx->sc.imgF = ctx->d_imgF;
     ctx->sc.edgeBlob = ctx->d_edge;
 
     HIPCHK(hipMalloc(&ctx->d_counters, sizeof(int) * 4));
@@ -269,7 +277,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evEval); freeEv(ctx->evFree);
     (void)hipFree(ctx->d_psoStates);
     (void)hipFree(ctx->d_queue);
-    (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
+    (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_imgF); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
     (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active);
     (void)hipFree(ctx->d_states); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_particles); (void)hipFree(ctx->d_out);

@@ -13,6 +13,8 @@
 // HBM layout: one DevCamera per camera in a dense array;
 // every pyramid level of every camera repacked row-major with stride == width
 // into one byte blob (levels 256-byte aligned), edge levels likewise as doubles.
+// The cost kernel's bilinear taps read a float copy of the byte blob (imgF): two adjacent pixels come
+// back with one 8-byte load and need no unpacking (4 fewer VALU instructions per tap).
 struct DevCamera {
     double KR[9], KT[3], R[9], T[3], C[3], optN[3], focal[2], pp[2];
     int maxLOD;
@@ -28,6 +30,7 @@ struct DevScene {
     pais_config cfg;
     const DevCamera *cams;
     const uint8_t *imgBlob;
+    const float *imgF;   // the same pixels as floats, same element offsets (imgOff): what the cost taps read
     const double *edgeBlob;
     const double *gauss; // patchDistWeight, S*S, indexed [x*S + y] (mvs.cpp:104-109)
     double lodScale[PAIS_MAX_LEVELS]; // pow(lodRatio, LOD) (camera.cpp:157, patch.cpp:309)

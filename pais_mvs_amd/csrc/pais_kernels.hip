@@ -131,27 +131,28 @@ __device__ __forceinline__ int clamp_i32(int v, int lo, int hi)
     return r;
 }
 
-// two adjacent bytes with one (unaligned) 16-bit global load
-__device__ __forceinline__ uint32_t load_pair(const uint8_t *p)
+// two adjacent pixels of the float image with one 8-byte (4-byte aligned) global load
+struct PixPair { float a, b; };
+__device__ __forceinline__ PixPair load_pair(const float *p)
 {
-    uint16_t v;
-    __builtin_memcpy(&v, p, 2);
-    return (uint32_t)v;
+    PixPair v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
 }
 
-// G consecutive cameras of one window pixel: homography (fma), one reciprocal, bounds test,
-// two 16-bit row loads and the fma lerps.  No lane-dependent branches; loads of the G cameras
-// are independent so they overlap.
+// G consecutive cameras of one window pixel: homography (fma), ONE reciprocal for the group, bounds test,
+// two 8-byte row loads and three fma lerps.  No lane-dependent branches; loads of the G cameras are
+// independent so they overlap.  Groups: pairs, and one triple when the camera count is odd (K = 1: single).
 template <int G>
 __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
                                           int c0, double x, double y, uint32_t &badBits, double &sum)
 {
-    static_assert(G == 1 || G == 2, "kernel arithmetic is defined for camera pairs + one leftover");
+    static_assert(G >= 1 && G <= 3, "kernel arithmetic is defined for groups of 1, 2, 3 cameras");
     // opaque re-definition of the pixel coordinates per group: without it the register allocator splits the live
     // ranges of x and y around the camera loop into one copy per use (20 v_mov + 16 VGPRs per window step)
     asm volatile("" : "+v"(x), "+v"(y));
     double bx[G], by[G], nx[G], ny[G], w[G], rw[G];
-    const uint8_t *base[G];
+    const float *base[G];
     uint32_t off[G], cwv[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -160,9 +161,16 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
         nx[u] = fma(H[1], y, fma(H[0], x, H[2]));
         ny[u] = fma(H[4], y, fma(H[3], x, H[5]));
     }
-    if (G == 2) {
-        // one reciprocal for the pair (Montgomery batch inversion): 1/w0 = w1 * 1/(w0 w1), 1/w1 = w0 * 1/(w0 w1).
-        // A zero / non-finite w poisons both, which is right: any overflowing tap makes the whole call DBL_MAX.
+    // one reciprocal per group (Montgomery batch inversion).  A zero / non-finite w poisons the whole group, which
+    // is right: any overflowing tap makes the whole call DBL_MAX.
+    if (G == 3) {
+        const double p01 = w[0] * w[1];
+        const double r = 1.0 / (p01 * w[G - 1]);
+        rw[G - 1] = r * p01;           // 1/w2
+        const double r01 = r * w[G - 1]; // 1/(w0 w1)
+        rw[0] = r01 * w[1];
+        rw[G > 1 ? 1 : 0] = r01 * w[0];
+    } else if (G == 2) {
         const double r = 1.0 / (w[0] * w[G - 1]);
         rw[0] = r * w[G - 1];
         rw[G - 1] = r * w[0];
@@ -183,11 +191,11 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
         bx[u] = __builtin_amdgcn_fract(ix);
         by[u] = __builtin_amdgcn_fract(iy);
         const uint32_t cw = (uint32_t)cams[c].w;
-        base[u] = sc.imgBlob + cams[c].imgOff; // wave-uniform
+        base[u] = sc.imgF + cams[c].imgOff; // wave-uniform
         off[u] = (uint32_t)py * cw + (uint32_t)px;
         cwv[u] = cw;
     }
-    uint32_t r0[G], r1[G];
+    PixPair r0[G], r1[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         r0[u] = load_pair(base[u] + off[u]);
@@ -195,12 +203,12 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        const double i00 = (double)(r0[u] & 0xffu), i10 = (double)(r0[u] >> 8);
-        const double i01 = (double)(r1[u] & 0xffu), i11 = (double)(r1[u] >> 8);
-        const double ax = 1.0 - bx[u], ay = 1.0 - by[u];
-        const double t0 = fma(i10, bx[u], i00 * ax);
-        const double t1 = fma(i11, bx[u], i01 * ax);
-        const double col = fma(t1, by[u], t0 * ay);
+        // bilinear as three lerps a + f (b - a); the pixel differences are exact in float (integers < 2^24)
+        const double i00 = (double)r0[u].a, d0 = (double)(r0[u].b - r0[u].a);
+        const double i01 = (double)r1[u].a, d1 = (double)(r1[u].b - r1[u].a);
+        const double t0 = fma(bx[u], d0, i00);
+        const double t1 = fma(bx[u], d1, i01);
+        const double col = fma(by[u], t1 - t0, t0);
         myc[(c0 + u) * 64] = col;
         sum += col;
     }
@@ -212,8 +220,8 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 //   cbuf : this wave's LDS scratch, (K+8)*64 doubles (per-camera colour of the lane's pixel; rows K..K+7:
 //          the lane's 4 x (fitness, weight) sub-accumulators -- in LDS, not registers, to stay at 4 waves/SIMD)
 // Arithmetic ("kernel arithmetic"; mirrored bit for bit by the oracle's
-// detMath/treeSum mode): homography rows with fma, ONE reciprocal per tap, bilinear as
-// two fma lerps, mean/SAD scaled by 1/K, exp/sin/cos from pais_detmath.hpp, lane partial
+// detMath/treeSum mode): homography rows with fma, ONE reciprocal per camera group, bilinear as
+// three fma lerps a + f (b - a), mean/SAD scaled by 1/K, exp/sin/cos from pais_detmath.hpp, lane partial
 // sums in increasing pixel index followed by the wave64 xor butterfly.
 // Reduction shape (canonical, independent of how many waves share one evaluation): the 64-pixel steps of the
 // window are dealt round-robin to FOUR sub-accumulators (step mod 4); each is summed per lane over its steps,
@@ -307,8 +315,9 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
         uint32_t badBits = 0; // != 0: some tap of this pixel left [2, w-3) x [2, h-3)
         double sum = 0;
         int c0 = 0;
-        for (; c0 + 2 <= K; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // camera pairs
-        if (c0 < K) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);                  // odd leftover
+        for (; K - c0 >= 4 || K - c0 == 2; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
+        if (K - c0 == 3) tap_group<3>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
+        else if (K - c0 == 1) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // K == 1
         const bool act = valid && (refMask != 0);
         if (__any(act && badBits != 0)) return 1; // :1001 -- whole call
         const double mean = sum * invK;
