@@ -34,10 +34,13 @@ using namespace pais;
 #else
 #define PAIS_EVAL_BOUNDS __launch_bounds__(64)
 #endif
-// k_pso_iter / k_fitness: 4 waves per SIMD (<= 128 VGPRs) without spilling
-#define PAIS_ITER_BOUNDS __launch_bounds__(64, 4)
-// rows of 64 doubles in a wave's colour buffer: one per camera + the 8 lane accumulators of eval_fitness_parts
-#define PAIS_CBUF_ROWS(K) ((K) + 8)
+// k_pso_iter / k_fitness: 3 waves per SIMD (<= 168 VGPRs): two window pixels per lane are in flight (tap_group<G, 2>)
+// and the LDS scratch of a wave (~11 KB at 5 cameras) allows 3.75 waves per SIMD anyway; measured better than
+// 4 waves with spills
+#define PAIS_ITER_BOUNDS __launch_bounds__(64, 3)
+// rows of 64 doubles in a wave's colour buffer: two per camera (two window pixels per lane in flight) + the 8 lane
+// accumulators of eval_fitness_parts
+#define PAIS_CBUF_ROWS(K) (2 * (K) + 8)
 
 // --------------------------------------------------------------- helpers ---
 __device__ __forceinline__ void wave_sync()
@@ -140,84 +143,102 @@ __device__ __forceinline__ PixPair load_pair(const float *p)
     return v;
 }
 
-// G consecutive cameras of one window pixel: homography (fma), ONE reciprocal for the group, bounds test,
-// two 8-byte row loads and three fma lerps.  No lane-dependent branches; loads of the G cameras are
-// independent so they overlap.  Groups: pairs, and one triple when the camera count is odd (K = 1: single).
-template <int G>
+// G consecutive cameras of NS window pixels of this lane: homography (fma), ONE reciprocal per (group, pixel),
+// bounds test, two 8-byte row loads and three fma lerps per tap.  No lane-dependent branches; the loads of the
+// G x NS taps are independent so they overlap.  Groups: pairs, and one triple when the camera count is odd
+// (K = 1: single).  NS = 2: the kernel is bound by LDS bandwidth as much as by the VALU -- the homographies and
+// camera constants are wave-uniform values that every lane reads from LDS -- so each read serves two pixels.
+template <int G, int NS>
 __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
-                                          int c0, double x, double y, uint32_t &badBits, double &sum)
+                                          int c0, double *x, double *y, uint32_t *badBits, double *sum)
 {
     static_assert(G >= 1 && G <= 3, "kernel arithmetic is defined for groups of 1, 2, 3 cameras");
     // opaque re-definition of the pixel coordinates per group: without it the register allocator splits the live
-    // ranges of x and y around the camera loop into one copy per use (20 v_mov + 16 VGPRs per window step)
-    asm volatile("" : "+v"(x), "+v"(y));
-    double bx[G], by[G], nx[G], ny[G], w[G], rw[G];
+    // ranges of x and y around the camera loop into one copy per use
+#pragma unroll
+    for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
+    double bx[NS][G], by[NS][G], nx[NS][G], ny[NS][G], w[NS][G], rw[NS][G];
     const float *base[G];
-    uint32_t off[G], cwv[G];
+    uint32_t off[NS][G], cwv[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         const double *H = Hbuf + 9 * (c0 + u);
-        w[u] = fma(H[7], y, fma(H[6], x, H[8]));
-        nx[u] = fma(H[1], y, fma(H[0], x, H[2]));
-        ny[u] = fma(H[4], y, fma(H[3], x, H[5]));
+        const double h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6], h7 = H[7], h8 = H[8];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            w[q][u] = fma(h7, y[q], fma(h6, x[q], h8));
+            nx[q][u] = fma(h1, y[q], fma(h0, x[q], h2));
+            ny[q][u] = fma(h4, y[q], fma(h3, x[q], h5));
+        }
     }
-    // one reciprocal per group (Montgomery batch inversion).  A zero / non-finite w poisons the whole group, which
-    // is right: any overflowing tap makes the whole call DBL_MAX.
-    if (G == 3) {
-        const double p01 = w[0] * w[1];
-        const double r = 1.0 / (p01 * w[G - 1]);
-        rw[G - 1] = r * p01;           // 1/w2
-        const double r01 = r * w[G - 1]; // 1/(w0 w1)
-        rw[0] = r01 * w[1];
-        rw[G > 1 ? 1 : 0] = r01 * w[0];
-    } else if (G == 2) {
-        const double r = 1.0 / (w[0] * w[G - 1]);
-        rw[0] = r * w[G - 1];
-        rw[G - 1] = r * w[0];
-    } else {
-        rw[0] = 1.0 / w[0];
+    // one reciprocal per group and pixel (Montgomery batch inversion).  A zero / non-finite w poisons the whole
+    // group, which is right: any overflowing tap makes the whole call DBL_MAX.
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        if (G == 3) {
+            const double p01 = w[q][0] * w[q][G > 1 ? 1 : 0];
+            const double r = 1.0 / (p01 * w[q][G - 1]);
+            rw[q][G - 1] = r * p01;                // 1/w2
+            const double r01 = r * w[q][G - 1];    // 1/(w0 w1)
+            rw[q][0] = r01 * w[q][G > 1 ? 1 : 0];
+            rw[q][G > 1 ? 1 : 0] = r01 * w[q][0];
+        } else if (G == 2) {
+            const double r = 1.0 / (w[q][0] * w[q][G - 1]);
+            rw[q][0] = r * w[q][G - 1];
+            rw[q][G - 1] = r * w[q][0];
+        } else {
+            rw[q][0] = 1.0 / w[q][0];
+        }
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         const int c = c0 + u;
-        const double ix = nx[u] * rw[u], iy = ny[u] * rw[u];
-        // patch.cpp:999 in the integer domain, without branches: for the truncated q = (int)ix,
-        // 2 <= ix < w-3  <=>  2 <= q <= w-4 (NaN converts to 0, +-inf / overflow saturate: all rejected;
-        // w == 0 needs no test of its own: the reciprocal is inf / NaN).  The clamped q addresses the tap,
-        // q != clamp(q) flags the overflow.  frac(ix) == ix - (double)q exactly for an accepted ix.
-        const int qx = (int)ix, qy = (int)iy;
-        const int px = clamp_i32(qx, 2, cams[c].qxmax), py = clamp_i32(qy, 2, cams[c].qymax);
-        badBits |= (uint32_t)((px ^ qx) | (py ^ qy));
-        bx[u] = __builtin_amdgcn_fract(ix);
-        by[u] = __builtin_amdgcn_fract(iy);
+        const int qxmax = cams[c].qxmax, qymax = cams[c].qymax;
         const uint32_t cw = (uint32_t)cams[c].w;
         base[u] = sc.imgF + cams[c].imgOff; // wave-uniform
-        off[u] = (uint32_t)py * cw + (uint32_t)px;
         cwv[u] = cw;
-    }
-    PixPair r0[G], r1[G];
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-        r0[u] = load_pair(base[u] + off[u]);
-        r1[u] = load_pair(base[u] + (off[u] + cwv[u]));
+        for (int q = 0; q < NS; ++q) {
+            const double ix = nx[q][u] * rw[q][u], iy = ny[q][u] * rw[q][u];
+            // patch.cpp:999 in the integer domain, without branches: for the truncated q = (int)ix,
+            // 2 <= ix < w-3  <=>  2 <= q <= w-4 (NaN converts to 0, +-inf / overflow saturate: all rejected;
+            // w == 0 needs no test of its own: the reciprocal is inf / NaN).  The clamped q addresses the tap,
+            // q != clamp(q) flags the overflow.  frac(ix) == ix - (double)q exactly for an accepted ix.
+            const int qx = (int)ix, qy = (int)iy;
+            const int px = clamp_i32(qx, 2, qxmax), py = clamp_i32(qy, 2, qymax);
+            badBits[q] |= (uint32_t)((px ^ qx) | (py ^ qy));
+            bx[q][u] = __builtin_amdgcn_fract(ix);
+            by[q][u] = __builtin_amdgcn_fract(iy);
+            off[q][u] = (uint32_t)py * cw + (uint32_t)px;
+        }
     }
+    PixPair r0[NS][G], r1[NS][G];
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-        // bilinear as three lerps a + f (b - a); the pixel differences are exact in float (integers < 2^24)
-        const double i00 = (double)r0[u].a, d0 = (double)(r0[u].b - r0[u].a);
-        const double i01 = (double)r1[u].a, d1 = (double)(r1[u].b - r1[u].a);
-        const double t0 = fma(bx[u], d0, i00);
-        const double t1 = fma(bx[u], d1, i01);
-        const double col = fma(by[u], t1 - t0, t0);
-        myc[(c0 + u) * 64] = col;
-        sum += col;
-    }
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            r0[q][u] = load_pair(base[u] + off[q][u]);
+            r1[q][u] = load_pair(base[u] + (off[q][u] + cwv[u]));
+        }
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            // bilinear as three lerps a + f (b - a); the pixel differences are exact in float (integers < 2^24)
+            const double i00 = (double)r0[q][u].a, d0 = (double)(r0[q][u].b - r0[q][u].a);
+            const double i01 = (double)r1[q][u].a, d1 = (double)(r1[q][u].b - r1[q][u].a);
+            const double t0 = fma(bx[q][u], d0, i00);
+            const double t1 = fma(bx[q][u], d1, i01);
+            const double col = fma(by[q][u], t1 - t0, t0);
+            myc[((c0 + u) * NS + q) * 64] = col;
+            sum[q] += col;
+        }
 }
 
 // PAIS::getFitness for one particle, executed by ONE wave (all 64 lanes enter
 // with identical arguments and leave with the identical result).
 //   Hbuf : this wave's LDS scratch, K*9 doubles   (homographies, patch.cpp:290-330)
-//   cbuf : this wave's LDS scratch, (K+8)*64 doubles (per-camera colour of the lane's pixel; rows K..K+7:
+//   cbuf : this wave's LDS scratch, (2K+8)*64 doubles (per-camera colour of the lane's two pixels; rows 2K..2K+7:
 //          the lane's 4 x (fitness, weight) sub-accumulators -- in LDS, not registers, to stay at 4 waves/SIMD)
 // Arithmetic ("kernel arithmetic"; mirrored bit for bit by the oracle's
 // detMath/treeSum mode): homography rows with fma, ONE reciprocal per camera group, bilinear as
@@ -289,49 +310,67 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useDiff = sc.cfg.adaptiveDifferenceEnable != 0,
                useGrad = sc.cfg.adaptiveGradientEnable != 0;
     const double invK = 1.0 / (double)K;
+    constexpr int NS = 2; // window pixels per lane and loop iteration (two of this wave's 64-pixel steps)
     double *myc = cbuf + lane;
-    double *myacc = cbuf + (size_t)K * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
+    double *myacc = cbuf + (size_t)K * NS * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
 #pragma unroll
     for (int a = 0; a < 8; ++a) myacc[a * 64] = 0;
 
-    // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel
-    // index / clamped addresses for lanes that have no pixel, a masked pixel or an overflowing
-    // tap); only wave-uniform conditions branch.  Contributions are selected at the end.
-    // Window pixel of this lane, advanced by 64 pixels per step without a division.
-    const int q64 = 64 / S, r64 = 64 - q64 * S; // uniform
-    int yw = lane / S, xw = lane - yw * S;
-    for (int base = 0, step = 0; base < S2;
-         base += 64, ++step, xw += r64, yw += q64, yw += (xw >= S) ? 1 : 0, xw -= (xw >= S) ? S : 0) {
-        const int acc = step & 3;                   // wave-uniform
-        if ((acc & (nparts - 1)) != part) continue; // another wave's share (nparts is 1, 2 or 4)
-        const bool valid = base + lane < S2;
-        const int yi = valid ? yw : (S - 1), xi = valid ? xw : (S - 1); // lanes past the window redo its last pixel
-        const double x = a0 + (double)xi, y = b0 + (double)yi; // == the reference's ++x / ++y walk
-        const int rx = cv_round(x), ry = cv_round(y);
-        // per-pixel operands, requested before the taps so that their latency hides behind them
-        const uint8_t refMask = refImg[ry * refW + rx]; // :986
-        const double wDist = useDist ? sc.gauss[xi * S + yi] : 1.0;
-        const double eGrad = useGrad ? refEdge[ry * refW + rx] : 1.0;
-        uint32_t badBits = 0; // != 0: some tap of this pixel left [2, w-3) x [2, h-3)
-        double sum = 0;
+    // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel index / clamped
+    // addresses for lanes that have no pixel, a masked pixel or an overflowing tap); only wave-uniform
+    // conditions branch.  Contributions are selected at the end.
+    // This wave's steps are part, part + nparts, ...: two of them per iteration.  The lane's window pixel is
+    // advanced by 64 * nparts pixels per step without a division.
+    const int adv = 64 * nparts;
+    const int qA = adv / S, rA = adv - qA * S; // uniform
+    int yw = (64 * part + lane) / S, xw = (64 * part + lane) - yw * S;
+    for (int st = part; 64 * st < S2; st += NS * nparts) {
+        double x[NS], y[NS], wDist[NS], eGrad[NS], sum[NS];
+        uint32_t badBits[NS];
+        uint8_t refMask[NS];
+        bool valid[NS];
+        int gi[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int stq = st + q * nparts;
+            valid[q] = 64 * stq + lane < S2; // steps past the window: every lane redoes the last pixel, unused
+            const int yi = valid[q] ? yw : (S - 1), xi = valid[q] ? xw : (S - 1);
+            x[q] = a0 + (double)xi; // == the reference's ++x / ++y walk
+            y[q] = b0 + (double)yi;
+            const int rx = cv_round(x[q]), ry = cv_round(y[q]);
+            // per-pixel operands, requested before the taps so that their latency hides behind them
+            refMask[q] = refImg[ry * refW + rx]; // :986
+            wDist[q] = useDist ? sc.gauss[xi * S + yi] : 1.0;
+            eGrad[q] = useGrad ? refEdge[ry * refW + rx] : 1.0;
+            badBits[q] = 0; // != 0: some tap of this pixel left [2, w-3) x [2, h-3)
+            sum[q] = 0;
+            gi[q] = stq & 3; // canonical sub-accumulator of the step
+            xw += rA; yw += qA;
+            yw += (xw >= S) ? 1 : 0;
+            xw -= (xw >= S) ? S : 0;
+        }
         int c0 = 0;
-        for (; K - c0 >= 4 || K - c0 == 2; c0 += 2) tap_group<2>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
-        if (K - c0 == 3) tap_group<3>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
-        else if (K - c0 == 1) tap_group<1>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // K == 1
-        const bool act = valid && (refMask != 0);
-        if (__any(act && badBits != 0)) return 1; // :1001 -- whole call
-        const double mean = sum * invK;
-        double sad = 0;
-        for (int c = 0; c < K; ++c) sad += fabs(myc[c * 64] - mean);
-        sad *= invK;
-        double weight = 1;
-        if (useDist) weight *= wDist;
-        if (useDiff) weight *= det_exp_bf(-(sad * sad) * invDiffW);
-        if (useGrad) weight *= det_exp_bf(-1.0 / (eGrad * gradW));
-        double *pa = myacc + acc * 128;
-        const double w0 = pa[64], f0 = pa[0];
-        pa[64] = act ? (w0 + weight) : w0;
-        pa[0] = act ? fma(weight, sad, f0) : f0;
+        for (; K - c0 >= 4 || K - c0 == 2; c0 += 2) tap_group<2, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
+        if (K - c0 == 3) tap_group<3, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
+        else if (K - c0 == 1) tap_group<1, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // K == 1
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (64 * (st + q * nparts) >= S2) break; // uniform: the window has no such step
+            const bool act = valid[q] && (refMask[q] != 0);
+            if (__any(act && badBits[q] != 0)) return 1; // :1001 -- whole call
+            const double mean = sum[q] * invK;
+            double sad = 0;
+            for (int c = 0; c < K; ++c) sad += fabs(myc[(c * NS + q) * 64] - mean);
+            sad *= invK;
+            double weight = 1;
+            if (useDist) weight *= wDist[q];
+            if (useDiff) weight *= det_exp_bf(-(sad * sad) * invDiffW);
+            if (useGrad) weight *= det_exp_bf(-1.0 / (eGrad[q] * gradW));
+            double *pa = myacc + gi[q] * 128;
+            const double w0 = pa[64], f0 = pa[0];
+            pa[64] = act ? (w0 + weight) : w0;
+            pa[0] = act ? fma(weight, sad, f0) : f0;
+        }
     }
     // butterflies only for this wave's sub-accumulators (uniform conditions)
     for (int a = part; a < 4; a += nparts) {

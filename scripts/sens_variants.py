@@ -6,14 +6,14 @@ SRC = os.path.join(ROOT, "pais_mvs_amd", "csrc")
 OUT = os.path.join(SRC, "variants")
 VARS = {
     "base": [],
-    "noload": [("r0[u] = load_pair(base[u] + off[u]);", "r0[u] = off[u] & 0xffffu;"),
-               ("r1[u] = load_pair(base[u] + (off[u] + cwv[u]));", "r1[u] = (off[u] >> 3) & 0xffffu;")],
+    # read the group's homographies a second time from LDS (results unused): how much LDS slack is there?
+    "lds2x": [('    double bx[G], by[G], nx[G], ny[G], w[G], rw[G];', '    { const double *Hx = Hbuf + 9 * ((c0 + G < 4) ? c0 + G : 0); for (int i_ = 0; i_ < 9 * G; ++i_) { double t_ = Hx[i_]; asm volatile("" ::"v"(t_)); } }\n    double bx[G], by[G], nx[G], ny[G], w[G], rw[G];')],
+    # the same amount of extra VALU work instead (18 dependent-free adds per pair)
+    "valu_extra": [('    double bx[G], by[G], nx[G], ny[G], w[G], rw[G];', '    { double e_ = x; for (int i_ = 0; i_ < 9 * G; ++i_) { e_ = e_ + y; asm volatile("" : "+v"(e_)); } }\n    double bx[G], by[G], nx[G], ny[G], w[G], rw[G];')],
     "nodiv": [("const double r = 1.0 / (w[0] * w[G - 1]);", "const double r = __builtin_amdgcn_rcp(w[0] * w[G - 1]);")],
     "noexp": [("if (useDiff) weight *= det_exp_bf(-(sad * sad) * invDiffW);", "if (useDiff) weight *= (1.0 - (sad * sad) * invDiffW);")],
-    "waves5": [("#define PAIS_ITER_BOUNDS __launch_bounds__(64, 4)", "#define PAIS_ITER_BOUNDS __launch_bounds__(64, 5)")],
-    "waves3": [("#define PAIS_ITER_BOUNDS __launch_bounds__(64, 4)", "#define PAIS_ITER_BOUNDS __launch_bounds__(64, 3)")],
-    "nolds_acc": [("pa[64] = act ? (w0 + weight) : w0;", "if (step == 99) pa[64] = act ? (w0 + weight) : w0;"),
-                  ("pa[0] = act ? fma(weight, sad, f0) : f0;", "if (step == 99) pa[0] = act ? fma(weight, sad, f0) : f0;")],
+    "waves5": [("#define PAIS_ITER_BOUNDS __launch_bounds__(64, 3)", "#define PAIS_ITER_BOUNDS __launch_bounds__(64, 5)")],
+    "waves4": [("#define PAIS_ITER_BOUNDS __launch_bounds__(64, 3)", "#define PAIS_ITER_BOUNDS __launch_bounds__(64, 4)")],
 }
 def main(names):
     os.makedirs(OUT, exist_ok=True)
