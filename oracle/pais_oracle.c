@@ -1532,6 +1532,21 @@ void po_expand_candidate(const po_scene *s, po_patch *out, const double center[3
     po_remove_invisible_camera(s, out);
 }
 
+/* n independent expansion candidates refined in parallel over PATCHES (one thread per candidate, particles
+ * serial) -- not the reference's structure (it parallelises over the <= 30 particles of one patch, patches are
+ * sequential): the stronger CPU number bench.py reports next to the reference-structured one. */
+void po_expand_candidates_parallel(const po_scene *s, po_patch *out, int n, const double *centers,
+                                   const double *parentNormals, const int *parentNumCam, const int *parentCamIdx,
+                                   const uint64_t *keys)
+{
+    po_scene local = *s;
+    local.ompParticles = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; ++i)
+        po_expand_candidate(&local, &out[i], centers + 3 * i, parentNormals + 3 * i, parentNumCam[i],
+                            parentCamIdx + (size_t)PO_MAX_VIS * i, keys[i]);
+}
+
 /* mvs.cpp:214-215 */
 void po_refine_seed(const po_scene *s, po_patch *p)
 {

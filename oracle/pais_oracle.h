@@ -233,6 +233,9 @@ void    po_expansion_center(const po_scene *s, int cam, const po_patch *parent, 
 void    po_expand_candidate(const po_scene *s, po_patch *out, const double center[3],
                             const double parentNormal[3], int parentNumCam,
                             const int *parentCamIdx, uint64_t key);
+void    po_expand_candidates_parallel(const po_scene *s, po_patch *out, int n, const double *centers,
+                                      const double *parentNormals, const int *parentNumCam, const int *parentCamIdx,
+                                      const uint64_t *keys); /* parentCamIdx: PO_MAX_VIS ints per candidate */
 void    po_refine_seed(const po_scene *s, po_patch *p);  /* refine + removeInvisibleCamera, mvs.cpp:214-215 */
 
 size_t  po_sizeof_patch(void);

@@ -141,6 +141,10 @@ def lib():
     L.po_set_correlation_table.argtypes = [C.POINTER(SceneS), C.POINTER(Patch), C.POINTER(C.c_double)]
     L.po_is_neighbor.restype = C.c_int
     L.po_is_neighbor.argtypes = [C.POINTER(SceneS), C.POINTER(Patch), C.POINTER(Patch)]
+    L.po_expand_candidates_parallel.argtypes = [C.POINTER(SceneS), C.POINTER(Patch), C.c_int, C.POINTER(C.c_double),
+                                                C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                C.POINTER(C.c_uint64)]
+    L.po_expand_candidates_parallel.restype = None
     L.po_expand_candidate.argtypes = [C.POINTER(SceneS), C.POINTER(Patch), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_uint64]
     L.po_mvs_create.restype = C.c_void_p
