@@ -212,6 +212,11 @@ int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
  * launch are not free); the environment variable PAIS_FINE_TIMING=1 turns it on at context creation. */
 int  pais_ctx_set_fine_timing(pais_ctx *ctx, int on);
 
+/* MVS::neighborPatchFiltering's O(n^2) part (mvs.cpp:448-524): counts[i] = number of OTHER centres within `radius`
+ * of centre i (dist = sqrt(dx^2+dy^2+dz^2) in that order, counted when !(dist > radius)).  centers: n x 3 doubles on
+ * the host.  kernel_ms (optional): duration of the kernel alone. */
+int  pais_neighbor_count(pais_ctx *ctx, int n, const double *centers, double radius, int32_t *counts, double *kernel_ms);
+
 /* Deterministic stream helpers (shared by host scheduler and tests). */
 uint32_t pais_rand31(uint64_t seed, uint64_t key, uint32_t run, uint32_t k);
 uint64_t pais_child_key(uint64_t parent_key, int cam, int cx, int cy);

@@ -87,6 +87,20 @@ int  pais_mvs_round_begin(pais_mvs *m, int parents_per_round, const pais_candida
 int  pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *results, int n);
 int  pais_mvs_expansion_end(pais_mvs *m);   /* setNeighborRadius (mvs.cpp:274) */
 
+/* ---- post filters: the `-f` verb (TMVS.cpp:124-172) --------------------- */
+/* Loader constructor Patch(center, normalS, camIdx, fitness, correlation, id) (patch.cpp:45-59), i.e. what
+ * FileLoader::loadMvsPatch builds from a .mvs file (fileloader.cpp:206-231).  Returns the id or < 0. */
+int  pais_mvs_load_patch(pais_mvs *m, const double center[3], const double normalS[2], int num_cam,
+                         const int32_t *cam_idx, double fitness, double correlation);
+/* MVS::cellFiltering / visibilityFiltering / neighborCellFiltering (mvs.cpp:278-446): sequential host passes in
+ * the reference's order (their decisions depend on the deletions made so far). */
+int  pais_mvs_cell_filtering(pais_mvs *m);
+int  pais_mvs_visibility_filtering(pais_mvs *m);
+int  pais_mvs_neighbor_cell_filtering(pais_mvs *m, double neighbor_ratio);
+/* MVS::neighborPatchFiltering (mvs.cpp:448-524): all-pairs neighbour counts on the GPU (k_neighbor_count), then
+ * the reference's average / ratio rule.  kernel_ms (optional) returns the kernel's duration. */
+int  pais_mvs_neighbor_patch_filtering(pais_mvs *m, double neighbor_ratio, double *kernel_ms);
+
 /* ---- inspection -------------------------------------------------------- */
 int    pais_mvs_num_patches(const pais_mvs *m);
 int    pais_mvs_num_slots(const pais_mvs *m);        /* ids are 0 .. slots-1 */

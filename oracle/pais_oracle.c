@@ -2077,6 +2077,184 @@ long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
     return m->refineCalls - before;
 }
 
+/* ------------------------------------------------------------------------ */
+/* post filters: the `-f` verb, TMVS.cpp:124-172                             */
+/* ------------------------------------------------------------------------ */
+/* Patch(center, normalS, camIdx, fitness, correlation, id), patch.cpp:45-59 (FileLoader::loadMvsPatch) */
+int po_mvs_load_patch(po_mvs *m, const double center[3], const double normalS[2], int numCam, const int *camIdx,
+                      double fitness, double correlation)
+{
+    const po_scene *s = m->s;
+    po_patch p;
+    patch_init(&p);
+    p.type = PO_TYPE_SEED;
+    for (int i = 0; i < 3; ++i) p.center[i] = center[i];
+    p.numCam = numCam > PO_MAX_VIS ? PO_MAX_VIS : numCam;
+    for (int i = 0; i < p.numCam; ++i) p.camIdx[i] = camIdx[i];
+    p.fitness = fitness;
+    p.correlation = correlation;
+    p.drop = 0;
+    p.key = (uint64_t)m->nslots;
+    p.normalS[0] = normalS[0];
+    p.normalS[1] = normalS[1];
+    s2n(s, normalS, p.normal); /* setNormal(Vec2d), abstractpatch.cpp:48-51 */
+    po_set_reference_camera(s, &p);
+    po_set_depth_and_ray(s, &p);
+    po_set_depth_range(s, &p);
+    po_set_lod(s, &p);
+    po_set_priority(s, &p);
+    po_set_image_point(s, &p);
+    p.drop = 0; /* the filter verbs never look at it; the loader does not test it either */
+    int id = mvs_store(m, &p);
+    m->patches[id]->expanded = 1;
+    return id;
+}
+
+static void filter_prepare(po_mvs *m)
+{
+    if (!m->cellMaps) { /* `if (cellMaps.empty())` at the head of every filter */
+        po_mvs_set_neighbor_radius(m);
+        mvs_set_cell_maps(m);
+    }
+}
+
+/* MVS::cellFiltering, mvs.cpp:278-325 */
+void po_mvs_cell_filtering(po_mvs *m)
+{
+    filter_prepare(m);
+    const po_scene *s = m->s;
+    for (int ci = 0; ci < s->numCams; ++ci) {
+        po_cellmap *map = &m->cellMaps[ci];
+        for (int x = 0; x < map->width; ++x) {
+            for (int y = 0; y < map->height; ++y) {
+                po_cell *cell = &map->cells[(long)y * map->width + x];
+                const int pthNum = cell->n;
+                if (pthNum == 0) continue;
+                int *removeIdx = (int *)malloc(sizeof(int) * (size_t)pthNum);
+                int nRem = 0;
+                for (int j = 0; j < pthNum; ++j) {
+                    double corrSum = 0;
+                    for (int k = 0; k < pthNum; ++k) {
+                        if (j == k) continue;
+                        const po_patch *q = m->patches[cell->ids[k]];
+                        if (!q) continue;
+                        corrSum += q->correlation;
+                    }
+                    const po_patch *pth = m->patches[cell->ids[j]];
+                    if (!pth) continue;
+                    if (pth->correlation * pth->numCam < corrSum) removeIdx[nRem++] = cell->ids[j];
+                }
+                for (int j = 0; j < nRem; ++j) mvs_delete_patch(m, removeIdx[j]);
+                free(removeIdx);
+            }
+        }
+    }
+}
+
+/* MVS::visibilityFiltering, mvs.cpp:394-446 */
+void po_mvs_visibility_filtering(po_mvs *m)
+{
+    filter_prepare(m);
+    const po_scene *s = m->s;
+    for (int id = 0; id < m->nslots; ++id) {
+        const po_patch *pth = m->patches[id];
+        if (!pth) continue;
+        int visibleCount = pth->numCam;
+        for (int i = 0; i < pth->numCam; ++i) {
+            const po_camera *cam = &s->cams[pth->camIdx[i]];
+            double d[3] = {pth->center[0] - cam->C[0], pth->center[1] - cam->C[1], pth->center[2] - cam->C[2]};
+            const double depth = norm3(d);
+            const int cx = (int)(pth->imgPoint[i][0] / s->cfg.cellSize), cy = (int)(pth->imgPoint[i][1] / s->cfg.cellSize);
+            po_cellmap *map = &m->cellMaps[pth->camIdx[i]];
+            if (!cm_in_map(map, cx, cy)) continue; /* undefined in the reference; does not happen for loaded clouds */
+            const po_cell *cell = &map->cells[(long)cy * map->width + cx];
+            for (int k = 0; k < cell->n; ++k) {
+                if (cell->ids[k] == pth->id) continue;
+                const po_patch *q = m->patches[cell->ids[k]];
+                if (!q) continue;
+                double dn[3] = {q->center[0] - cam->C[0], q->center[1] - cam->C[1], q->center[2] - cam->C[2]};
+                if (depth > norm3(dn)) {
+                    --visibleCount;
+                    break;
+                }
+            }
+        }
+        if (visibleCount < s->cfg.minCamNum) mvs_delete_patch(m, id);
+    }
+}
+
+/* MVS::neighborCellFiltering, mvs.cpp:327-392 */
+void po_mvs_neighbor_cell_filtering(po_mvs *m, double neighborRatio)
+{
+    filter_prepare(m);
+    const po_scene *s = m->s;
+    for (int ci = 0; ci < s->numCams; ++ci) {
+        po_cellmap *map = &m->cellMaps[ci];
+        for (int x = 0; x < map->width; ++x) {
+            for (int y = 0; y < map->height; ++y) {
+                po_cell *cell = &map->cells[(long)y * map->width + x];
+                const int pthNum = cell->n;
+                if (pthNum == 0) continue;
+                int *removeIdx = (int *)malloc(sizeof(int) * (size_t)pthNum);
+                int nRem = 0;
+                const int nx[9] = {x, x - 1, x + 1, x - 1, x + 1, x + 1, x, x - 1, x};
+                const int ny[9] = {y, y - 1, y - 1, y + 1, y + 1, y, y + 1, y, y - 1};
+                for (int j = 0; j < pthNum; ++j) {
+                    const po_patch *c = m->patches[cell->ids[j]];
+                    if (!c) continue;
+                    int neighborPthSum = 0, neighborPthNum = 0;
+                    for (int q = 0; q < 9; ++q) {
+                        if (!cm_in_map(map, nx[q], ny[q])) continue;
+                        const po_cell *nc = &map->cells[(long)ny[q] * map->width + nx[q]];
+                        neighborPthSum += nc->n;
+                        for (int k = 0; k < nc->n; ++k) {
+                            const po_patch *np = m->patches[nc->ids[k]];
+                            if (!np) continue;
+                            if (po_is_neighbor(s, c, np)) ++neighborPthNum;
+                        }
+                    }
+                    if ((double)neighborPthNum / (double)neighborPthSum < neighborRatio) removeIdx[nRem++] = c->id;
+                }
+                for (int j = 0; j < nRem; ++j) mvs_delete_patch(m, removeIdx[j]);
+                free(removeIdx);
+            }
+        }
+    }
+}
+
+/* MVS::neighborPatchFiltering, mvs.cpp:448-524.  The reference sorts every patch's distances to all others and walks
+ * them up to the first one beyond neighborRadius: that is the count of the others within the radius.  counts (optional):
+ * nslots ints, -1 for deleted ids. */
+void po_mvs_neighbor_patch_filtering(po_mvs *m, double neighborRatio, int *counts)
+{
+    filter_prepare(m);
+    const double radius = m->s->cfg.neighborRadius;
+    int n = 0;
+    int *cnt = (int *)malloc(sizeof(int) * (size_t)(m->nslots > 0 ? m->nslots : 1));
+    for (int a = 0; a < m->nslots; ++a) {
+        cnt[a] = -1;
+        const po_patch *p = m->patches[a];
+        if (!p) continue;
+        int c = 0;
+        for (int b = 0; b < m->nslots; ++b) {
+            const po_patch *q = m->patches[b];
+            if (!q || b == a) continue;
+            double d[3] = {p->center[0] - q->center[0], p->center[1] - q->center[1], p->center[2] - q->center[2]};
+            if (!(norm3(d) > radius)) ++c;
+        }
+        cnt[a] = c;
+        ++n;
+    }
+    double avg = 0;
+    for (int a = 0; a < m->nslots; ++a)
+        if (cnt[a] >= 0) avg += (double)cnt[a];
+    if (n > 0) avg /= (double)n;
+    if (counts) memcpy(counts, cnt, sizeof(int) * (size_t)m->nslots);
+    for (int a = 0; a < m->nslots; ++a)
+        if (cnt[a] >= 0 && (double)cnt[a] < (avg * neighborRatio)) mvs_delete_patch(m, a);
+    free(cnt);
+}
+
 void po_mvs_set_thin_front(po_mvs *m, int thinFront) { m->thinFront = thinFront < 0 ? 0 : thinFront; }
 
 size_t po_sizeof_patch(void) { return sizeof(po_patch); }

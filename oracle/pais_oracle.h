@@ -221,6 +221,13 @@ long    po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail
  * parent instead of one (0 = never).  Same rule and default as pais_mvs_set_thin_front (include/pais_mvs.h). */
 #define PO_DEFAULT_THIN_FRONT 64
 void    po_mvs_set_thin_front(po_mvs *m, int thinFront);
+/* post filters (`-f` verb, TMVS.cpp:124-172; mvs.cpp:278-524) and the .mvs loader constructor (patch.cpp:45-59) */
+int     po_mvs_load_patch(po_mvs *m, const double center[3], const double normalS[2], int numCam, const int *camIdx,
+                          double fitness, double correlation);
+void    po_mvs_cell_filtering(po_mvs *m);
+void    po_mvs_visibility_filtering(po_mvs *m);
+void    po_mvs_neighbor_cell_filtering(po_mvs *m, double neighborRatio);
+void    po_mvs_neighbor_patch_filtering(po_mvs *m, double neighborRatio, int *counts);
 int     po_mvs_num_patches(const po_mvs *m);
 int     po_mvs_num_slots(const po_mvs *m);              /* ids are 0..slots-1 */
 const po_patch *po_mvs_get_patch(const po_mvs *m, int id); /* NULL if deleted */

@@ -117,6 +117,7 @@ def load(build_if_needed: bool = True):
     L.pais_refine_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.pais_get_kernel_stats.argtypes = [C.c_void_p, C.POINTER(KernelStats), C.c_int]
     L.pais_ctx_set_fine_timing.argtypes = [C.c_void_p, C.c_int]
+    L.pais_neighbor_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.pais_rand31.restype = C.c_uint32
     L.pais_rand31.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     L.pais_child_key.restype = C.c_uint64

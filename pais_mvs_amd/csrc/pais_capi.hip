@@ -315,6 +315,40 @@ extern "C" int pais_ctx_synchronize(pais_ctx *ctx)
 
 // ------------------------------------------------------------ fitness batch --
 static int get_event_pair(pais_ctx *ctx, EventPair &p);
+static int get_event_pair(pais_ctx *ctx, EventPair &p);
+// MVS::neighborPatchFiltering's distance counts (mvs.cpp:448-524) -- see k_neighbor_count
+extern "C" int pais_neighbor_count(pais_ctx *ctx, int n, const double *centers, double radius, int32_t *counts, double *kernel_ms)
+{
+    if (!ctx || n < 0 || (n && (!centers || !counts))) return fail_msg("pais_neighbor_count: bad argument");
+    if (kernel_ms) *kernel_ms = 0;
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    double *d_c = nullptr;
+    int32_t *d_n = nullptr;
+    HIPCHK(hipMalloc(&d_c, sizeof(double) * 3 * (size_t)n));
+    if (hipMalloc(&d_n, sizeof(int32_t) * (size_t)n) != hipSuccess) { (void)hipFree(d_c); return fail_msg("pais_neighbor_count: out of device memory"); }
+    int rc = 0;
+    EventPair e{nullptr, nullptr};
+    if (get_event_pair(ctx, e)) rc = -2;
+    if (!rc && hipMemcpyAsync(d_c, centers, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -2;
+    if (!rc) {
+        (void)hipEventRecord(e.a, ctx->stream);
+        if (pais_launch::neighbor_count(d_c, n, radius, d_n, ctx->stream) != hipSuccess) rc = -2;
+        (void)hipEventRecord(e.b, ctx->stream);
+    }
+    if (!rc && hipMemcpyAsync(counts, d_n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = -2;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = -2;
+    if (!rc && kernel_ms) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) *kernel_ms = ms;
+    }
+    if (e.a) ctx->evFree.push_back(e);
+    (void)hipFree(d_c);
+    (void)hipFree(d_n);
+    if (rc) return fail_msg("pais_neighbor_count: HIP failure");
+    return 0;
+}
+
 extern "C" int pais_ctx_set_fine_timing(pais_ctx *ctx, int on)
 {
     if (!ctx) return fail_msg("pais_ctx_set_fine_timing: bad argument");

@@ -43,6 +43,7 @@ namespace pais_launch {
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, const int32_t *idx, const double *particles,
                    double *out, int nEvals, int Kmax, hipStream_t stream);
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream);
+hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream);
 int pso_waves(int N, int Kmax, int Nmax, size_t ldsLimit);
 size_t pso_lds(int W, int Kmax, int Nmax);
 hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters, unsigned long long *stat, int Kmax,

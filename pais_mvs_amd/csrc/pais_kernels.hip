@@ -1912,6 +1912,37 @@ __global__ __launch_bounds__(64) void k_after(DevScene sc, pais_patch_result *re
     }
 }
 
+// -------------------------------------------------------- k_neighbor_count ---
+// MVS::neighborPatchFiltering (mvs.cpp:448-524), the O(n^2) part: for every patch the number of OTHER patches
+// whose centre lies within neighborRadius (the reference sorts all distances and counts up to the first one
+// beyond the radius: the same number).  One thread per patch i; the centres are streamed through LDS in tiles
+// of 256.  dist = sqrt(dx*dx + dy*dy + dz*dz) accumulated in that order (cv::norm of a Vec3d), compared as
+// `!(dist > radius)` like the reference's `if (dist > neighborRadius) break`.
+__global__ __launch_bounds__(256) void k_neighbor_count(const double *centers, int n, double radius, int32_t *counts)
+{
+    __shared__ double tile[256 * 3];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool has = i < n;
+    const double cx = has ? centers[3 * i] : 0, cy = has ? centers[3 * i + 1] : 0, cz = has ? centers[3 * i + 2] : 0;
+    int cnt = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int m = (n - base) < 256 ? (n - base) : 256;
+        __syncthreads();
+        for (int t = threadIdx.x; t < 3 * m; t += 256) tile[t] = centers[3 * (size_t)base + t];
+        __syncthreads();
+        for (int j = 0; j < m; ++j) {
+            const double dx = cx - tile[3 * j], dy = cy - tile[3 * j + 1], dz = cz - tile[3 * j + 2];
+            double s2 = 0;
+            s2 += dx * dx;
+            s2 += dy * dy;
+            s2 += dz * dz;
+            const double dist = sqrt(s2);
+            cnt += ((base + j) != i && !(dist > radius)) ? 1 : 0;
+        }
+    }
+    if (has) counts[i] = cnt;
+}
+
 // --------------------------------------------------------------- launchers ---
 namespace pais_launch {
 
@@ -1989,6 +2020,12 @@ hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_pso, dim3(grid), dim3(64 * W), lds, stream, sc, recs, n, counters, stat, Kmax, Nmax);
+    return hipGetLastError();
+}
+hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_neighbor_count, dim3((n + 255) / 256), dim3(256), 0, stream, centers, n, radius, counts);
     return hipGetLastError();
 }
 size_t pso_lds(int W, int Kmax, int Nmax) { return pso_lds_bytes(W, Kmax, Nmax); }

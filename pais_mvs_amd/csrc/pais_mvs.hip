@@ -701,6 +701,188 @@ extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *resul
     return 0;
 }
 
+// ---------------------------------------------------------------- post filters ---
+// The step after the path (`-f` verb, TMVS.cpp:124-172): MVS::cellFiltering, visibilityFiltering,
+// neighborCellFiltering (mvs.cpp:278-446) are sequential host passes over the cell maps whose decisions depend on
+// the deletions made so far -- replayed here in the reference's order; neighborPatchFiltering (:448-524) counts
+// neighbours over all pairs of patches, which is the GPU kernel k_neighbor_count.
+
+// Loader constructor Patch(center, normalS, camIdx, fitness, correlation, id), patch.cpp:45-59 -- what
+// FileLoader::loadMvsPatch builds (fileloader.cpp:206-231).  Fills what the filter verbs and the writers read
+// (centre, normal, cameras, fitness, correlation, image points); the fields only refine() consumes (reference
+// camera, depth range, LOD, priority) are not derived on the host.
+extern "C" int pais_mvs_load_patch(pais_mvs *m, const double center[3], const double normalS[2], int num_cam,
+                                   const int32_t *cam_idx, double fitness, double correlation)
+{
+    if (!m || !center || !normalS || num_cam < 0 || num_cam > PAIS_MAX_VIS || (num_cam && !cam_idx))
+        return mfail("pais_mvs_load_patch: bad argument");
+    pais_patch_result r;
+    memset(&r, 0, sizeof(r));
+    for (int i = 0; i < 3; ++i) r.center[i] = center[i];
+    r.normalS[0] = normalS[0];
+    r.normalS[1] = normalS[1];
+    pais::spherical2normal(normalS[0], normalS[1], r.normal); // AbstractPatch::setNormal(Vec2d), abstractpatch.cpp:48-51
+    r.num_cam = num_cam;
+    for (int i = 0; i < num_cam; ++i) {
+        if (cam_idx[i] < 0 || cam_idx[i] >= (int)m->cams.size()) return mfail("pais_mvs_load_patch: bad camera index");
+        r.cam_idx[i] = cam_idx[i];
+        m->project0(cam_idx[i], center, r.imgPoint[i]); // setImagePoint, patch.cpp:627-653
+    }
+    r.type = PAIS_TYPE_SEED;
+    r.fitness = fitness;
+    r.correlation = correlation;
+    r.ref_cam = -1;
+    r.lod = -1;
+    r.key = (uint64_t)m->patches.size();
+    const int id = m->storePatch(r);
+    m->patches[id]->expanded = true;
+    return id;
+}
+
+static void filter_prepare(pais_mvs *m)
+{
+    if (m->cellMaps.empty()) { // `if (cellMaps.empty()) { setNeighborRadius(); setCellMaps(); }` at the head of every filter
+        m->setNeighborRadius();
+        m->setCellMaps();
+    }
+}
+// ids of a cell in the reference's vector order (insertion order; the linked list is newest-first)
+static void cell_ids(const pais_mvs *m, const CellMap &map, int x, int y, std::vector<int> &out)
+{
+    out.clear();
+    for (int e = map.head[(size_t)y * map.width + x]; e >= 0; e = m->pool[e].next) out.push_back(m->pool[e].id);
+    std::reverse(out.begin(), out.end());
+}
+
+// MVS::cellFiltering, mvs.cpp:278-325
+extern "C" int pais_mvs_cell_filtering(pais_mvs *m)
+{
+    if (!m) return mfail("pais_mvs_cell_filtering: bad argument");
+    filter_prepare(m);
+    std::vector<int> cell, removeIdx;
+    for (size_t ci = 0; ci < m->cellMaps.size(); ++ci) {
+        CellMap &map = m->cellMaps[ci];
+        for (int x = 0; x < map.width; ++x) {
+            for (int y = 0; y < map.height; ++y) {
+                if (map.head[(size_t)y * map.width + x] < 0) continue;
+                cell_ids(m, map, x, y, cell);
+                removeIdx.clear();
+                const int pthNum = (int)cell.size();
+                for (int j = 0; j < pthNum; ++j) {
+                    double corrSum = 0;
+                    for (int k = 0; k < pthNum; ++k) {
+                        if (j == k) continue;
+                        const HostPatch *q = m->patches[cell[k]];
+                        if (!q) continue;
+                        corrSum += q->r.correlation;
+                    }
+                    const HostPatch *p = m->patches[cell[j]];
+                    if (!p) continue;
+                    if (p->r.correlation * p->r.num_cam < corrSum) removeIdx.push_back(cell[j]);
+                }
+                for (int id : removeIdx) m->deletePatch(id);
+            }
+        }
+    }
+    return 0;
+}
+
+// MVS::visibilityFiltering, mvs.cpp:394-446
+extern "C" int pais_mvs_visibility_filtering(pais_mvs *m)
+{
+    if (!m) return mfail("pais_mvs_visibility_filtering: bad argument");
+    filter_prepare(m);
+    for (size_t id = 0; id < m->patches.size(); ++id) { // map<int,Patch> iterates in id order
+        const HostPatch *p = m->patches[id];
+        if (!p) continue;
+        const pais_patch_result &r = p->r;
+        int visibleCount = r.num_cam;
+        for (int i = 0; i < r.num_cam; ++i) {
+            const HostCamera &cam = m->cams[r.cam_idx[i]];
+            const double d[3] = {r.center[0] - cam.C[0], r.center[1] - cam.C[1], r.center[2] - cam.C[2]};
+            const double depth = pais::norm3(d);
+            const int cx = (int)(r.imgPoint[i][0] / m->cfg.cellSize), cy = (int)(r.imgPoint[i][1] / m->cfg.cellSize);
+            const CellMap &map = m->cellMaps[r.cam_idx[i]];
+            if (!map.inMap(cx, cy)) continue; // getCell on an outside cell is undefined in the reference; loaded patches project inside
+            for (int e = map.head[(size_t)cy * map.width + cx]; e >= 0; e = m->pool[e].next) {
+                if (m->pool[e].id == (int)id) continue;
+                const HostPatch *q = m->patches[m->pool[e].id];
+                if (!q) continue;
+                const double dn[3] = {q->r.center[0] - cam.C[0], q->r.center[1] - cam.C[1], q->r.center[2] - cam.C[2]};
+                if (depth > pais::norm3(dn)) { // some other patch of the cell is in front: one occlusion per camera
+                    --visibleCount;
+                    break;
+                }
+            }
+        }
+        if (visibleCount < m->cfg.minCamNum) m->deletePatch((int)id);
+    }
+    return 0;
+}
+
+// MVS::neighborCellFiltering, mvs.cpp:327-392
+extern "C" int pais_mvs_neighbor_cell_filtering(pais_mvs *m, double neighbor_ratio)
+{
+    if (!m) return mfail("pais_mvs_neighbor_cell_filtering: bad argument");
+    filter_prepare(m);
+    std::vector<int> cell, removeIdx;
+    for (size_t ci = 0; ci < m->cellMaps.size(); ++ci) {
+        CellMap &map = m->cellMaps[ci];
+        for (int x = 0; x < map.width; ++x) {
+            for (int y = 0; y < map.height; ++y) {
+                if (map.head[(size_t)y * map.width + x] < 0) continue;
+                cell_ids(m, map, x, y, cell);
+                removeIdx.clear();
+                const int nx[9] = {x, x - 1, x + 1, x - 1, x + 1, x + 1, x, x - 1, x};
+                const int ny[9] = {y, y - 1, y - 1, y + 1, y + 1, y, y + 1, y, y - 1};
+                for (int id : cell) {
+                    const HostPatch *c = m->patches[id];
+                    if (!c) continue;
+                    int neighborPthSum = 0, neighborPthNum = 0;
+                    for (int j = 0; j < 9; ++j) {
+                        if (!map.inMap(nx[j], ny[j])) continue;
+                        for (int e = map.head[(size_t)ny[j] * map.width + nx[j]]; e >= 0; e = m->pool[e].next) {
+                            ++neighborPthSum;
+                            const HostPatch *q = m->patches[m->pool[e].id];
+                            if (!q) continue;
+                            if (m->isNeighbor(c->r, q->r)) ++neighborPthNum;
+                        }
+                    }
+                    if ((double)neighborPthNum / (double)neighborPthSum < neighbor_ratio) removeIdx.push_back(id);
+                }
+                for (int id : removeIdx) m->deletePatch(id);
+            }
+        }
+    }
+    return 0;
+}
+
+// MVS::neighborPatchFiltering, mvs.cpp:448-524 (PCMVS filter): the pair counts come from the GPU
+extern "C" int pais_mvs_neighbor_patch_filtering(pais_mvs *m, double neighbor_ratio, double *kernel_ms)
+{
+    if (!m) return mfail("pais_mvs_neighbor_patch_filtering: bad argument");
+    if (!m->ctx) return mfail("pais_mvs_neighbor_patch_filtering: no GPU context (the pair counts are a HIP kernel; there is no host path)");
+    filter_prepare(m);
+    std::vector<int> ids;
+    std::vector<double> centers;
+    for (const HostPatch *p : m->patches) {
+        if (!p) continue;
+        ids.push_back(p->id);
+        centers.insert(centers.end(), p->r.center, p->r.center + 3);
+    }
+    const int n = (int)ids.size();
+    if (n == 0) return 0;
+    std::vector<int32_t> counts((size_t)n);
+    if (pais_neighbor_count(m->ctx, n, centers.data(), m->neighborRadius, counts.data(), kernel_ms))
+        return mfail(pais_last_error());
+    double avg = 0;
+    for (int i = 0; i < n; ++i) avg += (double)counts[i];
+    avg /= (double)n;
+    for (int i = 0; i < n; ++i)
+        if ((double)counts[i] < (avg * neighbor_ratio)) m->deletePatch(ids[i]);
+    return 0;
+}
+
 extern "C" int pais_mvs_set_thin_front(pais_mvs *m, int thin_front)
 {
     if (!m) return mfail("pais_mvs_set_thin_front: bad argument");

@@ -35,6 +35,11 @@ def _bind(L):
     L.pais_mvs_refine_seed_patches.argtypes = [vp]
     L.pais_mvs_expansion_patches.argtypes = [vp, C.c_int, C.c_int]
     L.pais_mvs_set_thin_front.argtypes = [vp, C.c_int]
+    L.pais_mvs_load_patch.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.c_double, C.c_double]
+    L.pais_mvs_cell_filtering.argtypes = [vp]
+    L.pais_mvs_visibility_filtering.argtypes = [vp]
+    L.pais_mvs_neighbor_cell_filtering.argtypes = [vp, C.c_double]
+    L.pais_mvs_neighbor_patch_filtering.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
     L.pais_mvs_seed_begin.argtypes = [vp, C.POINTER(C.POINTER(_lib.Candidate)), C.POINTER(C.c_int)]
     L.pais_mvs_seed_commit.argtypes = [vp, C.POINTER(_lib.PatchResult), C.c_int]
     L.pais_mvs_expansion_begin.argtypes = [vp]
@@ -101,6 +106,28 @@ class MVS:
     # ---- MVS::refineSeedPatches / MVS::expansionPatches
     def refineSeedPatches(self):
         self._check(self.L.pais_mvs_refine_seed_patches(self.h), "pais_mvs_refine_seed_patches")
+
+    # ---- FileLoader::loadMvsPatch + the `-f` filter verbs (TMVS.cpp:124-172)
+    def load_patch(self, center, normalS, cam_idx, fitness, correlation) -> int:
+        cen = (C.c_double * 3)(*[float(v) for v in center])
+        ns = (C.c_double * 2)(*[float(v) for v in normalS])
+        idx = (C.c_int32 * len(cam_idx))(*[int(v) for v in cam_idx])
+        return self._check(self.L.pais_mvs_load_patch(self.h, cen, ns, len(cam_idx), idx, float(fitness), float(correlation)), "pais_mvs_load_patch")
+
+    def cellFiltering(self):
+        self._check(self.L.pais_mvs_cell_filtering(self.h), "pais_mvs_cell_filtering")
+
+    def visibilityFiltering(self):
+        self._check(self.L.pais_mvs_visibility_filtering(self.h), "pais_mvs_visibility_filtering")
+
+    def neighborCellFiltering(self, neighbor_ratio: float = 0.25):
+        self._check(self.L.pais_mvs_neighbor_cell_filtering(self.h, float(neighbor_ratio)), "pais_mvs_neighbor_cell_filtering")
+
+    def neighborPatchFiltering(self, neighbor_ratio: float = 0.25) -> float:
+        """GPU all-pairs neighbour counts; returns the kernel's milliseconds."""
+        ms = C.c_double(0)
+        self._check(self.L.pais_mvs_neighbor_patch_filtering(self.h, float(neighbor_ratio), C.byref(ms)), "pais_mvs_neighbor_patch_filtering")
+        return ms.value
 
     def set_thin_front(self, thin_front: int):
         """Rounds with <= thin_front active parents take all remaining camera slots of each parent (0 = never)."""
