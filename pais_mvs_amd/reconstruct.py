@@ -1,4 +1,5 @@
 """`python -m pais_mvs_amd.reconstruct scene.nvm [--config config.txt] [--out DIR]`
+`python -m pais_mvs_amd.reconstruct --filter cloud.mvs [--config config.txt] [--out DIR]`   (the `-f` verb, TMVS.cpp:124-172)
 
 The reference's `TMVS.exe -r` verb (TMVS.cpp:76-122) on the MI355X path: load NVM/NVM2 (+ images via PIL),
 apply config.txt on top of the compiled-in defaults, refine the seeds, expand, write exp.mvs / exp.ply /
@@ -28,20 +29,7 @@ def load_image_gray(path: str):
     return np.clip(g, 0, 255).astype(np.uint8), rgb
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("scene")
-    ap.add_argument("--config", default="config.txt")
-    ap.add_argument("--out", default=".")
-    ap.add_argument("--parents-per-round", type=int, default=4096)
-    ap.add_argument("--device", type=int, default=0)
-    a = ap.parse_args(argv)
-    cfg = default_config()
-    if os.path.exists(a.config):
-        cfg = io.load_config(a.config, cfg)
-    nvm2 = a.scene.lower().endswith(".nvm2")
-    cams_io, pts = io.load_nvm(a.scene, nvm2=nvm2)
-    base = os.path.dirname(os.path.abspath(a.scene))
+def load_cameras(cams_io, base, cfg):
     cams = []
     for c in cams_io:
         name = c.file_name.decode()
@@ -51,6 +39,52 @@ def main(argv=None):
                            quaternion=np.array(c.quaternion[:]), center=np.array(c.center[:]), image=gray, name=name,
                            rgb=rgb, radial_distortion=c.radial_distortion).finalize(cfg.lodRatio, cfg.maxLOD,
                                                                                     build_edges=cfg.adaptiveGradientEnable))
+    return cams
+
+
+def run_filtering(path: str, config: str, out: str, device: int = 0):
+    """runFiltering (TMVS.cpp:124-172): PMVS filters 1-3, then the PCMVS neighbour filter, with the reference's
+    output names."""
+    file_cfg, cams_io, pats = io.load_mvs(path)
+    cfg = file_cfg or default_config()
+    if os.path.exists(config):
+        cfg = io.load_config(config, cfg)
+    cams = load_cameras(cams_io, os.path.dirname(os.path.abspath(path)), cfg)
+    m = MVS(cfg, cams, device=device)
+    for p in pats:
+        m.load_patch(p.center[:], p.normalS[:], list(p.cam_idx[:p.num_cam]), p.fitness, p.correlation)
+    print("patches: %d" % m.num_patches())
+    t0 = time.perf_counter()
+    m.cellFiltering()
+    m.writeMVS(os.path.join(out, "PMVS_filter1.mvs")); m.writePLY(os.path.join(out, "PMVS_filter1.ply"))
+    m.visibilityFiltering()
+    m.writeMVS(os.path.join(out, "PMVS_filter2.mvs")); m.writePLY(os.path.join(out, "PMVS_filter2.ply"))
+    m.neighborCellFiltering(0.25)
+    m.writeMVS(os.path.join(out, "PMVS_filter3.mvs")); m.writePLY(os.path.join(out, "PMVS_filter3.ply"))
+    ms = m.neighborPatchFiltering(0.25)
+    m.writeMVS(os.path.join(out, "PCMVS_filter.mvs")); m.writePLY(os.path.join(out, "PCMVS_filter.ply"))
+    print("patches after filtering: %d  time %.3f s (neighbour-count kernel %.3f ms)" % (m.num_patches(), time.perf_counter() - t0, ms))
+    m.close()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("scene")
+    ap.add_argument("--filter", action="store_true", help="the -f verb: filter an .mvs cloud instead of reconstructing")
+    ap.add_argument("--config", default="config.txt")
+    ap.add_argument("--out", default=".")
+    ap.add_argument("--parents-per-round", type=int, default=4096)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.filter:
+        return run_filtering(a.scene, a.config, a.out, a.device)
+    cfg = default_config()
+    if os.path.exists(a.config):
+        cfg = io.load_config(a.config, cfg)
+    nvm2 = a.scene.lower().endswith(".nvm2")
+    cams_io, pts = io.load_nvm(a.scene, nvm2=nvm2)
+    base = os.path.dirname(os.path.abspath(a.scene))
+    cams = load_cameras(cams_io, base, cfg)
     m = MVS(cfg, cams, device=a.device)
     for p in pts:
         m.add_seed(p.center[:], list(p.cam_idx[:p.num_meas]))

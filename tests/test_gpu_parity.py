@@ -440,3 +440,53 @@ def test_edge_cases(pawn_small):
     with pytest.raises(RuntimeError):
         ctx.fitness_batch([st], [0], [[0.0, 0.0, 1.0]])
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_file_level_verbs_reconstruct_then_filter(tmp_path, pawn_small):
+    """`-r` then `-f` from files (TMVS.cpp:76-172): NVM2 + PNG images in, seed/exp .mvs/.ply/.psr out, then the filter
+    chain on exp.mvs.  The cloud written must be the cloud the in-memory driver produces from the same inputs."""
+    from PIL import Image
+    from pais_mvs_amd import io, reconstruct
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    d = tmp_path
+    lines = ["NVM_V3", "", str(len(pawn_small.cameras))]
+    for i, cam in enumerate(pawn_small.cameras):
+        name = "cam%d.png" % i
+        Image.fromarray(np.repeat(cam.pyramid[0][:, :, None], 3, axis=2)).save(str(d / name))
+        lines.append("%s %r %r %r %r %s %s" % (name, float(cam.focal[0]), float(cam.focal[1]), float(cam.principle_point[0]),
+                                               float(cam.principle_point[1]), " ".join(repr(float(v)) for v in cam.quaternion),
+                                               " ".join(repr(float(v)) for v in cam.center)))
+    lines += ["", str(len(pawn_small.seeds))]
+    for X, vis in pawn_small.seeds:
+        meas = " ".join("%d 0 0.0 0.0" % c for c in vis)
+        lines.append("%r %r %r 128 128 128 %d %s" % (float(X[0]), float(X[1]), float(X[2]), len(vis), meas))
+    lines += ["", "0"]
+    (d / "scene.nvm2").write_text("\n".join(lines) + "\n")
+    (d / "config.txt").write_text("particleNum 6\nmaxIteration 8\n")
+    reconstruct.main([str(d / "scene.nvm2"), "--config", str(d / "config.txt"), "--out", str(d)])
+    for f in ("seed.mvs", "exp.mvs", "exp.ply", "exp.psr"):
+        assert (d / f).stat().st_size > 0
+    cfg_file, cams_io, pats = io.load_mvs(str(d / "exp.mvs"))
+    assert len(cams_io) == len(pawn_small.cameras) and len(pats) > len(pawn_small.seeds)
+    # the same inputs through the in-memory driver
+    cfg = io.load_config(str(d / "config.txt"), reconstruct.default_config())
+    cams = reconstruct.load_cameras(io.load_nvm(str(d / "scene.nvm2"), nvm2=True)[0], str(d), cfg)
+    m = MVS(cfg, cams, device=0)
+    for X, vis in pawn_small.seeds:
+        m.add_seed(X, vis)
+    m.refineSeedPatches()
+    m.expansionPatches(4096, 0)
+    mine = m.patches()
+    assert len(mine) == len(pats)
+    for a, b in zip(mine, pats):
+        assert list(a.center[:]) == list(b.center[:]) and list(a.normalS[:]) == list(b.normalS[:]) and a.fitness == b.fitness
+    m.close()
+    # `-f`
+    reconstruct.main([str(d / "exp.mvs"), "--filter", "--config", str(d / "config.txt"), "--out", str(d)])
+    n_prev = len(pats)
+    for f in ("PMVS_filter1.mvs", "PMVS_filter2.mvs", "PMVS_filter3.mvs", "PCMVS_filter.mvs"):
+        n = len(io.load_mvs(str(d / f))[2])
+        assert 0 < n <= n_prev
+        n_prev = n
