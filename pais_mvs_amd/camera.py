@@ -135,6 +135,40 @@ def sobel_magnitude_normalised(img: np.ndarray) -> np.ndarray:
     return np.zeros_like(mag)
 
 
+def build_pyramid_gpu(image: np.ndarray, lod_ratio: float, cfg_max_lod: int, build_edges: bool, device: int = 0):
+    """Camera::Camera's pyramid and edge maps on the MI355X (include/pais_pyramid.h): returns
+    (levels, edges, kernel_ms) with the same arrays resize_area / sobel_magnitude_normalised produce on the host."""
+    import ctypes as C
+    from . import _lib
+
+    class _Pyr(C.Structure):
+        _fields_ = [("max_lod", C.c_int), ("width", C.c_int * 16), ("height", C.c_int * 16),
+                    ("image", C.POINTER(C.c_uint8) * 16), ("edge", C.POINTER(C.c_double) * 16), ("kernel_ms", C.c_double)]
+    L = _lib.load()
+    L.pais_pyramid_build.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_int, C.c_int,
+                                     C.POINTER(C.POINTER(_Pyr))]
+    L.pais_pyramid_free.argtypes = [C.POINTER(_Pyr)]
+    L.pais_pyramid_free.restype = None
+    L.pais_pyramid_last_error.restype = C.c_char_p
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = img.shape
+    out = C.POINTER(_Pyr)()
+    rc = L.pais_pyramid_build(device, img.ctypes.data, w, h, w, float(lod_ratio), int(cfg_max_lod), 1 if build_edges else 0, C.byref(out))
+    if rc:
+        raise RuntimeError("pais_pyramid_build failed (%d): %s" % (rc, L.pais_pyramid_last_error().decode()))
+    try:
+        p = out.contents
+        levels, edges = [], []
+        for l in range(p.max_lod + 1):
+            n = p.width[l] * p.height[l]
+            levels.append(np.ctypeslib.as_array(p.image[l], shape=(n,)).reshape(p.height[l], p.width[l]).copy())
+            if build_edges:
+                edges.append(np.ctypeslib.as_array(p.edge[l], shape=(n,)).reshape(p.height[l], p.width[l]).copy())
+        return levels, edges, p.kernel_ms
+    finally:
+        L.pais_pyramid_free(out)
+
+
 @dataclass
 class Camera:
     """Host mirror of PAIS::Camera (mvs/camera.h:15-149)."""
@@ -157,7 +191,8 @@ class Camera:
     pyramid: List[np.ndarray] = field(default_factory=list)
     edge_pyramid: List[np.ndarray] = field(default_factory=list)
 
-    def finalize(self, lod_ratio: float, cfg_max_lod: int, build_edges: bool = True) -> "Camera":
+    def finalize(self, lod_ratio: float, cfg_max_lod: int, build_edges: bool = True, device: Optional[int] = None) -> "Camera":
+        """device: build the pyramid / edge maps with the HIP kernels on that GPU (identical arrays) instead of numpy."""
         self.focal = np.asarray(self.focal, dtype=np.float64).reshape(2)
         self.quaternion = np.asarray(self.quaternion, dtype=np.float64).reshape(4)
         self.center = np.asarray(self.center, dtype=np.float64).reshape(3)
@@ -177,6 +212,10 @@ class Camera:
         self.KT = np.array([K[i, 0] * T[0] + K[i, 1] * T[1] + K[i, 2] * T[2] for i in range(3)])
         self.optical_normal = np.array([R[0, i] * 0.0 + R[1, i] * 0.0 + R[2, i] * 1.0 for i in range(3)])
         self.max_lod = max_lod(w, h, lod_ratio, cfg_max_lod)
+        if device is not None:
+            self.pyramid, self.edge_pyramid, _ = build_pyramid_gpu(self.image, lod_ratio, cfg_max_lod, build_edges, device)
+            assert len(self.pyramid) == self.max_lod + 1
+            return self
         self.pyramid = [np.ascontiguousarray(self.image, dtype=np.uint8)]
         for i in range(1, self.max_lod + 1):
             self.pyramid.append(np.ascontiguousarray(resize_area(self.pyramid[0], lod_ratio ** i)))

@@ -33,7 +33,7 @@ def main(names):
         open(p, "w").write(s)
         so = os.path.join(OUT, "libpais_%s.so" % name)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-Wno-unused-result"] + [os.path.join(tmp, f) for f in ("pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip")] + ["-o", so])
+                               "-Wno-unused-result"] + [os.path.join(tmp, f) for f in ("pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip")] + ["-o", so])
         print("built", so)
 if __name__ == "__main__":
     main(sys.argv[1:] or list(VARS))

@@ -19,7 +19,7 @@ def _declared(header):
 def test_library_exports_every_declared_symbol():
     from pais_mvs_amd import _lib
     L = _lib.load()
-    names = _declared("pais_hip.h") + _declared("pais_mvs.h")
+    names = _declared("pais_hip.h") + _declared("pais_mvs.h") + _declared("pais_io.h") + _declared("pais_pyramid.h")
     assert len(names) >= 30
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
@@ -54,6 +54,9 @@ def test_no_gpu_means_loud_failure(pawn_small):
     with pytest.raises(RuntimeError):
         m.expansionPatches(4, 1)
     m.close()
+    from pais_mvs_amd.camera import build_pyramid_gpu
+    with pytest.raises(RuntimeError):
+        build_pyramid_gpu(pawn_small.cameras[0].pyramid[0], 0.8, 15, True, device=0)
 
 
 def test_product_does_not_touch_the_oracle():

@@ -490,3 +490,22 @@ def test_file_level_verbs_reconstruct_then_filter(tmp_path, pawn_small):
         n = len(io.load_mvs(str(d / f))[2])
         assert 0 < n <= n_prev
         n_prev = n
+
+
+@pytest.mark.gpu
+def test_pyramid_construction_on_gpu_is_the_host_restatement():
+    """N2 (camera.cpp:45-136): INTER_AREA resize chain from level 0, Sobel(ksize 1) magnitude, min-max -- the HIP
+    kernels must reproduce camera.py's arrays exactly (uchar levels and double edge maps), odd sizes included."""
+    from pais_mvs_amd.camera import build_pyramid_gpu, resize_area, sobel_magnitude_normalised, max_lod
+    rng = np.random.default_rng(3)
+    for (h, w) in ((480, 640), (271, 353), (1080, 1920)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (127 + 80 * np.sin(xx / 7.3) * np.cos(yy / 5.1) + rng.normal(0, 20, (h, w))).clip(0, 255).astype(np.uint8)
+        levels, edges, ms = build_pyramid_gpu(img, 0.8, 15, True, device=0)
+        assert len(levels) == max_lod(w, h, 0.8, 15) + 1 and len(edges) == len(levels) and ms > 0
+        assert np.array_equal(levels[0], img)
+        for i in range(1, len(levels)):
+            want = resize_area(img, 0.8 ** i)
+            assert levels[i].shape == want.shape and np.array_equal(levels[i], want), (h, w, i)
+        for i in range(len(levels)):
+            assert np.array_equal(edges[i], sobel_magnitude_normalised(levels[i])), (h, w, i)
