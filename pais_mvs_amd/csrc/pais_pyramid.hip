@@ -105,29 +105,46 @@ __global__ __launch_bounds__(256) void k_area_cols(const double *tmp, int w, con
     out[(size_t)dy * dw + dx] = (uint8_t)r;
 }
 // Sobel(ksize = 1): central differences with reflect-101 borders, magnitude; min / max of the level through
-// ordered-bit atomics (magnitudes are >= 0, so their bit patterns order like the values)
+// ordered-bit atomics (magnitudes are >= 0, so their bit patterns order like the values).  A workgroup sweeps a
+// 256 x SOBEL_ROWS tile and issues ONE atomic pair (all waves hammering two addresses was 90 % of the build time).
+#define SOBEL_ROWS 16
 __global__ __launch_bounds__(256) void k_sobel_mag(const uint8_t *img, int w, int h, double *mag, unsigned long long *minmax)
 {
+    __shared__ unsigned long long red[8];
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    double m = 0;
-    bool has = x < w && y < h;
-    if (has) {
+    unsigned long long lo = ~0ULL, hi = 0ULL;
+    if (x < w) {
         const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
-        const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-        const double gx = (double)img[(size_t)y * w + xr] - (double)img[(size_t)y * w + xl];
-        const double gy = (double)img[(size_t)yd * w + x] - (double)img[(size_t)yu * w + x];
-        m = sqrt(gx * gx + gy * gy);
-        mag[(size_t)y * w + x] = m;
+        for (int r = 0; r < SOBEL_ROWS; ++r) {
+            const int y = blockIdx.y * SOBEL_ROWS + r;
+            if (y >= h) break;
+            const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+            const double gx = (double)img[(size_t)y * w + xr] - (double)img[(size_t)y * w + xl];
+            const double gy = (double)img[(size_t)yd * w + x] - (double)img[(size_t)yu * w + x];
+            const double m = sqrt(gx * gx + gy * gy);
+            mag[(size_t)y * w + x] = m;
+            const unsigned long long u = (unsigned long long)__double_as_longlong(m);
+            lo = u < lo ? u : lo;
+            hi = u > hi ? u : hi;
+        }
     }
-    unsigned long long lo = has ? (unsigned long long)__double_as_longlong(m) : ~0ULL, hi = has ? lo : 0ULL;
     for (int s = 32; s >= 1; s >>= 1) {
         const unsigned long long ol = __shfl_xor(lo, s, 64), oh = __shfl_xor(hi, s, 64);
         lo = ol < lo ? ol : lo;
         hi = oh > hi ? oh : hi;
     }
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&minmax[0], lo);
+        red[wave] = lo;
+        red[4 + wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q) {
+            lo = red[q] < lo ? red[q] : lo;
+            hi = red[4 + q] > hi ? red[4 + q] : hi;
+        }
+        if (lo != ~0ULL) atomicMin(&minmax[0], lo);
         atomicMax(&minmax[1], hi);
     }
 }
@@ -232,7 +249,7 @@ extern "C" int pais_pyramid_build(int device, const uint8_t *level0, int width, 
         if (build_edges) {
             const unsigned long long init[2] = {~0ULL, 0ULL};
             PCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_sobel_mag, dim3((lw + 255) / 256, lh), dim3(256), 0, st, d_src, lw, lh, d_mag, d_mm);
+            hipLaunchKernelGGL(k_sobel_mag, dim3((lw + 255) / 256, (lh + SOBEL_ROWS - 1) / SOBEL_ROWS), dim3(256), 0, st, d_src, lw, lh, d_mag, d_mm);
             const size_t n = (size_t)lw * lh;
             hipLaunchKernelGGL(k_edge_normalise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mag, n, d_mm);
             PCHK(hipGetLastError());
