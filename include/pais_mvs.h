@@ -62,6 +62,12 @@ int  pais_mvs_reset(pais_mvs *m);
  * setEstimatedNormal :390-413).  Returns the patch id (>= 0) or < 0. */
 int  pais_mvs_add_seed(pais_mvs *m, const double center[3], int num_cam, const int32_t *cam_idx);
 
+/* NVM seed with its measurements (image points in pixels, num_cam x 2: FileLoader::loadNvmPatch adds cols/2, rows/2
+ * to the file's offsets, fileloader.cpp:155-160).  recenter != 0: MVS::reCentering first (mvs.cpp:134-145,
+ * patch.cpp:67-112) -- the point closest to the viewing rays, A.inv(DECOMP_SVD) * b -- as loadNVM does. */
+int  pais_mvs_add_seed_measured(pais_mvs *m, const double center[3], int num_cam, const int32_t *cam_idx,
+                                const double *img_points, int recenter);
+
 /* MVS::refineSeedPatches (mvs.cpp:196-231), one GPU batch. */
 int  pais_mvs_refine_seed_patches(pais_mvs *m);
 /* MVS::expansionPatches (mvs.cpp:233-275) in rounds of `parents_per_round`

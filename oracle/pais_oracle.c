@@ -1635,6 +1635,51 @@ int po_mvs_add_seed(po_mvs *m, const double center[3], int numCam, const int *ca
     return mvs_store(m, &p);
 }
 
+/* Patch::reCentering, patch.cpp:67-112 (A.inv(DECOMP_SVD) * b through the SVD back-substitution of the identity) */
+void po_recenter(const po_scene *s, int numCam, const int *camIdx, const double *imgPoints, double center[3])
+{
+    double A[9] = {0}, b[3] = {0, 0, 0};
+    for (int i = 0; i < numCam; ++i) {
+        const po_camera *cam = &s->cams[camIdx[i]];
+        const double p3[3] = {(imgPoints[2 * i] - cam->pp[0]) / cam->focal[0] - cam->T[0],
+                              (imgPoints[2 * i + 1] - cam->pp[1]) / cam->focal[1] - cam->T[1], 1.0 - cam->T[2]};
+        double w3[3];
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0;
+            for (int k = 0; k < 3; ++k) acc += cam->R[k * 3 + r] * p3[k];
+            w3[r] = acc;
+        }
+        double n[3] = {w3[0] - cam->C[0], w3[1] - cam->C[1], w3[2] - cam->C[2]};
+        const double sc = (1.0 / norm3(n));
+        for (int k = 0; k < 3; ++k) n[k] = n[k] * sc;
+        const double *cc = cam->C;
+        A[0] += 1 - n[0] * n[0];
+        A[1] += -n[0] * n[1];
+        A[2] += -n[0] * n[2];
+        A[3] += -n[0] * n[1];
+        A[4] += 1 - n[1] * n[1];
+        A[5] += -n[1] * n[2];
+        A[6] += -n[0] * n[2];
+        A[7] += -n[1] * n[2];
+        A[8] += 1 - n[2] * n[2];
+        b[0] += (1 - n[0] * n[0]) * cc[0] - n[0] * n[1] * cc[1] - n[0] * n[2] * cc[2];
+        b[1] += -n[0] * n[1] * cc[0] + (1 - n[1] * n[1]) * cc[1] - n[1] * n[2] * cc[2];
+        b[2] += -n[0] * n[2] * cc[0] - n[1] * n[2] * cc[1] + (1 - n[2] * n[2]) * cc[2];
+    }
+    double inv[9];
+    for (int j = 0; j < 3; ++j) {
+        double e[3] = {0, 0, 0}, col[3];
+        e[j] = 1.0;
+        svd_solve(3, 3, A, e, col);
+        for (int r = 0; r < 3; ++r) inv[r * 3 + j] = col[r];
+    }
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += inv[r * 3 + k] * b[k];
+        center[r] = acc;
+    }
+}
+
 int po_mvs_num_patches(const po_mvs *m) { return m->nalive; }
 int po_mvs_num_slots(const po_mvs *m) { return m->nslots; }
 const po_patch *po_mvs_get_patch(const po_mvs *m, int id)

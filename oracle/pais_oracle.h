@@ -221,6 +221,8 @@ long    po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail
  * parent instead of one (0 = never).  Same rule and default as pais_mvs_set_thin_front (include/pais_mvs.h). */
 #define PO_DEFAULT_THIN_FRONT 64
 void    po_mvs_set_thin_front(po_mvs *m, int thinFront);
+/* Patch::reCentering (patch.cpp:67-112): imgPoints numCam x 2 pixels -> center */
+void    po_recenter(const po_scene *s, int numCam, const int *camIdx, const double *imgPoints, double center[3]);
 /* post filters (`-f` verb, TMVS.cpp:124-172; mvs.cpp:278-524) and the .mvs loader constructor (patch.cpp:45-59) */
 int     po_mvs_load_patch(po_mvs *m, const double center[3], const double normalS[2], int numCam, const int *camIdx,
                           double fitness, double correlation);

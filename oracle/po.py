@@ -155,6 +155,7 @@ def lib():
     L.po_mvs_set_neighbor_radius.argtypes = [C.c_void_p]
     L.po_mvs_refine_seed_patches.argtypes = [C.c_void_p]
     L.po_mvs_set_thin_front.argtypes = [C.c_void_p, C.c_int]
+    L.po_recenter.argtypes = [C.POINTER(SceneS), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.po_mvs_load_patch.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_double, C.c_double]
     L.po_mvs_cell_filtering.argtypes = [C.c_void_p]
     L.po_mvs_visibility_filtering.argtypes = [C.c_void_p]

@@ -224,7 +224,8 @@ PAIS_HD void jacobi_lstsq(double (&A)[N][M], const double (&b)[N], double (&x)[M
         double ub = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k) ub += A[k][j] * b[k];
-        double coef = ub / w2[j];
+        const double wj = sqrt(w2[j]);
+        double coef = ub / (wj * wj); // U_j = Ut_j / w_j: (Ut_j . b) / w_j^2 with the singular value itself, as the oracle
 #pragma unroll
         for (int i = 0; i < M; ++i) x[i] += V[i][j] * coef;
     }

@@ -526,6 +526,73 @@ extern "C" int pais_mvs_add_seed(pais_mvs *m, const double center[3], int num_ca
     return m->storePatch(r);
 }
 
+// NVM seed with its image measurements (FileLoader::loadNvmPatch, fileloader.cpp:112-165: img_points are the file's
+// offsets plus cols/2, rows/2) and, if `recenter`, MVS::reCentering / Patch::reCentering (mvs.cpp:134-145,
+// patch.cpp:67-112): the point closest to the viewing rays through the measurements (normal equations summed over
+// the cameras, solved with A.inv(DECOMP_SVD) * b), then setEstimatedNormal.  SURVEY 8(f) N4.
+extern "C" int pais_mvs_add_seed_measured(pais_mvs *m, const double center[3], int num_cam, const int32_t *cam_idx,
+                                          const double *img_points, int recenter)
+{
+    if (!m || !center || num_cam < 0 || num_cam > PAIS_MAX_VIS || (num_cam && (!cam_idx || !img_points)))
+        return mfail("pais_mvs_add_seed_measured: bad argument");
+    for (int i = 0; i < num_cam; ++i)
+        if (cam_idx[i] < 0 || cam_idx[i] >= (int)m->cams.size()) return mfail("pais_mvs_add_seed_measured: bad camera index");
+    double c[3] = {center[0], center[1], center[2]};
+    if (recenter) {
+        double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, b[3] = {0, 0, 0};
+        for (int i = 0; i < num_cam; ++i) {
+            const HostCamera &cam = m->cams[cam_idx[i]];
+            // pixel on the z = 1 plane of the camera, to world: R^T (p - T)
+            const double p3[3] = {(img_points[2 * i] - cam.pp[0]) / cam.focal[0] - cam.T[0],
+                                  (img_points[2 * i + 1] - cam.pp[1]) / cam.focal[1] - cam.T[1], 1.0 - cam.T[2]};
+            double w3[3];
+            for (int r = 0; r < 3; ++r) { // gemm order: k = 0..2
+                double sacc = 0;
+                for (int k = 0; k < 3; ++k) sacc += cam.R[k * 3 + r] * p3[k];
+                w3[r] = sacc;
+            }
+            double n[3] = {w3[0] - cam.C[0], w3[1] - cam.C[1], w3[2] - cam.C[2]};
+            const double sc = (1.0 / pais::norm3(n));
+            for (int k = 0; k < 3; ++k) n[k] = n[k] * sc;
+            const double *cc = cam.C;
+            A[0][0] += 1 - n[0] * n[0];
+            A[0][1] += -n[0] * n[1];
+            A[0][2] += -n[0] * n[2];
+            A[1][0] += -n[0] * n[1];
+            A[1][1] += 1 - n[1] * n[1];
+            A[1][2] += -n[1] * n[2];
+            A[2][0] += -n[0] * n[2];
+            A[2][1] += -n[1] * n[2];
+            A[2][2] += 1 - n[2] * n[2];
+            b[0] += (1 - n[0] * n[0]) * cc[0] - n[0] * n[1] * cc[1] - n[0] * n[2] * cc[2];
+            b[1] += -n[0] * n[1] * cc[0] + (1 - n[1] * n[1]) * cc[1] - n[1] * n[2] * cc[2];
+            b[2] += -n[0] * n[2] * cc[0] - n[1] * n[2] * cc[1] + (1 - n[2] * n[2]) * cc[2];
+        }
+        // A.inv(DECOMP_SVD): SVD back-substitution of the identity, column by column; then inv * b
+        double inv[3][3];
+        for (int j = 0; j < 3; ++j) {
+            double Ac[3][3], e[3] = {0, 0, 0}, col[3];
+            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 3; ++k) Ac[r][k] = A[r][k];
+            e[j] = 1.0;
+            pais::jacobi_lstsq<3, 3>(Ac, e, col);
+            for (int r = 0; r < 3; ++r) inv[r][j] = col[r];
+        }
+        for (int r = 0; r < 3; ++r) {
+            double sacc = 0;
+            for (int k = 0; k < 3; ++k) sacc += inv[r][k] * b[k];
+            c[r] = sacc;
+        }
+    }
+    const int id = pais_mvs_add_seed(m, c, num_cam, cam_idx);
+    if (id >= 0)
+        for (int i = 0; i < num_cam; ++i) {
+            m->patches[id]->r.imgPoint[i][0] = img_points[2 * i];
+            m->patches[id]->r.imgPoint[i][1] = img_points[2 * i + 1];
+        }
+    return id;
+}
+
 extern "C" int pais_mvs_seed_begin(pais_mvs *m, const pais_candidate **cands, int *n)
 {
     if (!m || !cands || !n) return mfail("pais_mvs_seed_begin: bad argument");

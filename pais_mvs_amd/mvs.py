@@ -35,6 +35,7 @@ def _bind(L):
     L.pais_mvs_refine_seed_patches.argtypes = [vp]
     L.pais_mvs_expansion_patches.argtypes = [vp, C.c_int, C.c_int]
     L.pais_mvs_set_thin_front.argtypes = [vp, C.c_int]
+    L.pais_mvs_add_seed_measured.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]
     L.pais_mvs_load_patch.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.c_double, C.c_double]
     L.pais_mvs_cell_filtering.argtypes = [vp]
     L.pais_mvs_visibility_filtering.argtypes = [vp]
@@ -102,6 +103,15 @@ class MVS:
         cen = (C.c_double * 3)(*[float(v) for v in center])
         idx = (C.c_int32 * len(cam_idx))(*[int(v) for v in cam_idx])
         return self._check(self.L.pais_mvs_add_seed(self.h, cen, len(cam_idx), idx), "pais_mvs_add_seed")
+
+    def add_seed_measured(self, center, cam_idx, img_points, recenter: bool = True) -> int:
+        """NVM seed with its image measurements (pixels); recenter: MVS::reCentering first, as loadNVM does."""
+        cen = (C.c_double * 3)(*[float(v) for v in center])
+        idx = (C.c_int32 * len(cam_idx))(*[int(v) for v in cam_idx])
+        flat = [float(v) for p in img_points for v in p]
+        pts = (C.c_double * len(flat))(*flat)
+        return self._check(self.L.pais_mvs_add_seed_measured(self.h, cen, len(cam_idx), idx, pts, 1 if recenter else 0),
+                           "pais_mvs_add_seed_measured")
 
     # ---- MVS::refineSeedPatches / MVS::expansionPatches
     def refineSeedPatches(self):

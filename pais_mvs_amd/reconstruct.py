@@ -3,8 +3,8 @@
 
 The reference's `TMVS.exe -r` verb (TMVS.cpp:76-122) on the MI355X path: load NVM/NVM2 (+ images via PIL),
 apply config.txt on top of the compiled-in defaults, refine the seeds, expand, write exp.mvs / exp.ply /
-exp.psr.  Seed triangulation (`reCentering`, patch.cpp:67-112) and SIFT seeding are not part of this path
-(SURVEY 8f N4): NVM points are used as they are."""
+exp.psr.  NVM points are re-triangulated from their measurements like MVS::loadNVM does (`reCentering`,
+patch.cpp:67-112); SIFT seeding (featuremanager.cpp) is not part of this repository."""
 from __future__ import annotations
 
 import argparse
@@ -75,6 +75,7 @@ def main(argv=None):
     ap.add_argument("--out", default=".")
     ap.add_argument("--parents-per-round", type=int, default=4096)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--no-recenter", action="store_true", help="keep the NVM points as they are (skip MVS::reCentering)")
     a = ap.parse_args(argv)
     if a.filter:
         return run_filtering(a.scene, a.config, a.out, a.device)
@@ -87,7 +88,11 @@ def main(argv=None):
     cams = load_cameras(cams_io, base, cfg)
     m = MVS(cfg, cams, device=a.device)
     for p in pts:
-        m.add_seed(p.center[:], list(p.cam_idx[:p.num_meas]))
+        # FileLoader::loadNvmPatch (fileloader.cpp:155-160): measurements are offsets from the image centre;
+        # MVS::loadNVM then re-triangulates every point (reCentering, mvs.cpp:160-168)
+        idx = list(p.cam_idx[:p.num_meas])
+        meas = [[p.xy[i][0] + cams[c].width // 2, p.xy[i][1] + cams[c].height // 2] for i, c in enumerate(idx)]
+        m.add_seed_measured(p.center[:], idx, meas, recenter=not a.no_recenter)
     t0 = time.perf_counter()
     m.refineSeedPatches()
     m.writeMVS(os.path.join(a.out, "seed.mvs"))

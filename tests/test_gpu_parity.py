@@ -459,9 +459,17 @@ def test_file_level_verbs_reconstruct_then_filter(tmp_path, pawn_small):
                                                float(cam.principle_point[1]), " ".join(repr(float(v)) for v in cam.quaternion),
                                                " ".join(repr(float(v)) for v in cam.center)))
     lines += ["", str(len(pawn_small.seeds))]
+    seeds_meas = []
     for X, vis in pawn_small.seeds:
-        meas = " ".join("%d 0 0.0 0.0" % c for c in vis)
-        lines.append("%r %r %r 128 128 128 %d %s" % (float(X[0]), float(X[1]), float(X[2]), len(vis), meas))
+        ms = []
+        for c in vis:
+            cam = pawn_small.cameras[c]
+            q = cam.rotation @ np.asarray(X, float) + cam.translation
+            u, v = cam.focal[0] * q[0] / q[2] + cam.principle_point[0], cam.focal[1] * q[1] / q[2] + cam.principle_point[1]
+            ms.append((c, u - cam.width // 2, v - cam.height // 2))
+        seeds_meas.append(ms)
+        meas = " ".join("%d 0 %r %r" % (c, float(du), float(dv)) for c, du, dv in ms)
+        lines.append("%r %r %r 128 128 128 %d %s" % (float(X[0]) + 0.01, float(X[1]) - 0.01, float(X[2]) + 0.02, len(vis), meas))
     lines += ["", "0"]
     (d / "scene.nvm2").write_text("\n".join(lines) + "\n")
     (d / "config.txt").write_text("particleNum 6\nmaxIteration 8\n")
@@ -474,8 +482,10 @@ def test_file_level_verbs_reconstruct_then_filter(tmp_path, pawn_small):
     cfg = io.load_config(str(d / "config.txt"), reconstruct.default_config())
     cams = reconstruct.load_cameras(io.load_nvm(str(d / "scene.nvm2"), nvm2=True)[0], str(d), cfg)
     m = MVS(cfg, cams, device=0)
-    for X, vis in pawn_small.seeds:
-        m.add_seed(X, vis)
+    for (X, vis), ms in zip(pawn_small.seeds, seeds_meas):
+        pid = m.add_seed_measured([X[0] + 0.01, X[1] - 0.01, X[2] + 0.02], vis,
+                                  [[du + cams[c].width // 2, dv + cams[c].height // 2] for c, du, dv in ms], recenter=True)
+        assert np.linalg.norm(np.array(m.get_patch(pid).center[:]) - np.asarray(X, float)) < 1e-9   # re-triangulated
     m.refineSeedPatches()
     m.expansionPatches(4096, 0)
     mine = m.patches()

@@ -130,3 +130,38 @@ def test_one_parent_per_round_is_the_reference_order_for_any_thin_front(pawn_sma
     a, calls_a, _ = _run_oracle(cfg, pawn_small, 1, 0, 0)
     b, calls_b, _ = _run_oracle(cfg, pawn_small, 1, 0, 64)
     assert a == b and calls_a == calls_b and len(a) > len(pawn_small.seeds)
+
+
+def test_recentering_of_nvm_seeds(pawn_small):
+    """N4: MVS::reCentering (patch.cpp:67-112) -- the product's host statement equals the oracle's bit for bit, and with
+    exact measurements it returns the point the measurements came from."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    cfg = readme_config()
+    S = common.oracle_scene(cfg, pawn_small)
+    L = po.lib()
+    m = MVS(cfg, pawn_small.cameras, device=-1, seed=42)
+    rng = np.random.default_rng(11)
+    for X, vis in pawn_small.seeds[:40]:
+        X = np.asarray(X, float)
+        pts = []
+        for c in vis:
+            cam = pawn_small.cameras[c]
+            q = cam.rotation @ X + cam.translation
+            pts.append([cam.focal[0] * q[0] / q[2] + cam.principle_point[0], cam.focal[1] * q[1] / q[2] + cam.principle_point[1]])
+        start = X + rng.normal(0, 0.05, 3)                    # what an SfM point looks like before re-triangulation
+        for noise in (0.0, 0.7):
+            meas = [[p[0] + rng.normal(0, noise), p[1] + rng.normal(0, noise)] for p in pts]
+            flat = [v for p in meas for v in p]
+            want = (C.c_double * 3)()
+            L.po_recenter(S.ptr, len(vis), po.iarr(vis), po.darr(flat), want)
+            pid = m.add_seed_measured(start, vis, meas, recenter=True)
+            got = m.get_patch(pid)
+            assert list(got.center[:]) == list(want[:])
+            assert [list(got.imgPoint[k]) for k in range(len(vis))] == meas
+            if noise == 0.0:
+                assert np.linalg.norm(np.array(got.center[:]) - X) < 1e-9
+        pid = m.add_seed_measured(start, vis, pts, recenter=False)
+        assert list(m.get_patch(pid).center[:]) == list(start)
+    m.close()
