@@ -40,7 +40,7 @@ if f:
         if nl:
             raw=tot*1024.0/nl
             json.dump({"k_pso_iter_hbm_read_bytes_per_launch": 2.0*raw, "raw_fetch_size_bytes_per_launch": raw, "launches": nl,
-                       "note": "rocprofv3 --pmc FETCH_SIZE (KiB) summed over the k_pso_iter dispatches of 'bench.py --steps 1 --warmup 0' / launches, x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated for wide coalesced reads only, so an upper bound for these 2-byte gathers)"},
+                       "note": "rocprofv3 --pmc FETCH_SIZE (KiB) summed over the k_pso_iter dispatches of 'bench.py --steps 1 --warmup 0' / launches, x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated for wide coalesced reads only, so an upper bound for these 8-byte gathers)"},
                       open("gpurun_out/${tag}_pmc_traffic.json","w"))
 else:
     print("no db (see log)")
