@@ -30,14 +30,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     pickle.dump(res, open(sys.argv[2], "wb"))
     sys.exit(0)
 outs = {}
-for mode in ("split", "persist"):
+MODES = ("iter", "split", "laststep", "persist", "fused")
+for mode in MODES:
     env = dict(os.environ, PAIS_PSO_MODE=mode)
     f = "/tmp/dbg_%s.pkl" % mode
-    subprocess.check_call([sys.executable, __file__, "child", f], env=env)
+    subprocess.check_call([sys.executable, __file__, "child", f], env=env, stdout=subprocess.DEVNULL, timeout=300)
     outs[mode] = pickle.load(open(f, "rb"))
-a, b = outs["split"], outs["persist"]
-diff = [i for i in range(len(a)) if a[i] != b[i]]
-print("n", len(a), "differing", len(diff))
-for i in diff[:12]:
-    print(i, "split", a[i][:5], "persist", b[i][:5], b[i][7])
-print("dropped split", sum(x[0] for x in a), "persist", sum(x[0] for x in b))
+ref = outs["iter"]
+for mode in MODES[1:]:
+    b = outs[mode]
+    diff = [i for i in range(len(ref)) if i >= len(b) or ref[i] != b[i]]
+    print("%-9s records %d  differing from the default pipeline: %d" % (mode, len(b), len(diff)))
+    for i in diff[:4]:
+        print("   ", i, "iter", ref[i][:5], mode, b[i][:5] if i < len(b) else None)

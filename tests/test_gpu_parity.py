@@ -519,3 +519,33 @@ def test_pyramid_construction_on_gpu_is_the_host_restatement():
             assert levels[i].shape == want.shape and np.array_equal(levels[i], want), (h, w, i)
         for i in range(len(levels)):
             assert np.array_equal(edges[i], sobel_magnitude_normalised(levels[i])), (h, w, i)
+
+
+@pytest.mark.gpu
+def test_alternative_pso_pipelines_are_bit_identical(pawn_small, monkeypatch):
+    """the measured alternatives (PAIS_PSO_MODE = split / laststep / persist / fused) and every
+    waves-per-evaluation setting of the default pipeline produce the same records bit for bit."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import Context
+    cfg = readme_config()
+    S = common.oracle_scene(cfg, pawn_small)
+    _, cands = common.seed_candidates(S, pawn_small)
+    cands = cands[:24]
+
+    def run():
+        ctx = Context(cfg, pawn_small.cameras, device=0, seed=42)
+        res = ctx.refine_batch(cands)
+        out = [(r.dropped, r.pso_runs, r.pso_iterations, r.pso_evals, r.fitness, list(r.center[:]), list(r.normal[:]), r.cams())
+               for r in res]
+        ctx.close()
+        return out
+
+    ref = run()
+    assert any(not r[0] for r in ref)
+    for mode in ("split", "laststep", "persist", "fused"):
+        monkeypatch.setenv("PAIS_PSO_MODE", mode)
+        assert run() == ref, mode
+    monkeypatch.delenv("PAIS_PSO_MODE")
+    for parts in ("1", "2", "4"):
+        monkeypatch.setenv("PAIS_EVAL_PARTS", parts)
+        assert run() == ref, parts
