@@ -28,6 +28,16 @@ def shard_bounds(n: int, rank: int, world: int):
     return per, lo, hi
 
 
+REPLICATE_BELOW_PER_RANK = 64
+
+
+def replicate_round(n: int, world: int) -> bool:
+    """Rounds with fewer than 64 candidates per rank are latency bound on one GPU already: sharding them cannot
+    make them faster and the all-gather + synchronisation only adds to the round.  Every rank then refines the whole
+    round itself -- the refinement is deterministic, so the replicas agree bit for bit and no exchange is needed."""
+    return world > 1 and n < REPLICATE_BELOW_PER_RANK * world
+
+
 def _cand_bytes(cands_ptr, n: int) -> np.ndarray:
     if n == 0:
         return np.zeros(0, dtype=np.uint8)
@@ -43,8 +53,11 @@ class Exchange:
         self.refine_shard, self.all_gather = refine_shard, all_gather
 
     def run(self, cands_ptr, n: int, has_seeds: bool, max_cam: int):
-        per, lo, hi = shard_bounds(n, self.rank, self.world)
         cb = _cand_bytes(cands_ptr, n)
+        if replicate_round(n, self.world):
+            # thin round: every rank refines all of it (bit-identical results on every GPU), no collective
+            return np.frombuffer(self.refine_shard(cb, n, has_seeds, max_cam), dtype=np.uint8, count=n * SZ_R).copy()
+        per, lo, hi = shard_bounds(n, self.rank, self.world)
         mine = self.refine_shard(cb[lo * SZ_C:hi * SZ_C], hi - lo, has_seeds, max_cam)
         buf = np.zeros(per * SZ_R, dtype=np.uint8)
         if hi > lo:
@@ -99,8 +112,10 @@ def torch_gpu_exchange(m: MVS, rank: int, world: int) -> Exchange:
         return d_o
 
     def run(cands_ptr, n, has_seeds, max_cam):
-        per, lo, hi = shard_bounds(n, rank, world)
         cb = _cand_bytes(cands_ptr, n)
+        if replicate_round(n, world):
+            return refine_shard(cb, n, has_seeds, max_cam).cpu().numpy()
+        per, lo, hi = shard_bounds(n, rank, world)
         d_o = refine_shard(cb[lo * SZ_C:hi * SZ_C], hi - lo, has_seeds, max_cam)
         buf = torch.zeros(per * SZ_R, dtype=torch.uint8, device=dev)
         if d_o is not None:

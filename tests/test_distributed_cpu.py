@@ -50,8 +50,18 @@ def _worker(rank, world, port, q):
         dist.all_gather(outs, t)
         return torch.cat(outs).numpy()
 
+    # the product replicates thin rounds (fewer than 64 candidates per rank) instead of sharding them; here the choice is
+    # made by the parity of the round size so that both paths certainly run (any rule works as long as all ranks agree)
+    stats = {"sharded": 0, "replicated": 0}
+
+    def rr(n, w):
+        r = w > 1 and n % 2 == 0
+        stats["replicated" if r else "sharded"] += 1
+        return r
+    D.replicate_round = rr
     ex = D.Exchange(rank, world, refine_shard, all_gather)
     D.reconstruct(m, 8, ex, max_rounds=10)
+    q.put(("stats", rank, dict(stats)))
     cloud = m.cloud()
     st = m.stats()
     q.put((rank, cloud.tobytes(), cloud.shape, int(st.candidates_effective)))
@@ -68,11 +78,15 @@ def test_two_rank_sharded_reconstruction_is_rank_count_invariant():
         ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
         for p in ps:
             p.start()
-        got = [q.get(timeout=600) for _ in range(world)]
+        got = [q.get(timeout=300) for _ in range(2 * world)]
         for p in ps:
             p.join(timeout=60)
             assert p.exitcode == 0
-        res[world] = got
+        res[world] = [g for g in got if g[0] != "stats"]
+        if world == 2:   # both the sharded and the replicated kind of round were exercised on every rank
+            for g in got:
+                if g[0] == "stats":
+                    assert g[2]["sharded"] > 0 and g[2]["replicated"] > 0, g
     ref = res[1][0]
     assert ref[2][0] > 24
     for rank, blob, shape, eff in res[2]:
