@@ -57,6 +57,8 @@ struct pais_ctx {
     double *d_hp = nullptr;
     size_t hpBytes = 0;
     int *d_counters = nullptr;          // [0] PSO work counter, [1] "needs another pass" count, [2] active-list length
+    pais_candidate *h_cands = nullptr;  // pinned staging of pais_refine_batch
+    pais_patch_result *h_recs = nullptr;
     int *d_active = nullptr;            // compacted indices of the candidates that run a PSO in the current pass
     size_t activeCap = 0;
     unsigned long long *d_stat = nullptr; // [0] evals [1] evals*bytesPerPixel [2] patches [3] ncc tables [4] tables*K
@@ -279,7 +281,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_imgF); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
-    (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active);
+    (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active); (void)hipHostFree(ctx->h_cands); (void)hipHostFree(ctx->h_recs);
     (void)hipFree(ctx->d_states); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_particles); (void)hipFree(ctx->d_out);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -638,12 +640,20 @@ extern "C" int pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *can
         ctx->recCap = (size_t)n + (size_t)n / 2 + 256;
         HIPCHK(hipMalloc(&ctx->d_cands, sizeof(pais_candidate) * ctx->recCap));
         HIPCHK(hipMalloc(&ctx->d_recs, sizeof(pais_patch_result) * ctx->recCap));
+        // pinned staging for the two per-batch copies: a pageable hipMemcpyAsync is staged by the runtime in small
+        // synchronous pieces (two copy kernels and ~0.1 ms per round, which thin rounds notice)
+        (void)hipHostFree(ctx->h_cands); (void)hipHostFree(ctx->h_recs);
+        ctx->h_cands = nullptr; ctx->h_recs = nullptr;
+        HIPCHK(hipHostMalloc((void **)&ctx->h_cands, sizeof(pais_candidate) * ctx->recCap, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&ctx->h_recs, sizeof(pais_patch_result) * ctx->recCap, hipHostMallocDefault));
     }
-    HIPCHK(hipMemcpyAsync(ctx->d_cands, cands, sizeof(pais_candidate) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    memcpy(ctx->h_cands, cands, sizeof(pais_candidate) * (size_t)n);
+    HIPCHK(hipMemcpyAsync(ctx->d_cands, ctx->h_cands, sizeof(pais_candidate) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     int rc = pais_refine_batch_device(ctx, n, ctx->d_cands, ctx->d_recs, Kmax, hasSeeds);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out, ctx->d_recs, sizeof(pais_patch_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_recs, ctx->d_recs, sizeof(pais_patch_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->h_recs, sizeof(pais_patch_result) * (size_t)n);
     return 0;
 }
 
