@@ -37,10 +37,16 @@ using namespace pais;
 // k_pso_iter / k_fitness: 3 waves per SIMD (<= 168 VGPRs): two window pixels per lane are in flight (tap_group<G, 2>)
 // and the LDS scratch of a wave (~11 KB at 5 cameras) allows 3.75 waves per SIMD anyway; measured better than
 // 4 waves with spills
-#define PAIS_ITER_BOUNDS __launch_bounds__(64, 3)
+#ifndef PAIS_ITER_WAVES
+#define PAIS_ITER_WAVES 3
+#endif
+#define PAIS_ITER_BOUNDS __launch_bounds__(64, PAIS_ITER_WAVES)
 // rows of 64 doubles in a wave's colour buffer: two per camera (two window pixels per lane in flight) + the 8 lane
 // accumulators of eval_fitness_parts
-#define PAIS_CBUF_ROWS(K) (2 * (K) + 8)
+#ifndef PAIS_NS
+#define PAIS_NS 2 // window pixels per lane and loop iteration of the cost evaluation
+#endif
+#define PAIS_CBUF_ROWS(K) (PAIS_NS * (K) + 8)
 
 // --------------------------------------------------------------- helpers ---
 __device__ __forceinline__ void wave_sync()
@@ -310,7 +316,7 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useDiff = sc.cfg.adaptiveDifferenceEnable != 0,
                useGrad = sc.cfg.adaptiveGradientEnable != 0;
     const double invK = 1.0 / (double)K;
-    constexpr int NS = 2; // window pixels per lane and loop iteration (two of this wave's 64-pixel steps)
+    constexpr int NS = PAIS_NS; // window pixels per lane and loop iteration (NS of this wave's 64-pixel steps)
     double *myc = cbuf + lane;
     double *myacc = cbuf + (size_t)K * NS * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
 #pragma unroll

@@ -6,6 +6,9 @@ SRC = os.path.join(ROOT, "pais_mvs_amd", "csrc")
 OUT = os.path.join(SRC, "variants")
 VARS = {
     "base": [],
+    "ns4w2": "DEFINE:PAIS_NS=4 -DPAIS_ITER_WAVES=2",
+    "ns3w2": "DEFINE:PAIS_NS=3 -DPAIS_ITER_WAVES=2",
+    "ns1w4": "DEFINE:PAIS_NS=1 -DPAIS_ITER_WAVES=4",
     # read the group's homographies a second time from LDS (results unused): how much LDS slack is there?
     "lds2x": [('    double bx[G], by[G], nx[G], ny[G], w[G], rw[G];', '    { const double *Hx = Hbuf + 9 * ((c0 + G < 4) ? c0 + G : 0); for (int i_ = 0; i_ < 9 * G; ++i_) { double t_ = Hx[i_]; asm volatile("" ::"v"(t_)); } }\n    double bx[G], by[G], nx[G], ny[G], w[G], rw[G];')],
     # the same amount of extra VALU work instead (18 dependent-free adds per pair)
@@ -27,13 +30,17 @@ def main(names):
         shutil.copytree(os.path.join(ROOT, "include"), "/tmp/sens/%s/x/include" % name)
         p = os.path.join(tmp, "pais_kernels.hip")
         s = open(p).read()
-        for a, b in VARS[name]:
-            assert a in s, (name, a)
-            s = s.replace(a, b)
+        defs = []
+        if isinstance(VARS[name], str):
+            defs = ["-D" + VARS[name].split(":", 1)[1].split()[0]] + VARS[name].split(":", 1)[1].split()[1:]
+        else:
+            for a, b in VARS[name]:
+                assert a in s, (name, a)
+                s = s.replace(a, b)
         open(p, "w").write(s)
         so = os.path.join(OUT, "libpais_%s.so" % name)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-Wno-unused-result"] + [os.path.join(tmp, f) for f in ("pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip")] + ["-o", so])
+                               "-Wno-unused-result"] + defs + [os.path.join(tmp, f) for f in ("pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip")] + ["-o", so])
         print("built", so)
 if __name__ == "__main__":
     main(sys.argv[1:] or list(VARS))
