@@ -157,12 +157,20 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the PAIS HIP path has no CPU fallback")
+    # test hooks (one-GPU boxes): PAIS_FORCE_DEVICE puts every rank on that device, PAIS_DIST_BACKEND=gloo exchanges the
+    # records through host memory -- RCCL refuses two ranks on one GPU.  The driver never sets them.
+    if "PAIS_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["PAIS_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("PAIS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from pais_mvs_amd import _lib
     from pais_mvs_amd.mvs import MVS
@@ -209,7 +217,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # Roofline leg (not part of `value`): ONE more step of the same workload with every k_pso_iter launch
