@@ -87,3 +87,22 @@ def test_pyramid_and_camera_prep(pawn_small):
     R = cam.rotation
     assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
     assert np.allclose(cam.translation, -R @ cam.center) and np.allclose(cam.optical_normal, R[2])
+
+
+def test_new_entry_points_reject_bad_arguments(pawn_small):
+    """Argument errors of the widened entry points are status codes with a message, never crashes (scheduler-only driver)."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    m = MVS(readme_config(), pawn_small.cameras, device=-1)
+    ncam = len(pawn_small.cameras)
+    with pytest.raises(RuntimeError):
+        m.load_patch([0, 0, 0], [0.1, 0.2], [0, ncam], 1.0, 0.9)            # camera index out of range
+    with pytest.raises(RuntimeError):
+        m.add_seed_measured([0, 0, 0], [0, -1], [[1.0, 2.0], [3.0, 4.0]])    # negative camera index
+    pid = m.load_patch(pawn_small.seeds[0][0], [1.0, 0.5], pawn_small.seeds[0][1], 0.5, 0.95)
+    assert pid == 0 and m.num_patches() == 1
+    # filters on a one-patch cloud: nothing to compare against, nothing deleted, no crash
+    m.cellFiltering(); m.visibilityFiltering(); m.neighborCellFiltering(0.25)
+    assert m.num_patches() == 1
+    m.set_thin_front(-5)                                                     # clamped to 0
+    m.close()

@@ -549,3 +549,28 @@ def test_alternative_pso_pipelines_are_bit_identical(pawn_small, monkeypatch):
     for parts in ("1", "2", "4"):
         monkeypatch.setenv("PAIS_EVAL_PARTS", parts)
         assert run() == ref, parts
+
+
+@pytest.mark.gpu
+def test_edge_cases_of_the_widened_entry_points(pawn_small):
+    from pais_mvs_amd.camera import build_pyramid_gpu, resize_area, max_lod
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    # pyramid of a tiny image: levels down to 1 x 1, and invalid ratios are refused
+    img = (np.arange(9 * 7, dtype=np.uint8) * 3).reshape(7, 9)
+    levels, edges, _ = build_pyramid_gpu(img, 0.8, 15, True, device=0)
+    assert len(levels) == max_lod(9, 7, 0.8, 15) + 1
+    for i in range(1, len(levels)):
+        assert np.array_equal(levels[i], resize_area(img, 0.8 ** i))
+    with pytest.raises(RuntimeError):
+        build_pyramid_gpu(img, 1.5, 15, False, device=0)
+    # neighbour counts: n = 0 and n = 1
+    m = MVS(readme_config(), pawn_small.cameras, device=0)
+    cnt = np.zeros(1, dtype=np.int32)
+    one = np.zeros(3, dtype=np.float64)
+    assert m.L.pais_neighbor_count(m.ctx_handle, 0, None, C.c_double(1.0), None, None) == 0
+    assert m.L.pais_neighbor_count(m.ctx_handle, 1, one.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(1.0),
+                                   cnt.ctypes.data_as(C.POINTER(C.c_int32)), None) == 0 and cnt[0] == 0
+    # the PCMVS filter on an empty driver is a no-op
+    assert m.neighborPatchFiltering(0.25) == 0.0
+    m.close()
