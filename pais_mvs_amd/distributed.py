@@ -99,35 +99,56 @@ def torch_gpu_exchange(m: MVS, rank: int, world: int) -> Exchange:
     L = m.L
     ctx = m.ctx_handle
     dev = torch.device("cuda", torch.cuda.current_device())
+    nccl = dist.get_backend() == "nccl"
+    # buffers reused across rounds (grown on demand): pinned host staging for the candidates and the gathered records,
+    # device buffers for this rank's shard and for the gathered result
+    bufs = {"h_c": None, "d_c": None, "d_o": None, "d_all": None, "h_all": None}
 
-    def refine_shard(cb: np.ndarray, count: int, has_seeds: bool, max_cam: int):
+    def ensure(name, nbytes, device, pinned=False):
+        t = bufs[name]
+        if t is None or t.numel() < nbytes:
+            cap = int(nbytes * 1.5) + 4096
+            t = torch.empty(cap, dtype=torch.uint8, device=device, pin_memory=pinned)
+            bufs[name] = t
+        return t
+
+    def refine_into(d_o, cb: np.ndarray, count: int, has_seeds: bool, max_cam: int):
+        """candidates (host bytes) -> records in d_o[:count*SZ_R] on the device"""
         if count == 0:
-            return None
-        d_c = torch.from_numpy(np.ascontiguousarray(cb)).to(dev)
-        d_o = torch.empty(count * SZ_R, dtype=torch.uint8, device=dev)
+            return
+        nb = count * SZ_C
+        h_c = ensure("h_c", nb, "cpu", pinned=True)
+        h_c[:nb].numpy()[:] = cb
+        d_c = ensure("d_c", nb, dev)
+        d_c[:nb].copy_(h_c[:nb], non_blocking=True)
         torch.cuda.current_stream().synchronize()
         _lib.check(L.pais_refine_batch_device(ctx, count, d_c.data_ptr(), d_o.data_ptr(), max_cam, 1 if has_seeds else 0),
                    "pais_refine_batch_device")
         _lib.check(L.pais_ctx_synchronize(ctx), "pais_ctx_synchronize")
-        return d_o
+
+    def to_host(d_t, nbytes):
+        h = ensure("h_all", nbytes, "cpu", pinned=True)
+        h[:nbytes].copy_(d_t[:nbytes], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return h[:nbytes].numpy()
 
     def run(cands_ptr, n, has_seeds, max_cam):
         cb = _cand_bytes(cands_ptr, n)
         if replicate_round(n, world):
-            return refine_shard(cb, n, has_seeds, max_cam).cpu().numpy()
+            d_o = ensure("d_o", n * SZ_R, dev)
+            refine_into(d_o, cb, n, has_seeds, max_cam)
+            return to_host(d_o, n * SZ_R)
         per, lo, hi = shard_bounds(n, rank, world)
-        d_o = refine_shard(cb[lo * SZ_C:hi * SZ_C], hi - lo, has_seeds, max_cam)
-        buf = torch.zeros(per * SZ_R, dtype=torch.uint8, device=dev)
-        if d_o is not None:
-            buf[:(hi - lo) * SZ_R] = d_o
-        if dist.get_backend() != "nccl":           # test hook: gloo has no device collectives
-            hb = buf.cpu()
+        d_o = ensure("d_o", per * SZ_R, dev)            # the tail of the last rank's shard is never read
+        refine_into(d_o, cb[lo * SZ_C:hi * SZ_C], hi - lo, has_seeds, max_cam)
+        if not nccl:                                    # test hook: gloo has no device collectives
+            hb = d_o[:per * SZ_R].cpu()
             ho = torch.empty(world * per * SZ_R, dtype=torch.uint8)
             dist.all_gather_into_tensor(ho, hb)
             return ho.numpy()
-        out = torch.empty(world * per * SZ_R, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, buf)      # the one collective of the round
-        return out.cpu().numpy()
+        d_all = ensure("d_all", world * per * SZ_R, dev)
+        dist.all_gather_into_tensor(d_all[:world * per * SZ_R], d_o[:per * SZ_R])   # the one collective of the round
+        return to_host(d_all, world * per * SZ_R)
 
     ex = Exchange(rank, world, None, None)
     ex.run = run  # device-resident variant
