@@ -256,6 +256,7 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 // computes all four (nparts = 1), or `nparts` (2 / 4) waves compute the sub-accumulators a with
 // a mod nparts == part and whoever consumes the fitness adds them -- the same bits either way.
 // Returns 0 and fills f4/w4 (zeros for the sub-accumulators of other parts), or 1 if the call is DBL_MAX.
+template <int NS>
 __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf,
                                   double *cbuf, double theta, double phi, double depth, int lane, int part, int nparts,
                                   double *f4, double *w4)
@@ -316,7 +317,7 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useDiff = sc.cfg.adaptiveDifferenceEnable != 0,
                useGrad = sc.cfg.adaptiveGradientEnable != 0;
     const double invK = 1.0 / (double)K;
-    constexpr int NS = PAIS_NS; // window pixels per lane and loop iteration (NS of this wave's 64-pixel steps)
+    // NS: window pixels per lane and loop iteration (NS of this wave's 64-pixel steps)
     double *myc = cbuf + lane;
     double *myacc = cbuf + (size_t)K * NS * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
 #pragma unroll
@@ -396,7 +397,7 @@ __device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const Ev
                                double *cbuf, double theta, double phi, double depth, int lane)
 {
     double f4[4], w4[4];
-    if (eval_fitness_parts(sc, ep, cams, Hbuf, cbuf, theta, phi, depth, lane, 0, 1, f4, w4)) return DBL_MAX;
+    if (eval_fitness_parts<PAIS_NS>(sc, ep, cams, Hbuf, cbuf, theta, phi, depth, lane, 0, 1, f4, w4)) return DBL_MAX;
     return combine_parts(f4, w4);
 }
 
@@ -1337,8 +1338,10 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 // launch L = 0: cost of the initial swarm.  L >= 1: step (L-1) + cost of the moved particle.  finishOnly: one
 // wave per candidate that only replays the step (the launch after the last possible iteration: every run ends).
 // Tasks: positions [listLo, min(listHi, *activeCount)) of the active list written by k_pso_init.
-template <int nparts>
-__global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
+// NS = 2 (3 waves per SIMD) for patches seen by few cameras, NS = 1 (4 waves per SIMD) beyond: a wave's LDS scratch
+// grows with NS * K and caps the occupancy (measured: K ~ 4: NS 2 +3 %, K ~ 7: NS 1 +9 %)
+template <int nparts, int NS>
+__global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
                                             const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly)
 {
@@ -1520,7 +1523,7 @@ __global__ PAIS_ITER_BOUNDS void k_pso_iter(DevScene sc, unsigned char *states, 
         fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
         __syncthreads();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane, part, nparts, f4, w4);
+        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane, part, nparts, f4, w4);
         if (lane == 0) {
             if (nparts == 1) {
                 Wb.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
@@ -2059,32 +2062,37 @@ hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int 
     hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, fuseStep);
     return hipGetLastError();
 }
+template <int P, int NS>
+static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,
+                                  int listLo, int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L,
+                                  int finishOnly, hipStream_t stream)
+{
+    const size_t lds = sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * (NS * Kmax + 8);
+    static size_t attrFor = 0;
+    if (lds > 64 * 1024 && lds > attrFor) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_pso_iter<P, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attrFor = lds;
+    }
+    const long total = (long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P);
+    const int grid = (int)(total < 262144 ? total : 262144);
+    hipLaunchKernelGGL((k_pso_iter<P, NS>), dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax,
+                       Kmax, recs, stat, L, finishOnly);
+    return hipGetLastError();
+}
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                     int nparts, hipStream_t stream)
 {
-    const int n = listHi - listLo;
-    size_t lds = fitness_lds_bytes(Kmax);
-    static bool attrSet = false;
-    if (lds > 64 * 1024 && !attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_pso_iter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_pso_iter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_pso_iter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attrSet = true;
-    }
-    long total = (long)n * (finishOnly ? 1 : Nmax * nparts);
-    int grid = (int)(total < 262144 ? total : 262144);
-    if (nparts == 4)
-        hipLaunchKernelGGL(k_pso_iter<4>, dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L,
-                           finishOnly);
-    else if (nparts == 2)
-        hipLaunchKernelGGL(k_pso_iter<2>, dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L,
-                           finishOnly);
-    else
-        hipLaunchKernelGGL(k_pso_iter<1>, dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L,
-                           finishOnly);
-    return hipGetLastError();
+    if (listHi <= listLo) return hipSuccess;
+    const bool two = Kmax <= 5; // two window pixels per lane only while the LDS scratch leaves >= 3 waves per SIMD
+#define PAIS_DISPATCH(P)                                                                                                            \
+    return two ? pso_iter_launch<P, 2>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, stream) \
+               : pso_iter_launch<P, 1>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, stream)
+    if (nparts == 4) { PAIS_DISPATCH(4); }
+    if (nparts == 2) { PAIS_DISPATCH(2); }
+    PAIS_DISPATCH(1);
+#undef PAIS_DISPATCH
 }
 size_t pso_queue_ints(int n, int Nmax, int maxIt) { return sizeof(PsoQueue) / sizeof(int) + (size_t)n * Nmax * (size_t)(maxIt + 2); }
 hipError_t pso_persist(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, int maxIt, pais_patch_result *recs,
