@@ -614,11 +614,15 @@ __device__ void set_priority_and_image_point(const DevScene &sc, pais_patch_resu
 // Patch::removeInvisibleCamera, patch.cpp:655-721 (with setCorrelationTable :221-267,
 // getHomographyPatch :332-386, getHomographyRegionRatio :269-288).
 //   hp    : global scratch of this workgroup, Kmax*S2 doubles (warped patches)
-//   table : LDS, Kmax*Kmax doubles ; Hn: LDS, Kmax*9 doubles ; tmp: LDS, Kmax doubles
+//   table : LDS, Kmax*Kmax doubles ; Hn: LDS, Kmax*9 doubles ; tmp: LDS, Kmax + 1 doubles (region ratios + drop flag)
+// Called by a workgroup of TWO waves: wave 0 warps the patches and builds the correlation table while wave 1 fits the
+// ellipses (three serial Jacobi SVDs per camera lane, a third of the function's latency); everything else is done
+// redundantly by both waves with single-writer stores (tid 0).
 __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *st, double *hp, double *table,
-                                        double *Hn, double *tmp, int lane)
+                                        double *Hn, double *tmp, int lane, int wave)
 {
     if (st->dropped) return;
+    const bool lead = (lane == 0) && (wave == 0);
     const int K = st->num_cam;
     const int r = sc.cfg.patchRadius, S = sc.cfg.patchSize, S2 = S * S;
     const int LOD = st->lod, refCam = st->ref_cam;
@@ -653,8 +657,9 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
     cam_project(sc, refCam, center, pt, LOD);
     const double a0 = pt[0] - r, b0 = pt[1] - r;
 
-    // setCorrelationTable: warped, L2-normalised patches
+    // setCorrelationTable: warped, L2-normalised patches (wave 0)
     bool dropNow = false;
+    if (wave == 0) {
     for (int c = 0; c < K && !dropNow; ++c) {
         const DevCamera &cam = sc.cams[st->cam_idx[c]];
         const uint8_t *img = sc.imgBlob + cam.imgOff[LOD];
@@ -686,17 +691,11 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
         for (int k = lane; k < S2; k += 64) hpc[k] = hpc[k] * inv; // hp /= sqrt(sum)
     }
     wave_sync();
-    if (lane == 0) st->ncc_tables += 1;
-    if (dropNow) {
-        // patch.cpp:243-247: drop, correlation = 0 (and every later step is a no-op)
-        __syncthreads();
-        if (lane == 0) {
-            st->dropped = 1;
-            st->correlation = 0;
-        }
-        __syncthreads();
-        return;
+    if (lane == 0) {
+        st->ncc_tables += 1;
+        tmp[K] = dropNow ? 1.0 : 0.0; // the other wave has to take the same exit
     }
+    if (!dropNow) {
     for (int i = 0; i < K; ++i) {
         for (int j = i + 1; j < K; ++j) {
             const double *a = hp + (size_t)i * S2, *b = hp + (size_t)j * S2;
@@ -709,7 +708,26 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
             }
         }
     }
+        } // !dropNow
+    } else {
+        // region ratios, one camera per lane (wave 1)
+        for (int c = lane; c < K; c += 64) {
+            double H[9];
+            for (int i = 0; i < 9; ++i) H[i] = Hn[c * 9 + i];
+            tmp[c] = region_ratio(pt[0], pt[1], r, H);
+        }
+    }
     __syncthreads();
+    if (tmp[K] != 0.0) {
+        // patch.cpp:243-247: drop, correlation = 0 (and every later step is a no-op)
+        __syncthreads();
+        if (lead) {
+            st->dropped = 1;
+            st->correlation = 0;
+        }
+        __syncthreads();
+        return;
+    }
 
     double correlation = 0;
     for (int i = 0; i < K; ++i)
@@ -726,13 +744,6 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
             maxCorr = corrSum;
         }
     }
-    // region ratios, one camera per lane
-    for (int c = lane; c < K; c += 64) {
-        double H[9];
-        for (int i = 0; i < 9; ++i) H[i] = Hn[c * 9 + i];
-        tmp[c] = region_ratio(pt[0], pt[1], r, H);
-    }
-    __syncthreads();
 
     // mark + erase, keeping order (removeIdx holds distinct camera indices)
     int newIdx[PAIS_MAX_VIS];
@@ -754,7 +765,7 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
         if (!rem) newIdx[nn++] = ci;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (lead) {
         st->correlation = correlation;
         for (int i = 0; i < nn; ++i) st->cam_idx[i] = newIdx[i];
         st->num_cam = nn;
@@ -764,11 +775,11 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
 }
 
 // LDS <-> global copy of a patch record by one wave
-__device__ void copy_record(pais_patch_result *dst, const pais_patch_result *src, int lane)
+__device__ void copy_record(pais_patch_result *dst, const pais_patch_result *src, int tid, int nthreads = 64)
 {
     const uint32_t *s = (const uint32_t *)src;
     uint32_t *d = (uint32_t *)dst;
-    for (int i = lane; i < (int)(sizeof(pais_patch_result) / 4); i += 64) d[i] = s[i];
+    for (int i = tid; i < (int)(sizeof(pais_patch_result) / 4); i += nthreads) d[i] = s[i];
 }
 
 // ---------------------------------------------------------------- k_begin ---
@@ -1845,7 +1856,8 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
 // ---------------------------------------------------------------- k_after ---
 // After one PSO run: patch.cpp:161-175 (+ the caller's removeInvisibleCamera,
 // mvs.cpp:215 / :574, once the refine loop has ended).
-__global__ __launch_bounds__(64) void k_after(DevScene sc, pais_patch_result *recs, int n, double *hpScratch,
+// Two waves per candidate (see remove_invisible_camera); the setters run redundantly in both, stores by thread 0.
+__global__ __launch_bounds__(128) void k_after(DevScene sc, pais_patch_result *recs, int n, double *hpScratch,
                                               int *counters, unsigned long long *stat, int Kmax)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1854,18 +1866,19 @@ __global__ __launch_bounds__(64) void k_after(DevScene sc, pais_patch_result *re
     double *table = (double *)(smem + off); off += sizeof(double) * Kmax * Kmax;
     double *Hn = (double *)(smem + off); off += sizeof(double) * 9 * Kmax;
     double *tmp = (double *)(smem + off);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool lead = threadIdx.x == 0;
     const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
     double *hp = hpScratch + (size_t)blockIdx.x * Kmax * S2;
 
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
         if (recs[c].stage != PAIS_STAGE_AFTER) continue;
         __syncthreads();
-        copy_record(st, &recs[c], lane);
+        copy_record(st, &recs[c], threadIdx.x, 128);
         __syncthreads();
 
         const int nccBefore = st->ncc_tables;
-        remove_invisible_camera(sc, st, hp, table, Hn, tmp, lane);
+        remove_invisible_camera(sc, st, hp, table, Hn, tmp, lane, wave);
         set_reference_camera(sc, st, lane);
         set_depth_and_ray(sc, st, lane);
         set_depth_range(sc, st, lane);
@@ -1878,7 +1891,7 @@ __global__ __launch_bounds__(64) void k_after(DevScene sc, pais_patch_result *re
             const int cnt = st->count;
             const bool cond = (st->before_ref != afterRef || st->before_num != afterNum) && (cnt <= st->total_cam_num);
             __syncthreads();
-            if (lane == 0) {
+            if (lead) {
                 st->after_ref = afterRef;
                 st->after_num = afterNum;
                 st->count = cnt + 1; // count++ is evaluated whenever the first operand is true ... (see note)
@@ -1887,7 +1900,7 @@ __global__ __launch_bounds__(64) void k_after(DevScene sc, pais_patch_result *re
             if (cond) {
                 if (st->num_cam < sc.cfg.minCamNum) { // :142-147
                     __syncthreads();
-                    if (lane == 0) {
+                    if (lead) {
                         st->fitness = DBL_MAX;
                         st->priority = DBL_MAX;
                         st->dropped = 1;
@@ -1896,7 +1909,7 @@ __global__ __launch_bounds__(64) void k_after(DevScene sc, pais_patch_result *re
                 } else {
                     again = true;
                     __syncthreads();
-                    if (lane == 0) {
+                    if (lead) {
                         st->before_ref = st->ref_cam;
                         st->before_num = st->num_cam;
                         st->stage = PAIS_STAGE_PSO;
@@ -1907,17 +1920,18 @@ __global__ __launch_bounds__(64) void k_after(DevScene sc, pais_patch_result *re
         }
         if (!again) {
             set_priority_and_image_point(sc, st, lane);
-            remove_invisible_camera(sc, st, hp, table, Hn, tmp, lane); // mvs.cpp:215 / :574
+            remove_invisible_camera(sc, st, hp, table, Hn, tmp, lane, wave); // mvs.cpp:215 / :574
             __syncthreads();
-            if (lane == 0) st->stage = PAIS_STAGE_DONE;
+            if (lead) st->stage = PAIS_STAGE_DONE;
         }
         __syncthreads();
-        if (lane == 0) {
+        if (lead) {
             if (again) atomicAdd(&counters[1], 1);
             atomicAdd(&stat[3], (unsigned long long)(st->ncc_tables - nccBefore));
             atomicAdd(&stat[4], (unsigned long long)(st->ncc_tables - nccBefore) * (unsigned long long)st->total_cam_num);
         }
-        copy_record(&recs[c], st, lane);
+        __syncthreads();
+        copy_record(&recs[c], st, threadIdx.x, 128);
     }
 }
 
@@ -1970,7 +1984,7 @@ static size_t after_lds_bytes(int Kmax)
     size_t off = (sizeof(pais_patch_result) + 15) & ~(size_t)15;
     off += sizeof(double) * Kmax * Kmax;
     off += sizeof(double) * 9 * Kmax;
-    off += sizeof(double) * Kmax;
+    off += sizeof(double) * (Kmax + 1); // region ratios + the drop flag of remove_invisible_camera
     return off;
 }
 static size_t fitness_lds_bytes(int Kmax)
@@ -2145,7 +2159,7 @@ hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpS
         hipError_t e = hipFuncSetAttribute((const void *)k_after, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_after, dim3(grid), dim3(64), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax);
+    hipLaunchKernelGGL(k_after, dim3(grid), dim3(128), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax);
     return hipGetLastError();
 }
 
