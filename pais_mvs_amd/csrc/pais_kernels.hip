@@ -668,17 +668,17 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
         double *hpc = hp + (size_t)c * S2;
         double sq = 0;
         bool bad = false;
+        // no lane-dependent exit inside the walk (an out-of-image sample is flagged and sampled at a clamped position,
+        // its value is never used: the whole patch is dropped), so the loads of the 16 steps overlap
         for (int k = lane; k < S2; k += 64) {
             const int yi = k / S, xi = k - yi * S;
             const double x = a0 + (double)xi, y = b0 + (double)yi;
             const double w = (H[6] * x + H[7] * y + H[8]);
             const double ix = (H[0] * x + H[1] * y + H[2]) / w;
             const double iy = (H[3] * x + H[4] * y + H[5]) / w;
-            if (!(ix >= 0 && ix < cw - 1 && iy >= 0 && iy < ch - 1) || w == 0) { // :355
-                bad = true;
-                break;
-            }
-            const double v = bilinear(img, cw, ix, iy);
+            const bool out = !(ix >= 0 && ix < cw - 1 && iy >= 0 && iy < ch - 1) || w == 0; // :355
+            bad = bad || out;
+            const double v = bilinear(img, cw, out ? 0.0 : ix, out ? 0.0 : iy);
             hpc[k] = v;
             sq += v * v;
         }
