@@ -59,6 +59,8 @@ struct pais_ctx {
     int *d_counters = nullptr;          // [0] PSO work counter, [1] "needs another pass" count, [2] active-list length
     pais_candidate *h_cands = nullptr;  // pinned staging of pais_refine_batch
     pais_patch_result *h_recs = nullptr;
+    unsigned char *d_evalBlocks = nullptr; // per candidate: EvalPatch + EvalCam[K], written by k_pso_init, read by k_pso_iter
+    size_t evalBlockCap = 0;
     int *d_active = nullptr;            // compacted indices of the candidates that run a PSO in the current pass
     size_t activeCap = 0;
     unsigned long long *d_stat = nullptr; // [0] evals [1] evals*bytesPerPixel [2] patches [3] ncc tables [4] tables*K
@@ -281,7 +283,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_imgF); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
-    (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active); (void)hipHostFree(ctx->h_cands); (void)hipHostFree(ctx->h_recs);
+    (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active); (void)hipFree(ctx->d_evalBlocks); (void)hipHostFree(ctx->h_cands); (void)hipHostFree(ctx->h_recs);
     (void)hipFree(ctx->d_states); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_particles); (void)hipFree(ctx->d_out);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -480,6 +482,16 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         ctx->activeCap = (size_t)n + (size_t)n / 2 + 64;
         HIPCHK(hipMalloc(&ctx->d_active, sizeof(int) * ctx->activeCap));
     }
+    {
+        const size_t needEb = pais_launch::pso_eval_block_bytes(Kmax) * (size_t)n;
+        if (needEb > ctx->evalBlockCap) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_evalBlocks);
+            ctx->d_evalBlocks = nullptr;
+            ctx->evalBlockCap = needEb + needEb / 2;
+            HIPCHK(hipMalloc(&ctx->d_evalBlocks, ctx->evalBlockCap));
+        }
+    }
     int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
     const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
     for (int pass = 0; pass < maxPass; ++pass) {
@@ -499,7 +511,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 HIPCHK(hipMalloc(&ctx->d_psoStates, ctx->psoStateBytes));
             }
             const int maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
-            HIPCHK(pais_launch::pso_split_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, ctx->d_counters + 2, ctx->stream));
+            HIPCHK(pais_launch::pso_split_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, ctx->d_counters + 2, ctx->d_evalBlocks, Kmax, ctx->stream));
             if (ctx->psoMode == 3) {
                 const size_t qi = pais_launch::pso_queue_ints(n, Nmax, maxIt);
                 if (qi > ctx->queueInts) {
@@ -581,7 +593,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                             HIPCHK(hipEventRecord(ee.a, st));
                         }
                         if (useIter)
-                            HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, it, 0, parts, st));
+                            HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, it, 0, parts, ctx->d_evalBlocks, st));
                         else
                             HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0, st));
                         if (timeIt) {
@@ -592,7 +604,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                         if (!useIter) HIPCHK(pais_launch::pso_split_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
                     }
                     // the launch after the last possible iteration only ends the runs still active
-                    if (useIter) HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, maxIt + 1, 1, parts, st));
+                    if (useIter) HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, maxIt + 1, 1, parts, ctx->d_evalBlocks, st));
                     if (S > 1) {
                         HIPCHK(hipEventRecord(ctx->subDone[sI], st));
                         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI], 0));

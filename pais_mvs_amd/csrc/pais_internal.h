@@ -50,12 +50,13 @@ hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters
                int Nmax, int W, int grid, hipStream_t stream);
 size_t pso_split_state_bytes(int Nmax);
 hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax,
-                          int *activeList, int *activeCount, hipStream_t stream);
+                          int *activeList, int *activeCount, unsigned char *evalBlocks, int Kmax, hipStream_t stream);
+size_t pso_eval_block_bytes(int Kmax);
 hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
                           unsigned long long *stat, int fuseStep, hipStream_t stream);
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                    int nparts, hipStream_t stream);
+                    int nparts, const unsigned char *evalBlocks, hipStream_t stream);
 size_t pso_queue_ints(int n, int Nmax, int maxIt);
 hipError_t pso_persist(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, int maxIt, pais_patch_result *recs,
                        unsigned long long *stat, int *qmem, int numCUs, hipStream_t stream);

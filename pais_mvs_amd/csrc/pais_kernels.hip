@@ -1119,8 +1119,12 @@ __device__ __forceinline__ PsoArrays pso_arrays(unsigned char *base, int Nmax, i
 
 // activeList / activeCount (optional): compacted indices of the candidates that run a PSO in this pass, so that
 // the per-iteration launches create waves only for them (k_pso_iter)
+// evalBlocks (optional): per candidate the EvalPatch + EvalCam[K] image of what the evaluation keeps in LDS, built ONCE per
+// PSO run here; the evaluation waves of k_pso_iter copy it with a few coalesced loads instead of each re-deriving it
+// from the camera table through a serial chain of global loads (that was a quarter of a wave's latency)
 __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_result *recs, int n, unsigned char *states,
-                                                 int Nmax, int *activeList, int *activeCount)
+                                                 int Nmax, int *activeList, int *activeCount, unsigned char *evalBlocks,
+                                                 size_t evalBlockBytes)
 {
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
@@ -1180,6 +1184,11 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
             if (activeList) activeList[atomicAdd(activeCount, 1)] = c;
         }
         for (int k = lane; k < P->num_cam; k += 64) hd->camIdx[k] = P->cam_idx[k];
+        if (evalBlocks) {
+            unsigned char *blk = evalBlocks + evalBlockBytes * (size_t)c;
+            fill_eval_patch(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), P->ray, P->ref_cam, P->lod, P->num_cam, P->cam_idx,
+                            lane, 64);
+        }
         // initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
         for (int i = lane; i < N; i += 64) {
             for (int d = 0; d < 3; ++d) {
@@ -1354,7 +1363,8 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 template <int nparts, int NS>
 __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
                                             const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
-                                            pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly)
+                                            pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
+                                            const unsigned char *evalBlocks, size_t evalBlockBytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EvalPatch *ep = (EvalPatch *)smem;
@@ -1531,7 +1541,12 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
         }
         if (finishOnly) continue; // unreachable for a well-formed schedule: every run has ended by now
         __syncthreads();
-        fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
+        {   // the candidate's evaluation constants, prepared by k_pso_init: [EvalPatch][EvalCam x K], same layout as the LDS
+            const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+            uint64_t *dst = (uint64_t *)smem;
+            const int nw = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)hd->K) / 8);
+            for (int q = lane; q < nw; q += 64) dst[q] = src[q];
+        }
         __syncthreads();
         double f4[4], w4[4];
         const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane, part, nparts, f4, w4);
@@ -2054,11 +2069,13 @@ hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *
 size_t pso_lds(int W, int Kmax, int Nmax) { return pso_lds_bytes(W, Kmax, Nmax); }
 
 size_t pso_split_state_bytes(int Nmax) { return pso_state_bytes(Nmax); }
+size_t pso_eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
 hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax,
-                          int *activeList, int *activeCount, hipStream_t stream)
+                          int *activeList, int *activeCount, unsigned char *evalBlocks, int Kmax, hipStream_t stream)
 {
     int grid = n < 65536 ? n : 65536;
-    hipLaunchKernelGGL(k_pso_init, dim3(grid), dim3(64), 0, stream, sc, recs, n, states, Nmax, activeList, activeCount);
+    hipLaunchKernelGGL(k_pso_init, dim3(grid), dim3(64), 0, stream, sc, recs, n, states, Nmax, activeList, activeCount, evalBlocks,
+                       pso_eval_block_bytes(Kmax));
     return hipGetLastError();
 }
 hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
@@ -2079,7 +2096,7 @@ hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int 
 template <int P, int NS>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,
                                   int listLo, int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L,
-                                  int finishOnly, hipStream_t stream)
+                                  int finishOnly, const unsigned char *evalBlocks, hipStream_t stream)
 {
     const size_t lds = sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * (NS * Kmax + 8);
     static size_t attrFor = 0;
@@ -2091,18 +2108,18 @@ static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, con
     const long total = (long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P);
     const int grid = (int)(total < 262144 ? total : 262144);
     hipLaunchKernelGGL((k_pso_iter<P, NS>), dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax,
-                       Kmax, recs, stat, L, finishOnly);
+                       Kmax, recs, stat, L, finishOnly, evalBlocks, pso_eval_block_bytes(Kmax));
     return hipGetLastError();
 }
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                    int nparts, hipStream_t stream)
+                    int nparts, const unsigned char *evalBlocks, hipStream_t stream)
 {
     if (listHi <= listLo) return hipSuccess;
     const bool two = Kmax <= 5; // two window pixels per lane only while the LDS scratch leaves >= 3 waves per SIMD
 #define PAIS_DISPATCH(P)                                                                                                            \
-    return two ? pso_iter_launch<P, 2>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, stream) \
-               : pso_iter_launch<P, 1>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, stream)
+    return two ? pso_iter_launch<P, 2>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, stream) \
+               : pso_iter_launch<P, 1>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, stream)
     if (nparts == 4) { PAIS_DISPATCH(4); }
     if (nparts == 2) { PAIS_DISPATCH(2); }
     PAIS_DISPATCH(1);
