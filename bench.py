@@ -220,7 +220,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # Roofline leg (not part of `value`): ONE more step of the same workload with every k_pso_iter launch
+    # Roofline leg (not part of `value`): ONE more step of the same workload with every cost-evaluation launch
     # bracketed by HIP events on the stream it is launched on (two overlapping sub-streams by default).
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 1)
     m.L.pais_ctx_set_fine_timing(m.ctx_handle, 1)
@@ -237,7 +237,7 @@ def main():
         tnote = "no PMC summary found under profiles/"
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same command
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pj["k_pso_iter_hbm_read_bytes_per_launch"]
+            traffic = pj["eval_hbm_read_bytes_per_launch"]
             tnote = pj.get("note", "")
         except Exception:
             pass
@@ -261,7 +261,7 @@ def main():
                        "rounds_per_step": int(last.rounds) if last else 0,
                        "pso_evals_per_patch": evals_eff / max(units, 1),
                        "parallelism": "candidates sharded over %d GPU(s), 1 all-gather per round" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_pso_iter", "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "cost evaluation (k_pso_eval in large batches, k_pso_iter in small ones)", "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pso_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": k_launches, "avg_launch_ms": k_ms / k_launches,
                          "algorithmic_bytes_per_launch": ks.pso_algorithmic_bytes / k_launches,
@@ -271,7 +271,7 @@ def main():
                                  "(SURVEY 8d) x evaluations of the launch; durations from HIP events on the launching sub-stream "
                                  "(launches of the two sub-streams overlap).  The kernel is FP64-VALU bound, not HBM bound "
                                  "(DESIGN.md 4): the window taps hit L1/L2.  traffic: " + tnote},
-            "kernel_ms_per_step": {"pso_pass": ks.pso_ms, "k_pso_iter_sum_of_launches": ks.eval_ms, "k_begin": ks.begin_ms,
+            "kernel_ms_per_step": {"pso_pass": ks.pso_ms, "cost_evaluation_sum_of_launches": ks.eval_ms, "k_begin": ks.begin_ms,
                                    "k_after": ks.after_ms,
                                    "host_enumerate": last.host_enumerate_ms if last else 0,
                                    "host_commit": last.host_commit_ms if last else 0},

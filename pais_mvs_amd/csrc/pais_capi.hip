@@ -71,6 +71,7 @@ struct pais_ctx {
                                         // 1: eval + step kernels per iteration (PAIS_PSO_MODE=split),
                                         // 2: eval launches with last-arriver step, 3: persistent task-queue kernel,
                                         // 0: fused one-workgroup-per-candidate k_pso  (measured alternatives)
+    long splitAbove = 0;                // batches of at least this many evaluation waves use k_pso_eval + k_pso_step (set at create)
     int psoMinPer = 64;
     int evalParts = 0;                  // waves per cost evaluation in k_pso_iter (1, 2, 4); 0 = chosen per slice
     double partFill = 1.0;              // ... such that parts * waves <= partFill * resident wave slots
@@ -254,6 +255,8 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
         ctx->psoMode = (strcmp(e, "fused") == 0) ? 0 : (strcmp(e, "laststep") == 0) ? 2 : (strcmp(e, "persist") == 0) ? 3 : (strcmp(e, "split") == 0) ? 1 : 4;
     if (const char *e = getenv("PAIS_EVAL_PARTS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) ctx->evalParts = v; }
     if (const char *e = getenv("PAIS_PART_FILL")) { double v = atof(e); if (v > 0) ctx->partFill = v; }
+    ctx->splitAbove = 3L * ctx->numCUs * 12;
+    if (const char *e = getenv("PAIS_SPLIT_ABOVE")) { long v = atol(e); if (v > 0) ctx->splitAbove = v; }
     if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     HIPCHK(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming));
@@ -552,7 +555,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 ctx->evalLaunches++;
             } else if (ctx->psoMode == 2) {
                 for (int it = 0; it <= maxIt; ++it) {
-                    HIPCHK(pais_launch::pso_split_eval(sc, ctx->d_psoStates, n, Nmax, Kmax, d_out, ctx->d_stat, 1, ctx->stream));
+                    HIPCHK(pais_launch::pso_split_eval(sc, ctx->d_psoStates, n, Nmax, Kmax, d_out, ctx->d_stat, 1, nullptr, ctx->stream));
                     ctx->evalLaunches++;
                 }
             } else {
@@ -563,7 +566,10 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 const size_t SB = pais_launch::pso_split_state_bytes(Nmax);
                 // psoMode 4: one k_pso_iter launch per iteration (step folded into the evaluation waves);
                 // needs the swarm of a candidate in the lanes of one wave
-                const bool useIter = ctx->psoMode == 4 && Nmax <= 64;
+                // ... while the batch is small.  A batch of several residency passes (>= 3 x 12 waves per CU) is throughput
+                // bound: there the step replay in every evaluation wave (~13 % of a wave's time) costs more than a separate
+                // one-wave-per-candidate k_pso_step launch per iteration, whose latency the other sub-stream hides.
+                const bool useIter = ctx->psoMode == 4 && Nmax <= 64 && (long)n * Nmax < ctx->splitAbove;
                 // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
                 // its length is n at most in the first pass and exactly the "again" count afterwards
                 const int nRun = useIter ? (pass == 0 ? n : againCount) : n;
@@ -595,7 +601,8 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                         if (useIter)
                             HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, it, 0, parts, ctx->d_evalBlocks, st));
                         else
-                            HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0, st));
+                            HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0,
+                                                             ctx->d_evalBlocks + pais_launch::pso_eval_block_bytes(Kmax) * (size_t)lo, st));
                         if (timeIt) {
                             HIPCHK(hipEventRecord(ee.b, st));
                             ctx->evEval.push_back(ee);

@@ -53,7 +53,7 @@ hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int
                           int *activeList, int *activeCount, unsigned char *evalBlocks, int Kmax, hipStream_t stream);
 size_t pso_eval_block_bytes(int Kmax);
 hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
-                          unsigned long long *stat, int fuseStep, hipStream_t stream);
+                          unsigned long long *stat, int fuseStep, const unsigned char *evalBlocks, hipStream_t stream);
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                     int nparts, const unsigned char *evalBlocks, hipStream_t stream);

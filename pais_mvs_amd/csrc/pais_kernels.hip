@@ -1221,7 +1221,8 @@ __device__ void pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c
 // particles' fitness with agent-scope atomic loads (cdna_hip_programming.md G16, "8-B agent atomics
 // both sides").  Everything else the step reads was written by a previous launch.
 __global__ PAIS_EVAL_BOUNDS void k_pso_eval(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
-                                            pais_patch_result *recs, unsigned long long *stat, int fuseStep)
+                                            pais_patch_result *recs, unsigned long long *stat, int fuseStep,
+                                            const unsigned char *evalBlocks, size_t evalBlockBytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EvalPatch *ep = (EvalPatch *)smem;
@@ -1242,7 +1243,14 @@ __global__ PAIS_EVAL_BOUNDS void k_pso_eval(DevScene sc, unsigned char *states, 
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
         const int N = hd->N;
         __syncthreads();
-        fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
+        if (evalBlocks) { // the candidate's evaluation constants as prepared by k_pso_init (same layout as the LDS)
+            const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+            uint64_t *dst = (uint64_t *)smem;
+            const int nw = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)hd->K) / 8);
+            for (int q = lane; q < nw; q += 64) dst[q] = src[q];
+        } else {
+            fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
+        }
         __syncthreads();
         const double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, A.pos[i][0], A.pos[i][1], A.pos[i][2], lane);
         if (!fuseStep) {
@@ -2079,7 +2087,7 @@ hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int
     return hipGetLastError();
 }
 hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
-                          unsigned long long *stat, int fuseStep, hipStream_t stream)
+                          unsigned long long *stat, int fuseStep, const unsigned char *evalBlocks, hipStream_t stream)
 {
     size_t lds = fitness_lds_bytes(Kmax) + sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
     static bool attrSet = false;
@@ -2090,7 +2098,8 @@ hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int 
     }
     long total = (long)n * Nmax;
     int grid = (int)(total < 262144 ? total : 262144);
-    hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, fuseStep);
+    hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, fuseStep, evalBlocks,
+                       pso_eval_block_bytes(Kmax));
     return hipGetLastError();
 }
 template <int P, int NS>
