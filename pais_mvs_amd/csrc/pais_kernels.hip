@@ -1269,6 +1269,40 @@ __global__ PAIS_EVAL_BOUNDS void k_pso_eval(DevScene sc, unsigned char *states, 
     }
 }
 
+// The evaluation launch of large batches (split pipeline): one wave per (candidate, particle), nothing but the cost.
+// The candidate's constants come from the block k_pso_init prepared; positions from swarm buffer 0 (k_pso_step).
+template <int NS>
+__global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    EvalPatch *ep = (EvalPatch *)smem;
+    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
+    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
+    double *cbuf = Hbuf + Kmax * 9;
+    const int lane = threadIdx.x;
+    const size_t SB = pso_state_bytes(Nmax);
+    const int total = n * Nmax;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int c = t / Nmax, i = t - c * Nmax; // candidate-major: a CU's waves gather from the same few image windows
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        if (!hd->active || i >= hd->N) continue;
+        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        __syncthreads();
+        {
+            const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+            uint64_t *dst = (uint64_t *)smem;
+            const int nw = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)hd->K) / 8);
+            for (int q = lane; q < nw; q += 64) dst[q] = src[q];
+        }
+        const double p0 = A.pos[i][0], p1 = A.pos[i][1], p2 = A.pos[i][2];
+        __syncthreads();
+        double f4[4], w4[4];
+        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane, 0, 1, f4, w4);
+        if (lane == 0) A.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
+    }
+}
+
 // Intra-launch sharing between waves on different CUs / XCDs (per-XCD L2s are not coherent, a CU's L1 is
 // never refreshed): 8-byte / 4-byte agent-scope relaxed atomics on both sides (cdna_hip_programming.md G16).
 template <typename T> __device__ __forceinline__ T ld_agent(const T *p)
@@ -2086,9 +2120,28 @@ hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int
                        pso_eval_block_bytes(Kmax));
     return hipGetLastError();
 }
+template <int NS>
+static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
+                                   hipStream_t stream)
+{
+    const size_t lds = sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * (NS * Kmax + 8);
+    static size_t attrFor = 0;
+    if (lds > 64 * 1024 && lds > attrFor) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_pso_eval2<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attrFor = lds;
+    }
+    const long total = (long)n * Nmax;
+    const int grid = (int)(total < 262144 ? total : 262144);
+    hipLaunchKernelGGL((k_pso_eval2<NS>), dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks, pso_eval_block_bytes(Kmax));
+    return hipGetLastError();
+}
 hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
                           unsigned long long *stat, int fuseStep, const unsigned char *evalBlocks, hipStream_t stream)
 {
+    if (!fuseStep && evalBlocks) // the default split pipeline: lean evaluation kernel, pixels per lane by camera count
+        return Kmax <= 5 ? pso_eval2_launch<2>(sc, states, n, Nmax, Kmax, evalBlocks, stream)
+                         : pso_eval2_launch<1>(sc, states, n, Nmax, Kmax, evalBlocks, stream);
     size_t lds = fitness_lds_bytes(Kmax) + sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
     static bool attrSet = false;
     if (lds > 64 * 1024 && !attrSet) {
