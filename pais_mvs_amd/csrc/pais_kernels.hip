@@ -1283,19 +1283,28 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_eval2(DevScene sc, 
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
     const int total = n * Nmax;
+    const int nwMax = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax) / 8);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int c = t / Nmax, i = t - c * Nmax; // candidate-major: a CU's waves gather from the same few image windows
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
-        if (!hd->active || i >= hd->N) continue;
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        // everything this wave needs from global memory is requested at once -- the run's state flags, the particle and
+        // the first 192 words of the constants -- so that there is ONE memory round trip before the cost starts
+        const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+        const int iLoad = i < Nmax ? i : 0;
+        const int active = hd->active, Nrun = hd->N;
+        const double p0 = A.pos[iLoad][0], p1 = A.pos[iLoad][1], p2 = A.pos[iLoad][2];
+        const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0,
+                       v2 = lane + 128 < nwMax ? src[lane + 128] : 0;
+        if (!active || i >= Nrun) continue;
         __syncthreads();
         {
-            const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
             uint64_t *dst = (uint64_t *)smem;
-            const int nw = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)hd->K) / 8);
-            for (int q = lane; q < nw; q += 64) dst[q] = src[q];
+            if (lane < nwMax) dst[lane] = v0;
+            if (lane + 64 < nwMax) dst[lane + 64] = v1;
+            if (lane + 128 < nwMax) dst[lane + 128] = v2;
+            for (int q = lane + 192; q < nwMax; q += 64) dst[q] = src[q]; // more than 5 cameras
         }
-        const double p0 = A.pos[i][0], p1 = A.pos[i][1], p2 = A.pos[i][2];
         __syncthreads();
         double f4[4], w4[4];
         const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane, 0, 1, f4, w4);
