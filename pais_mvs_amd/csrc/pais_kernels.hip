@@ -1436,6 +1436,12 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
         const int c = activeList[listLo + lp];
         const int i = ip / nparts, part = ip - i * nparts;
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        // the candidate's evaluation constants are requested now and stored to LDS after the step replay: their memory
+        // round trip overlaps the replay's
+        const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+        const int nwMax = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax) / 8);
+        const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0,
+                       v2 = lane + 128 < nwMax ? src[lane + 128] : 0;
         if (!hd->active || i >= hd->N) continue;
         const int N = hd->N;
         PsoArrays Wb = pso_arrays((unsigned char *)hd, Nmax, L & 1);
@@ -1593,10 +1599,11 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
         if (finishOnly) continue; // unreachable for a well-formed schedule: every run has ended by now
         __syncthreads();
         {   // the candidate's evaluation constants, prepared by k_pso_init: [EvalPatch][EvalCam x K], same layout as the LDS
-            const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
             uint64_t *dst = (uint64_t *)smem;
-            const int nw = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)hd->K) / 8);
-            for (int q = lane; q < nw; q += 64) dst[q] = src[q];
+            if (lane < nwMax) dst[lane] = v0;
+            if (lane + 64 < nwMax) dst[lane + 64] = v1;
+            if (lane + 128 < nwMax) dst[lane + 128] = v2;
+            for (int q = lane + 192; q < nwMax; q += 64) dst[q] = src[q]; // more than 5 cameras
         }
         __syncthreads();
         double f4[4], w4[4];
