@@ -574,3 +574,33 @@ def test_edge_cases_of_the_widened_entry_points(pawn_small):
     # the PCMVS filter on an empty driver is a no-op
     assert m.neighborPatchFiltering(0.25) == 0.0
     m.close()
+
+
+@pytest.mark.gpu
+def test_large_swarms_and_the_split_pipeline_match_oracle(pawn_small, monkeypatch):
+    """Swarms above 64 particles cannot sit in the lanes of one wave (k_pso_iter) and take the k_pso_eval2 + k_pso_step
+    pipeline, as large batches do; force that pipeline on a small batch too.  Both must equal the oracle bit for bit."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import make_candidate
+    L = po.lib()
+    for particles, env in ((40, None), (8, "1")):      # seeds run 2 x particleNum: 80 particles > 64; then a forced split
+        if env:
+            monkeypatch.setenv("PAIS_SPLIT_ABOVE", env)
+        cfg = readme_config(particleNum=particles, maxIteration=6)
+        S = common.oracle_scene(cfg, pawn_small)
+        S.set_kernel_arithmetic(True)
+        ctx = _ctx(cfg, pawn_small)
+        pats, cands = [], []
+        for i, (X, vis) in enumerate(pawn_small.seeds[:10]):
+            p = S.seed_patch(X, vis, key=7000 + i)
+            pats.append(p)
+            cands.append(make_candidate(p.center[:], p.normal[:], p.cams(), 7000 + i, 0, normalS=p.normalS[:]))
+        res = ctx.refine_batch(cands)
+        alive = 0
+        for i, p in enumerate(pats):
+            L.po_refine_seed(S.ptr, C.byref(p))
+            _compare_patch(res[i], p, "particles %d seed %d" % (particles, i))
+            alive += 0 if p.drop else 1
+        assert alive >= 3
+        ctx.close()
