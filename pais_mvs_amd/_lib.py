@@ -82,8 +82,12 @@ def load(build_if_needed: bool = True):
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("PAIS_LIB_PATH") or _build.LIB   # PAIS_LIB_PATH: tuning variants (scripts/build_variants.py)
+    path = os.environ.get("PAIS_LIB_PATH") or _build.LIB   # PAIS_LIB_PATH: tuning variants (scripts/sens_variants.py)
     if path != _build.LIB:
+        build_if_needed = False
+    # several ranks of one job must not race to rebuild the same file: a multi-process launch (torch.distributed.run
+    # sets WORLD_SIZE) only ever loads what __graft_entry__.build() / `python -m pais_mvs_amd.build` produced
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PAIS_NO_BUILD"):
         build_if_needed = False
     if build_if_needed and _build.needs_build():
         try:
