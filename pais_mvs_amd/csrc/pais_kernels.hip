@@ -1442,38 +1442,43 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
         const int nwMax = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax) / 8);
         const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0,
                        v2 = lane + 128 < nwMax ? src[lane + 128] : 0;
-        if (!hd->active || i >= hd->N) continue;
-        const int N = hd->N;
+        // ... and so is everything the step replay reads: all addresses follow from c, i and the lane alone (particle
+        // j of the swarm in lane j), so the run's flags, the swarm and the loop-carried scalars come back in ONE memory
+        // round trip; a finished run wastes these loads
         PsoArrays Wb = pso_arrays((unsigned char *)hd, Nmax, L & 1);
+        PsoArrays Rb = pso_arrays((unsigned char *)hd, Nmax, (L > 0 ? L - 1 : 0) & 1);
+        const int jl = lane < Nmax ? lane : 0;
+        const int active = hd->active, N = hd->N, maxIt = hd->maxIt;
+        const PsoState::IterDyn dr = hd->dyn[(L > 0 ? L - 1 : 0) & 1];
+        double pos[3], pb[3];
+        for (int d = 0; d < 3; ++d) {
+            pos[d] = Rb.pos[jl][d];
+            pb[d] = Rb.pBest[jl][d];
+        }
+        double fitj;
+        if (nparts == 1) {
+            fitj = Rb.fit[jl];
+        } else {
+            double f4[4], w4[4];
+            bool bad = false;
+            for (int a = 0; a < 4; ++a) {
+                f4[a] = Rb.part[jl][2 * a];
+                w4[a] = Rb.part[jl][2 * a + 1];
+                bad = bad || (w4[a] < 0); // a part's call overflowed: DBL_MAX
+            }
+            fitj = bad ? DBL_MAX : combine_parts(f4, w4);
+        }
+        double pbf = Rb.pBestFit[jl];
+        const double vecI[3] = {Rb.vec[i][0], Rb.vec[i][1], Rb.vec[i][2]};
+        const double nbI[3] = {Rb.nBest[i][0], Rb.nBest[i][1], Rb.nBest[i][2]};
+        const double q0 = Wb.pos[i][0], q1 = Wb.pos[i][1], q2 = Wb.pos[i][2]; // launch 0: the initial swarm
+        if (!active || i >= N) continue;
         double p0, p1, p2;
         if (L == 0) {
-            p0 = Wb.pos[i][0];
-            p1 = Wb.pos[i][1];
-            p2 = Wb.pos[i][2];
+            p0 = q0;
+            p1 = q1;
+            p2 = q2;
         } else {
-            PsoArrays Rb = pso_arrays((unsigned char *)hd, Nmax, (L - 1) & 1);
-            const PsoState::IterDyn dr = hd->dyn[(L - 1) & 1];
-            const int maxIt = hd->maxIt;
-            const int jl = lane < N ? lane : 0;
-            double pos[3], pb[3];
-            for (int d = 0; d < 3; ++d) {
-                pos[d] = Rb.pos[jl][d];
-                pb[d] = Rb.pBest[jl][d];
-            }
-            double fitj;
-            if (nparts == 1) {
-                fitj = Rb.fit[jl];
-            } else {
-                double f4[4], w4[4];
-                bool bad = false;
-                for (int a = 0; a < 4; ++a) {
-                    f4[a] = Rb.part[jl][2 * a];
-                    w4[a] = Rb.part[jl][2 * a + 1];
-                    bad = bad || (w4[a] < 0); // a part's call overflowed: DBL_MAX
-                }
-                fitj = bad ? DBL_MAX : combine_parts(f4, w4);
-            }
-            double pbf = Rb.pBestFit[jl];
             int it, g;
             double gf, iw;
             if (!dr.started) {
@@ -1564,8 +1569,6 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
             // moveParticles (:220-265) for iteration `it`, own particle only
             const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
             const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
-            const double vecI[3] = {Rb.vec[i][0], Rb.vec[i][1], Rb.vec[i][2]};
-            const double nbI[3] = {Rb.nBest[i][0], Rb.nBest[i][1], Rb.nBest[i][2]};
             double u[4];
             const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
             for (int q = 0; q < 4; ++q) u[q] = uniform_from(hd->streamBase, (uint32_t)hd->run, k0 + q);
