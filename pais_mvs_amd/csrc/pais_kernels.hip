@@ -1920,6 +1920,9 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
                                                  int Nmax, unsigned long long *stat)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // the step of one slice runs while the other slice's evaluation launch fills the GPU; its few waves sit on the
+    // critical path of their own slice (next evaluation launch), so they take issue priority over the evaluation waves
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
