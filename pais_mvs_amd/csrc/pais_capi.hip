@@ -260,7 +260,7 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     HIPCHK(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming));
-    for (int i = 0; i < ctx->psoStreams; ++i) {
+    for (int i = 0; i + 1 < ctx->psoStreams; ++i) { // slice 0 runs on ctx->stream itself
         hipStream_t st; hipEvent_t ev;
         HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -581,8 +581,10 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 for (int sI = 0; sI < S; ++sI) {
                     const int lo = (int)((long)nRun * sI / S), hi = (int)((long)nRun * (sI + 1) / S);
                     if (hi <= lo) continue;
-                    hipStream_t st = (S == 1) ? ctx->stream : ctx->sub[sI];
-                    if (S > 1) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
+                    // slice 0 stays on the context's own stream, the others fork to sub-streams and join back
+                    const bool own = (S == 1) || (sI == 0);
+                    hipStream_t st = own ? ctx->stream : ctx->sub[sI - 1];
+                    if (!own) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
                     unsigned char *stp = ctx->d_psoStates + SB * (size_t)lo;
                     // waves per evaluation: a slice that leaves the GPU mostly empty is bound by the latency of
                     // one evaluation wave, so share each evaluation among 4 (2) waves while they all stay resident
@@ -612,9 +614,9 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                     }
                     // the launch after the last possible iteration only ends the runs still active
                     if (useIter) HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, maxIt + 1, 1, parts, ctx->d_evalBlocks, st));
-                    if (S > 1) {
-                        HIPCHK(hipEventRecord(ctx->subDone[sI], st));
-                        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI], 0));
+                    if (!own) {
+                        HIPCHK(hipEventRecord(ctx->subDone[sI - 1], st));
+                        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
                     }
                 }
             }
