@@ -35,6 +35,7 @@ static inline double m_exp(const po_scene *s, double x) { return s->detMath ? po
 static inline double m_sin(const po_scene *s, double x) { return s->detMath ? po_det_sin(x) : sin(x); }
 static inline double m_cos(const po_scene *s, double x) { return s->detMath ? po_det_cos(x) : cos(x); }
 double po_exp_det(double x) { return po_det_exp(x); }
+double po_exp_poly(double x) { return po_det_exp_poly(x); }
 double po_sin_det(double x) { return po_det_sin(x); }
 double po_cos_det(double x) { return po_det_cos(x); }
 
@@ -603,7 +604,7 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
     if (s->detMath) {
         /* "kernel arithmetic" (DESIGN.md 5.3): the same quantities as the literal branch
          * below, evaluated the way the HIP kernel does -- homography rows with fma, one
-         * reciprocal per camera group, bilinear as three fma lerps, mean/SAD scaled by 1/K, fdlibm exp.
+         * reciprocal per camera group, bilinear as three fma lerps, polynomial exp (po_det_exp_poly), mean/SAD scaled by 1/K, fdlibm exp.
          * Differs from the literal branch in the last bits only. */
         const double invK = 1.0 / (double)camNum, invDiffW = 1.0 / s->cfg.diffWeighting;
         double sum = 0;
@@ -662,9 +663,9 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
         avgSad *= invK;
         double weight = 1;
         if (s->cfg.adaptiveDistanceEnable) weight *= distW;
-        if (s->cfg.adaptiveDifferenceEnable) weight *= po_det_exp(-(avgSad * avgSad) * invDiffW);
+        if (s->cfg.adaptiveDifferenceEnable) weight *= po_det_exp_poly(-(avgSad * avgSad) * invDiffW);
         if (s->cfg.adaptiveGradientEnable)
-            weight *= po_det_exp(-1.0 / (f->edgeImg[(size_t)cv_round(y) * f->refCols + cv_round(x)] * s->cfg.gradientWeighting));
+            weight *= po_det_exp_poly(-1.0 / (f->edgeImg[(size_t)cv_round(y) * f->refCols + cv_round(x)] * s->cfg.gradientWeighting));
         *weightOut = weight;
         *sadOut = avgSad;
         return 1;

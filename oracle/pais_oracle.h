@@ -158,7 +158,8 @@ void po_homographies(const po_scene *s, const po_patch *p, const double center[3
 double po_region_ratio(const po_scene *s, const double pt[2], const double H[9]); /* patch.cpp:269-288 */
 void po_fit_ellipse(int n, const float *xy, float *cx, float *cy, float *w, float *h, float *angle); /* OpenCV 2.4 */
 
-double po_exp_det(double x); double po_sin_det(double x); double po_cos_det(double x); /* po_detmath.h */
+double po_exp_det(double x);
+double po_exp_poly(double x);   /* exp of the cost weights in kernel-arithmetic mode */ double po_sin_det(double x); double po_cos_det(double x); /* po_detmath.h */
 
 /* ---- cost -------------------------------------------------------------- */
 double po_get_fitness(const po_scene *s, const po_patch *p, const double pos[3]); /* patch.cpp:914-1047 */

@@ -177,7 +177,7 @@ def lib():
     L.po_runtime_filtering.argtypes = [C.c_void_p, C.POINTER(Patch)]
     L.po_expansion_center.argtypes = [C.POINTER(SceneS), C.c_int, C.POINTER(Patch), C.c_int, C.c_int,
                                       C.POINTER(C.c_double)]
-    for n in ("po_exp_det", "po_sin_det", "po_cos_det"):
+    for n in ("po_exp_det", "po_exp_poly", "po_sin_det", "po_cos_det"):
         getattr(L, n).restype = C.c_double
         getattr(L, n).argtypes = [C.c_double]
     L.po_sizeof_patch.restype = C.c_size_t

@@ -9,6 +9,7 @@
  */
 #ifndef PO_DETMATH_H
 #define PO_DETMATH_H
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -174,5 +175,34 @@ static inline double po_det_cos(double x)
     }
 }
 
+
+/* exp of the cost weights in kernel-arithmetic mode: the same operations as pais::det_exp_poly
+ * (pais_mvs_amd/csrc/pais_detmath.hpp) -- Cody-Waite reduction with fdlibm's split of ln2, Taylor polynomial of degree
+ * 13 in Horner form with fma, ldexp.  <= 1 ulp from glibc. */
+static inline double po_det_exp_poly(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const int ok = (x > -746.0) && (x < 710.0);
+    const double xs = ok ? x : 0.0;
+    const double k = rint(xs * invln2);
+    double r = fma(-k, ln2HI, xs);
+    r = fma(-k, ln2LO, r);
+    double q = 1.6059043836821613e-10;
+    q = fma(q, r, 2.08767569878681e-09);
+    q = fma(q, r, 2.505210838544172e-08);
+    q = fma(q, r, 2.755731922398589e-07);
+    q = fma(q, r, 2.7557319223985893e-06);
+    q = fma(q, r, 2.48015873015873e-05);
+    q = fma(q, r, 1.984126984126984e-04);
+    q = fma(q, r, 1.388888888888889e-03);
+    q = fma(q, r, 8.333333333333333e-03);
+    q = fma(q, r, 4.1666666666666664e-02);
+    q = fma(q, r, 1.6666666666666666e-01);
+    q = fma(q, r, 0.5);
+    const double s = fma(r * r, q, r);
+    const double y = ldexp(1.0 + s, (int)k);
+    return ok ? y : ((x != x) ? (x + x) : ((x < 0.0) ? 0.0 : (x + x) * 1.0e300 * 1.0e300));
+}
 
 #endif

@@ -14,6 +14,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #endif
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -125,6 +126,37 @@ PAIS_HD double det_exp_bf(double x)
     const double y = 1.0 - ((lo - (xr * c) / (2.0 - c)) - hi);
     const double scaled = u2d(d2u(y) + ((uint64_t)(int64_t)k << 52));
     return (hx < 0x3e300000) ? (1.0 + x) : scaled;
+}
+
+// exp for the cost weights (patch.cpp:1034,1037): no division, no lane-dependent branch, ~22 instructions instead of
+// ~45.  Cody-Waite reduction x = k ln2 + r (|r| <= 0.3466, fdlibm's split of ln2), Taylor polynomial of degree 13 in
+// Horner form with fma (truncation 4e-18), exact scaling with ldexp.  <= 1 ulp from glibc (tests); the oracle's
+// kernel-arithmetic mode evaluates the very same operations (po_det_exp_poly).
+PAIS_HD double det_exp_poly(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const bool ok = (x > -746.0) && (x < 710.0); // false for NaN too
+    const double xs = ok ? x : 0.0;
+    const double k = rint(xs * invln2);
+    double r = fma(-k, ln2HI, xs);
+    r = fma(-k, ln2LO, r);
+    double q = 1.6059043836821613e-10;       // 1/13!
+    q = fma(q, r, 2.08767569878681e-09);     // 1/12!
+    q = fma(q, r, 2.505210838544172e-08);    // 1/11!
+    q = fma(q, r, 2.755731922398589e-07);    // 1/10!
+    q = fma(q, r, 2.7557319223985893e-06);   // 1/9!
+    q = fma(q, r, 2.48015873015873e-05);     // 1/8!
+    q = fma(q, r, 1.984126984126984e-04);    // 1/7!
+    q = fma(q, r, 1.388888888888889e-03);    // 1/6!
+    q = fma(q, r, 8.333333333333333e-03);    // 1/5!
+    q = fma(q, r, 4.1666666666666664e-02);   // 1/4!
+    q = fma(q, r, 1.6666666666666666e-01);   // 1/3!
+    q = fma(q, r, 0.5);                      // 1/2!
+    const double s = fma(r * r, q, r);       // exp(r) - 1
+    const double y = ldexp(1.0 + s, (int)k);
+    // outside (-746, 710): 0 / +inf / NaN as exp gives them
+    return ok ? y : ((x != x) ? (x + x) : ((x < 0.0) ? 0.0 : (x + x) * 1.0e300 * 1.0e300));
 }
 
 PAIS_HD double det_ksin(double x, double y, int iy)

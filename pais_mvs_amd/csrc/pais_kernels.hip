@@ -371,8 +371,8 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
             sad *= invK;
             double weight = 1;
             if (useDist) weight *= wDist[q];
-            if (useDiff) weight *= det_exp_bf(-(sad * sad) * invDiffW);
-            if (useGrad) weight *= det_exp_bf(-1.0 / (eGrad[q] * gradW));
+            if (useDiff) weight *= det_exp_poly(-(sad * sad) * invDiffW);
+            if (useGrad) weight *= det_exp_poly(-1.0 / (eGrad[q] * gradW));
             double *pa = myacc + gi[q] * 128;
             const double w0 = pa[64], f0 = pa[0];
             pa[64] = act ? (w0 + weight) : w0;

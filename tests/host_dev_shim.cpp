@@ -2,6 +2,7 @@
 // lane-local arithmetic that is inlined into the gfx950 kernels) for the host so
 // that it can be checked against the oracle without a GPU.  Not part of the
 // product; nothing in the product links this.
+#include <math.h>
 #include <string.h>
 #include "../pais_mvs_amd/csrc/pais_dev.hpp"
 
@@ -14,6 +15,19 @@ long shim_exp_bf_mismatches(const double *x, long n)
     long bad = 0;
     for (long i = 0; i < n; ++i) bad += pais::d2u(pais::det_exp_bf(x[i])) != pais::d2u(pais::det_exp(x[i]));
     return bad;
+}
+double shim_exp_poly(double x) { return pais::det_exp_poly(x); }
+// max |ulp| error of det_exp_poly against the platform exp over an array (inputs where exp is finite and normal)
+double shim_exp_poly_max_ulp(const double *x, long n)
+{
+    double worst = 0;
+    for (long i = 0; i < n; ++i) {
+        const double a = pais::det_exp_poly(x[i]), b = exp(x[i]);
+        if (!(b > 1e-300) || !(b < 1e300)) continue;
+        const double u = fabs(a - b) / (nextafter(b, INFINITY) - b);
+        if (u > worst) worst = u;
+    }
+    return worst;
 }
 double shim_sin(double x) { return pais::det_sin(x); }
 double shim_cos(double x) { return pais::det_cos(x); }

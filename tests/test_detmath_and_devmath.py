@@ -24,7 +24,9 @@ def shim():
     S = C.CDLL(so)
     S.shim_exp_bf_mismatches.restype = C.c_long
     S.shim_exp_bf_mismatches.argtypes = [C.POINTER(C.c_double), C.c_long]
-    for n in ("shim_exp", "shim_exp_bf", "shim_sin", "shim_cos"):
+    S.shim_exp_poly_max_ulp.restype = C.c_double
+    S.shim_exp_poly_max_ulp.argtypes = [C.POINTER(C.c_double), C.c_long]
+    for n in ("shim_exp", "shim_exp_bf", "shim_exp_poly", "shim_sin", "shim_cos"):
         getattr(S, n).restype = C.c_double
         getattr(S, n).argtypes = [C.c_double]
     S.shim_rand31.restype = C.c_uint32
@@ -84,6 +86,24 @@ def test_branch_free_exp_is_bit_identical(shim):
     xs = np.ascontiguousarray(np.concatenate(parts + [np.array(edges, dtype=np.float64)]))
     bad = shim.shim_exp_bf_mismatches(xs.ctypes.data_as(C.POINTER(C.c_double)), len(xs))
     assert bad == 0, bad
+
+
+def test_polynomial_exp_of_the_cost_weights(shim):
+    """det_exp_poly (division-free exp of the adaptive weights): <= 1 ulp from the platform exp over the ranges the cost
+    produces and beyond, the specials of exp, and bit for bit the oracle's statement of the same operations."""
+    from oracle import po
+    L = po.lib()
+    rng = np.random.default_rng(5)
+    for lo, hi, n in ((-6.0, 0.0, 2_000_000), (-60.0, 0.0, 1_000_000), (-700.0, 700.0, 1_000_000), (-1e-3, 1e-3, 200_000)):
+        xs = np.ascontiguousarray(rng.uniform(lo, hi, n))
+        assert shim.shim_exp_poly_max_ulp(xs.ctypes.data_as(C.POINTER(C.c_double)), n) <= 1.0
+    for x in list(rng.uniform(-50, 1, 20000)) + [0.0, -0.0, -745.0, -745.5, -746.0, -800.0, 709.0, 709.9, 710.0, 1e5,
+                                                  0.5 * math.log(2), -0.5 * math.log(2), -1e-300, 1e-300]:
+        a, b = shim.shim_exp_poly(float(x)), L.po_exp_poly(float(x))
+        assert a == b, (x, a, b)
+    assert shim.shim_exp_poly(float("-inf")) == 0.0 and shim.shim_exp_poly(float("inf")) == float("inf")
+    assert math.isnan(shim.shim_exp_poly(float("nan"))) and math.isnan(L.po_exp_poly(float("nan")))
+    assert shim.shim_exp_poly(-746.0) == 0.0 and shim.shim_exp_poly(0.0) == 1.0
 
 
 def test_rng_stream_identical(shim):
