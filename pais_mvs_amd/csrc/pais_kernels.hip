@@ -1,18 +1,22 @@
 // pais_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the PAIS-MVS hot path.
 //
-//   k_fitness : batched PAIS::getFitness                      (patch.cpp:914-1047)
-//   k_begin   : head of Patch::refine()                       (patch.cpp:114-136)
-//   k_pso     : Patch::psoOptimization() == one GLN-PSO run    (patch.cpp:180-219,
-//               with the cost evaluated wave-parallel           pso/psosolver.cpp)
-//   k_after   : removeInvisibleCamera + setters + loop control (patch.cpp:156-175,
-//               + the trailing removeInvisibleCamera             655-721; mvs.cpp:215,574)
+//   k_begin      : head of Patch::refine()                         (patch.cpp:114-136)
+//   k_pso_init   : psoOptimization set-up, initial swarm, the candidate's evaluation constants   (patch.cpp:180-200,
+//                                                                                                  psosolver.cpp:94-110)
+//   k_pso_eval2  : PAIS::getFitness for one (candidate, particle) per wave          (patch.cpp:914-1047)   } large
+//   k_pso_step   : PsoSolver::run() between two fitness passes, one wave per candidate   (psosolver.cpp)    } batches
+//   k_pso_iter   : the same step replayed inside the evaluation waves + getFitness: one launch per iteration (small
+//                  batches; 1 / 2 / 4 waves per evaluation)
+//   k_after      : removeInvisibleCamera + setters + seed-loop control  (patch.cpp:156-175, 655-721; mvs.cpp:215,574)
+//   k_fitness    : batched PAIS::getFitness (pais_fitness_batch)
+//   k_neighbor_count : all-pairs neighbour counts of MVS::neighborPatchFiltering   (mvs.cpp:448-524)
+//   k_pso / k_pso_eval / k_pso_persist : measured alternative pipelines (PAIS_PSO_MODE), same results
 //
-// Mapping: one workgroup per candidate patch in k_pso,
-// particles <-> waves, window pixels <-> lanes (row-major so that neighbouring
-// lanes read neighbouring bytes of the reprojected image rows), FP64 xor-butterfly
-// reductions in a fixed order so a cost value is a pure function of (patch,
-// particle).  Camera matrices / homographies / swarm state live in LDS.  No MFMA:
-// the work is byte gathers + FP64 VALU.
+// Mapping: one wave per cost evaluation, window pixels <-> lanes (row-major, so neighbouring
+// lanes read neighbouring pixels of the reprojected image rows), the swarm of a candidate <-> lanes in the step, FP64
+// xor-butterfly reductions in a fixed order so that a cost value is a pure function of (patch, particle).  Homographies,
+// camera constants and the per-camera colours of a pixel live in LDS.  No MFMA: the work is gathers + FP64 VALU
+// (SURVEY 8d).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -1066,7 +1070,7 @@ __global__ __launch_bounds__(512) void k_pso(DevScene sc, pais_patch_result *rec
     }
 }
 
-// ------------------------------------------------ split PSO pipeline (default) ---
+// ------------------------------------- split PSO pipeline (large batches) ---
 // The same GLN-PSO as k_pso, as a launch-per-iteration pipeline:
 //   k_pso_init : per candidate, Patch::psoOptimization set-up + initParticles/setParticle
 //   k_pso_eval : ONE WAVE PER (candidate, particle) -- PAIS::getFitness; no barriers, waves that
