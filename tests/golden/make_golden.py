@@ -137,7 +137,83 @@ def cost_vectors():
     return out
 
 
+def schedule_vectors():
+    """Regression vectors of the oracle's driver-level functions (LITERAL arithmetic -- the mode that restates the
+    reference and does not move with the kernels): the cloud of a short R(B) expansion, the `-f` filter chain on it,
+    and MVS::reCentering.  Pins round rule, cell claims, thin front, filters and the SVD solve against silent drift."""
+    import hashlib
+    from pais_mvs_amd import synth
+    from pais_mvs_amd.config import readme_config
+    from tests import common
+    scene = synth.pawn_scene(width=320, height=240, n_seeds=24)
+    cfg = readme_config(particleNum=6, maxIteration=8, maxCellPatchNum=6, minCorrelation=0.6)
+    L = po.lib()
+    out = {"scene": "synth.pawn_scene(width=320, height=240, n_seeds=24); particleNum 6, maxIteration 8, maxCellPatchNum 6, minCorrelation 0.6",
+           "image_sha1": [hashlib.sha1(c.image.tobytes()).hexdigest() for c in scene.cameras], "runs": []}
+
+    def cloud_of(mo):
+        pts = []
+        for i in range(L.po_mvs_num_slots(mo)):
+            pp = L.po_mvs_get_patch(mo, i)
+            if pp:
+                p = pp.contents
+                pts.append((i, list(p.center[:]), list(p.normalS[:]), p.cams(), p.fitness, p.correlation))
+        return pts
+
+    def digest(pts):
+        h = hashlib.sha1()
+        for i, c, ns, cams, fit, corr in pts:
+            h.update(struct.pack(">i", i))
+            for v in c + ns + [fit, corr]:
+                h.update(struct.pack(">d", v))
+            h.update(bytes(cams))
+        return h.hexdigest()
+
+    for B, thin, rounds in ((1, 64, 30), (8, 64, 20), (8, 0, 20)):
+        S = common.oracle_scene(cfg, scene)
+        mo = L.po_mvs_create(S.ptr)
+        for X, vis in scene.seeds:
+            L.po_mvs_add_seed(mo, po.darr(X), len(vis), po.iarr(vis))
+        L.po_mvs_refine_seed_patches(mo)
+        L.po_mvs_set_thin_front(mo, thin)
+        L.po_mvs_expansion_patches(mo, B, rounds, 1)
+        pts = cloud_of(mo)
+        rec = {"B": B, "thin_front": thin, "max_rounds": rounds, "patches": len(pts), "refine_calls": int(L.po_mvs_refine_calls(mo)),
+               "cloud_sha1": digest(pts)}
+        if B == 8 and thin == 64:
+            # the `-f` chain on this cloud, loaded the way a .mvs file is
+            m2 = L.po_mvs_create(S.ptr)
+            for i, c, ns, cams, fit, corr in pts:
+                L.po_mvs_load_patch(m2, po.darr(c), po.darr(ns), len(cams), po.iarr(cams), fit, corr)
+            alive = []
+            L.po_mvs_cell_filtering(m2); alive.append(len(cloud_of(m2)))
+            L.po_mvs_visibility_filtering(m2); alive.append(len(cloud_of(m2)))
+            L.po_mvs_neighbor_cell_filtering(m2, 0.25); alive.append(len(cloud_of(m2)))
+            L.po_mvs_neighbor_patch_filtering(m2, 0.25, None); alive.append(len(cloud_of(m2)))
+            rec["filter_chain_alive"] = alive
+            rec["filter_chain_ids_sha1"] = hashlib.sha1(bytes(str([p[0] for p in cloud_of(m2)]), "ascii")).hexdigest()
+            L.po_mvs_destroy(m2)
+        L.po_mvs_destroy(mo)
+        out["runs"].append(rec)
+    # reCentering
+    S = common.oracle_scene(cfg, scene)
+    rc = []
+    for k, (X, vis) in enumerate(scene.seeds[:6]):
+        meas = []
+        for c in vis:
+            cam = scene.cameras[c]
+            q = cam.rotation @ np.asarray(X, float) + cam.translation
+            meas += [cam.focal[0] * q[0] / q[2] + cam.principle_point[0] + 0.25 * ((k + c) % 3 - 1),
+                     cam.focal[1] * q[1] / q[2] + cam.principle_point[1] - 0.5 * ((k * c) % 2)]
+        got = (C.c_double * 3)()
+        L.po_recenter(S.ptr, len(vis), po.iarr(vis), po.darr(meas), got)
+        rc.append({"seed": k, "meas": [hexd(v) for v in meas], "center": [hexd(v) for v in got]})
+    out["recenter"] = rc
+    return out
+
+
 if __name__ == "__main__":
     json.dump(pso_traces(), open(os.path.join(HERE, "pso_reference_traces.json"), "w"), indent=0)
     json.dump(cost_vectors(), open(os.path.join(HERE, "oracle_cost_vectors.json"), "w"), indent=0)
+    json.dump(schedule_vectors(), open(os.path.join(HERE, "oracle_schedule_vectors.json"), "w"), indent=0)
     print("golden vectors written")
