@@ -151,6 +151,11 @@ def cpu_baseline(cfg, scene, budget_s: float, n_seed_units: int, n_expand_units:
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON of rank 0: libraries that write to the C-level stdout (RCCL prints a
+    # version banner there) are sent to stderr for the whole run, the JSON goes out through the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -163,7 +168,11 @@ def main():
         local = int(os.environ["PAIS_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("PAIS_FORCE_DIST") == "1"   # test hook: the multi-rank code path with one rank
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PAIS_DIST_BACKEND", "nccl")
@@ -178,14 +187,14 @@ def main():
 
     cfg, scene, wname = build_scene(args)
     m = MVS(cfg, scene.cameras, device=local, seed=42)
-    ex = D.torch_gpu_exchange(m, rank, world) if world > 1 else None
+    ex = D.torch_gpu_exchange(m, rank, world) if (world > 1 or force_dist) else None
     B = args.parents_per_round
 
     def step():
         m.reset()
         for X, vis in scene.seeds:
             m.add_seed(X, vis)
-        if world == 1:
+        if ex is None:
             m.refineSeedPatches()
             m.expansionPatches(B, args.max_rounds)
         else:
@@ -278,7 +287,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, scene, args.cpu_seconds, int(last.seeds_refined), int(last.candidates_effective))
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
     m.close()
