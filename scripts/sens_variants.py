@@ -6,6 +6,11 @@ SRC = os.path.join(ROOT, "pais_mvs_amd", "csrc")
 OUT = os.path.join(SRC, "variants")
 VARS = {
     "base": [],
+    # compiler scheduling strategies (no source change)
+    "sched_ilp": "DEFINE:PAIS_DUMMY -mllvm -amdgpu-sched-strategy=max-ilp",
+    "sched_mem": "DEFINE:PAIS_DUMMY -mllvm -amdgpu-sched-strategy=max-memory-clause",
+    "sched_iter_ilp": "DEFINE:PAIS_DUMMY -mllvm -amdgpu-sched-strategy=iterative-ilp",
+    "sched_aa": "DEFINE:PAIS_DUMMY -mllvm -amdgpu-use-aa-in-codegen",
     "ns4w2": "DEFINE:PAIS_NS=4 -DPAIS_ITER_WAVES=2",
     "ns3w2": "DEFINE:PAIS_NS=3 -DPAIS_ITER_WAVES=2",
     "ns1w4": "DEFINE:PAIS_NS=1 -DPAIS_ITER_WAVES=4",
