@@ -601,76 +601,6 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
 
     if (f->refImg[(size_t)cv_round(y) * f->refCols + cv_round(x)] == 0) return 0; /* :986 */
 
-    if (s->detMath) {
-        /* "kernel arithmetic" (DESIGN.md 5.3): the same quantities as the literal branch
-         * below, evaluated the way the HIP kernel does -- homography rows with fma, one
-         * reciprocal per camera group, bilinear as three fma lerps, polynomial exp (po_det_exp_poly), mean/SAD scaled by 1/K, fdlibm exp.
-         * Differs from the literal branch in the last bits only. */
-        const double invK = 1.0 / (double)camNum, invDiffW = 1.0 / s->cfg.diffWeighting;
-        double sum = 0;
-        for (int i0 = 0; i0 < camNum;) {
-            /* cameras are handled in groups with ONE reciprocal per group (batch inversion): pairs, and one
-             * triple at the end when the camera count is odd (a single camera only for camNum == 1) */
-            const int left = camNum - i0;
-            const int g = (left >= 4 || left == 2) ? 2 : (left == 3 ? 3 : 1);
-            double ww[3], nx[3], ny[3], rw[3];
-            for (int u = 0; u < g; ++u) {
-                const double *Hi = f->H + 9 * (i0 + u);
-                ww[u] = fma(Hi[7], y, fma(Hi[6], x, Hi[8]));
-                nx[u] = fma(Hi[1], y, fma(Hi[0], x, Hi[2]));
-                ny[u] = fma(Hi[4], y, fma(Hi[3], x, Hi[5]));
-            }
-            if (g == 3) {
-                const double p01 = ww[0] * ww[1];
-                const double r = 1.0 / (p01 * ww[2]);
-                rw[2] = r * p01;
-                const double r01 = r * ww[2];
-                rw[0] = r01 * ww[1];
-                rw[1] = r01 * ww[0];
-            } else if (g == 2) {
-                const double r = 1.0 / (ww[0] * ww[1]);
-                rw[0] = r * ww[1];
-                rw[1] = r * ww[0];
-            } else {
-                rw[0] = 1.0 / ww[0];
-            }
-            /* the kernel flags every bad tap of the group before giving up: same result, DBL_MAX */
-            for (int u = 0; u < g; ++u) {
-                const po_camera *cam = &s->cams[patch->camIdx[i0 + u]];
-                const int cols = cam->width[LOD], rows = cam->height[LOD];
-                const double jx = nx[u] * rw[u], jy = ny[u] * rw[u];
-                if (!(jx >= 2 && jx < cols - 3 && jy >= 2 && jy < rows - 3)) return -1;
-            }
-            for (int u = 0; u < g; ++u) {
-                const int i = i0 + u;
-                const po_camera *cam = &s->cams[patch->camIdx[i]];
-                const uint8_t *img = cam->img[LOD];
-                const int cols = cam->width[LOD];
-                const double jx = nx[u] * rw[u], jy = ny[u] * rw[u];
-                const int qx = (int)jx, qy = (int)jy;
-                const double bx = jx - (double)qx, by = jy - (double)qy;
-                const uint8_t *r0 = img + (size_t)qy * cols + qx, *r1 = r0 + cols;
-                /* three lerps a + f (b - a); the pixel differences are exact */
-                const double t0 = fma(bx, (double)((int)r0[1] - (int)r0[0]), (double)r0[0]);
-                const double t1 = fma(bx, (double)((int)r1[1] - (int)r1[0]), (double)r1[0]);
-                c[i] = fma(by, t1 - t0, t0);
-                sum += c[i];
-            }
-            i0 += g;
-        }
-        mean = sum * invK;
-        for (int i = 0; i < camNum; i++) avgSad += fabs(c[i] - mean);
-        avgSad *= invK;
-        double weight = 1;
-        if (s->cfg.adaptiveDistanceEnable) weight *= distW;
-        if (s->cfg.adaptiveDifferenceEnable) weight *= po_det_exp_poly(-(avgSad * avgSad) * invDiffW);
-        if (s->cfg.adaptiveGradientEnable)
-            weight *= po_det_exp_poly(-1.0 / (f->edgeImg[(size_t)cv_round(y) * f->refCols + cv_round(x)] * s->cfg.gradientWeighting));
-        *weightOut = weight;
-        *sadOut = avgSad;
-        return 1;
-    }
-
     for (int i = 0; i < camNum; ++i) {
         const po_camera *cam = &s->cams[patch->camIdx[i]];
         const uint8_t *img = cam->img[LOD];
@@ -712,10 +642,135 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
 }
 
 /* ------------------------------------------------------------------------ */
+/* "Kernel arithmetic" v5 of the cost: the same function as   */
+/* po_get_fitness's literal branch, evaluated the way the HIP kernels do      */
+/* (pais_mvs_amd/csrc/pais_eval.hpp) -- differs in the last bits only:        */
+/*  * every particle's centre ray*depth + C_ref projects to the same point of */
+/*    the reference camera up to rounding, so the window origin is taken once */
+/*    per run from ray*1 + C_ref, and with it the mask, the reference camera's*/
+/*    own colour (identity homography: a bilinear sample at (x, y)) and the   */
+/*    distance / gradient weights of every window pixel;                      */
+/*  * homography rows with fma, ONE reciprocal per group of the other cameras */
+/*    (pairs, one triple for an odd count), bilinear as three lerps,          */
+/*    colours summed reference first, mean / SAD scaled by 1/K, polynomial    */
+/*    exp, weight = (dist * grad) * diff;                                     */
+/*  * pixel k = yi*S + xi goes to lane k%64 of sub-accumulator (k/64)%4; each */
+/*    (sub-accumulator, lane) adds its pixels in increasing k; wave64         */
+/*    butterfly per sub-accumulator, then ((a0 + a1) + a2) + a3.              */
+/* ------------------------------------------------------------------------ */
+static double lerp3_u8(const uint8_t *img, int cols, int qx, int qy, double bx, double by)
+{
+    const uint8_t *r0 = img + (size_t)qy * cols + qx, *r1 = r0 + cols;
+    /* three lerps a + f (b - a); the pixel differences are exact */
+    const double t0 = fma(bx, (double)((int)r0[1] - (int)r0[0]), (double)r0[0]);
+    const double t1 = fma(bx, (double)((int)r1[1] - (int)r1[0]), (double)r1[0]);
+    return fma(by, t1 - t0, t0);
+}
+
+static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const double pos[3])
+{
+    const int r = s->cfg.patchRadius, S = s->cfg.patchSize;
+    const int LOD = patch->LOD;
+    const po_camera *refCam = &s->cams[patch->refCamIdx];
+    const int K = patch->numCam;
+    const uint8_t *refImg = refCam->img[LOD];
+    const double *edgeImg = refCam->edge[LOD];
+    const int refCols = refCam->width[LOD], refRows = refCam->height[LOD];
+
+    double normal[3];
+    double sph[2] = {pos[0], pos[1]};
+    s2n(s, sph, normal);
+    if (dot3(normal, refCam->optN) > 0) return DBL_MAX; /* :939 */
+
+    /* the window of the run (:952-962) */
+    double c1[3], pt[2];
+    for (int i = 0; i < 3; ++i) c1[i] = patch->ray[i] * 1.0 + refCam->C[i];
+    if (!po_project(s, patch->refCamIdx, c1, pt, LOD)) return DBL_MAX;
+    if (pt[0] - r < 2 || pt[0] + r >= refCols - 3 || pt[1] - r < 2 || pt[1] + r >= refRows - 3) return DBL_MAX;
+    if (!(fabs(pos[2]) > 0)) return DBL_MAX; /* centre == C_ref: the reference's own projection is 0/0 */
+
+    double center[3];
+    for (int i = 0; i < 3; ++i) center[i] = patch->ray[i] * pos[2] + refCam->C[i]; /* :944 */
+    double H[PO_MAX_VIS * 9];
+    po_homographies(s, patch, center, normal, H); /* :948 */
+
+    /* the first occurrence of the reference camera is served by the window; the others are tapped in camIdx order */
+    int firstRef = -1, other[PO_MAX_VIS], M = 0;
+    for (int i = 0; i < K; ++i) {
+        if (firstRef < 0 && patch->camIdx[i] == patch->refCamIdx) firstRef = i;
+        else other[M++] = i;
+    }
+    const int hasRef = firstRef >= 0;
+    const double invK = 1.0 / (double)K, invDiffW = 1.0 / s->cfg.diffWeighting;
+    const double a0 = pt[0] - r, b0 = pt[1] - r;
+    double pf[4][64] = {{0}}, pw[4][64] = {{0}};
+    double c[PO_MAX_VIS];
+    for (int k = 0; k < S * S; ++k) {
+        const int yi = k / S, xi = k - yi * S;
+        const double x = a0 + (double)xi, y = b0 + (double)yi;
+        const int rx = cv_round(x), ry = cv_round(y);
+        if (refImg[(size_t)ry * refCols + rx] == 0) continue; /* :986 */
+        const int qx0 = (int)x, qy0 = (int)y;
+        const double refCol = lerp3_u8(refImg, refCols, qx0, qy0, x - (double)qx0, y - (double)qy0);
+        double ws = s->cfg.adaptiveDistanceEnable ? s->gauss[xi * S + yi] : 1.0;
+        if (s->cfg.adaptiveGradientEnable) ws *= po_det_exp_poly(-1.0 / (edgeImg[(size_t)ry * refCols + rx] * s->cfg.gradientWeighting));
+        double sum = hasRef ? refCol : 0.0;
+        for (int i0 = 0; i0 < M;) {
+            const int left = M - i0;
+            const int g = (left >= 4 || left == 2) ? 2 : (left == 3 ? 3 : 1);
+            double ww[3], nx[3], ny[3], rw[3];
+            for (int u = 0; u < g; ++u) {
+                const double *Hi = H + 9 * other[i0 + u];
+                ww[u] = fma(Hi[7], y, fma(Hi[6], x, Hi[8]));
+                nx[u] = fma(Hi[1], y, fma(Hi[0], x, Hi[2]));
+                ny[u] = fma(Hi[4], y, fma(Hi[3], x, Hi[5]));
+            }
+            if (g == 3) {
+                const double p01 = ww[0] * ww[1];
+                const double rr = 1.0 / (p01 * ww[2]);
+                rw[2] = rr * p01;
+                const double r01 = rr * ww[2];
+                rw[0] = r01 * ww[1];
+                rw[1] = r01 * ww[0];
+            } else if (g == 2) {
+                const double rr = 1.0 / (ww[0] * ww[1]);
+                rw[0] = rr * ww[1];
+                rw[1] = rr * ww[0];
+            } else {
+                rw[0] = 1.0 / ww[0];
+            }
+            for (int u = 0; u < g; ++u) {
+                const po_camera *cam = &s->cams[patch->camIdx[other[i0 + u]]];
+                const int cols = cam->width[LOD], rows = cam->height[LOD];
+                const double jx = nx[u] * rw[u], jy = ny[u] * rw[u];
+                if (!(jx >= 2 && jx < cols - 3 && jy >= 2 && jy < rows - 3)) return DBL_MAX; /* :999 -- whole call */
+                const int qx = (int)jx, qy = (int)jy;
+                c[i0 + u] = lerp3_u8(cam->img[LOD], cols, qx, qy, jx - (double)qx, jy - (double)qy);
+                sum += c[i0 + u];
+            }
+            i0 += g;
+        }
+        const double mean = sum * invK;
+        double sad = hasRef ? fabs(refCol - mean) : 0.0;
+        for (int i = 0; i < M; ++i) sad += fabs(c[i] - mean);
+        sad *= invK;
+        double weight = ws;
+        if (s->cfg.adaptiveDifferenceEnable) weight *= po_det_exp_poly(-(sad * sad) * invDiffW);
+        const int a = (k >> 6) & 3, l = k & 63;
+        pw[a][l] += weight;
+        pf[a][l] = fma(weight, sad, pf[a][l]);
+    }
+    const double F = ((tree64(pf[0]) + tree64(pf[1])) + tree64(pf[2])) + tree64(pf[3]);
+    const double W = ((tree64(pw[0]) + tree64(pw[1])) + tree64(pw[2])) + tree64(pw[3]);
+    return F / W;
+}
+
+/* ------------------------------------------------------------------------ */
 /* cost: PAIS::getFitness, patch.cpp:914-1047                                */
 /* ------------------------------------------------------------------------ */
 double po_get_fitness(const po_scene *s, const po_patch *patch, const double pos[3])
 {
+    if (s->detMath || s->treeSum) return get_fitness_kernel(s, patch, pos); /* the two switches are set together */
     const int patchRadius = s->cfg.patchRadius;
     const int LOD = patch->LOD;
     const po_camera *refCam = &s->cams[patch->refCamIdx];
@@ -750,41 +805,18 @@ double po_get_fitness(const po_scene *s, const po_patch *patch, const double pos
     double sumWeight = 0;
     double weight, avgSad;
 
-    if (!s->treeSum) {
-        /* the reference's walk: x outer, y inner, sequential sums (patch.cpp:979-1041) */
-        const double *it = s->gauss;
-        for (double x = pt[0] - patchRadius; x <= pt[0] + patchRadius; ++x) {
-            for (double y = pt[1] - patchRadius; y <= pt[1] + patchRadius; ++y, ++it) {
-                int st = fit_pixel(&fx, x, y, *it, &weight, &avgSad);
-                if (st < 0) return DBL_MAX;
-                if (st == 0) continue;
-                sumWeight += weight;
-                fitness += weight * avgSad;
-            }
-        }
-        return fitness / sumWeight;
-    } else {
-        /* the HIP kernels' order: pixel k = yi*S + xi goes to lane k%64 of
-         * sub-accumulator (k/64)%4; every (sub-accumulator, lane) adds its pixels in increasing k;
-         * each sub-accumulator is reduced with the wave64 butterfly and the four are added as
-         * ((a0 + a1) + a2) + a3 -- the shape is the same whether one wave or several share a call */
-        const int S = s->cfg.patchSize;
-        const double a0 = pt[0] - patchRadius, b0 = pt[1] - patchRadius;
-        double pf[4][64] = {{0}}, pw[4][64] = {{0}};
-        for (int k = 0; k < S * S; ++k) {
-            const int yi = k / S, xi = k - yi * S;
-            const double x = a0 + (double)xi, y = b0 + (double)yi;
-            int st = fit_pixel(&fx, x, y, s->gauss[xi * S + yi], &weight, &avgSad);
+    /* the reference's walk: x outer, y inner, sequential sums (patch.cpp:979-1041) */
+    const double *it = s->gauss;
+    for (double x = pt[0] - patchRadius; x <= pt[0] + patchRadius; ++x) {
+        for (double y = pt[1] - patchRadius; y <= pt[1] + patchRadius; ++y, ++it) {
+            int st = fit_pixel(&fx, x, y, *it, &weight, &avgSad);
             if (st < 0) return DBL_MAX;
             if (st == 0) continue;
-            const int a = (k >> 6) & 3, l = k & 63;
-            pw[a][l] += weight;
-            pf[a][l] = s->detMath ? fma(weight, avgSad, pf[a][l]) : pf[a][l] + weight * avgSad;
+            sumWeight += weight;
+            fitness += weight * avgSad;
         }
-        const double F = ((tree64(pf[0]) + tree64(pf[1])) + tree64(pf[2])) + tree64(pf[3]);
-        const double W = ((tree64(pw[0]) + tree64(pw[1])) + tree64(pw[2])) + tree64(pw[3]);
-        return F / W;
     }
+    return fitness / sumWeight;
 }
 
 /* ------------------------------------------------------------------------ */

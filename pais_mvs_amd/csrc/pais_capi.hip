@@ -50,51 +50,52 @@ struct pais_ctx {
     double *d_edge = nullptr;
     double *d_gauss = nullptr;
     size_t imgBytes = 0, edgeBytes = 0;
-    // work buffers
+    // work buffers (grown on demand, never shrunk)
     pais_candidate *d_cands = nullptr;
     pais_patch_result *d_recs = nullptr;
     size_t recCap = 0;
     double *d_hp = nullptr;
     size_t hpBytes = 0;
-    int *d_counters = nullptr;          // [0] PSO work counter, [1] "needs another pass" count, [2] active-list length
+    int *d_counters = nullptr;          // [1] "needs another pass" count, [2] active-list length
     pais_candidate *h_cands = nullptr;  // pinned staging of pais_refine_batch
     pais_patch_result *h_recs = nullptr;
-    unsigned char *d_evalBlocks = nullptr; // per candidate: EvalPatch + EvalCam[K], written by k_pso_init, read by k_pso_iter
+    unsigned char *d_evalBlocks = nullptr; // per candidate: EvalPatch + EvalCam[M] (pais_eval.hpp), written by k_pso_init
     size_t evalBlockCap = 0;
+    unsigned char *d_win = nullptr;     // per candidate: the reference window WinPix[S*S] of the PSO run
+    size_t winCap = 0;
     int *d_active = nullptr;            // compacted indices of the candidates that run a PSO in the current pass
     size_t activeCap = 0;
     unsigned long long *d_stat = nullptr; // [0] evals [1] evals*bytesPerPixel [2] patches [3] ncc tables [4] tables*K
     int *h_counters = nullptr;          // pinned
-    unsigned char *d_psoStates = nullptr; // split pipeline: one PsoState block per candidate
+    unsigned char *d_psoStates = nullptr; // one PsoState block per candidate
     size_t psoStateBytes = 0;
-    int psoMode = 4;                    // 4: one k_pso_iter launch per iteration, pipelined over several streams (default),
-                                        // 1: eval + step kernels per iteration (PAIS_PSO_MODE=split),
-                                        // 2: eval launches with last-arriver step, 3: persistent task-queue kernel,
-                                        // 0: fused one-workgroup-per-candidate k_pso  (measured alternatives)
-    long splitAbove = 0;                // batches of at least this many evaluation waves use k_pso_eval + k_pso_step (set at create)
+    // PSO pass of a batch: small batches run one k_pso_iter launch per iteration (the step is replayed
+    // inside the evaluation waves); batches of at least `splitAbove` evaluation waves are throughput bound and run
+    // k_pso_eval2 + k_pso_step per iteration, cut into slices whose sequences overlap on separate HIP streams
+    long splitAbove = 0;
     int psoMinPer = 64;
     int evalParts = 0;                  // waves per cost evaluation in k_pso_iter (1, 2, 4); 0 = chosen per slice
     double partFill = 1.0;              // ... such that parts * waves <= partFill * resident wave slots
-    int psoStreams = 2;                 // slices of a batch whose eval/step sequences overlap on separate HIP streams
+    int psoStreams = 2;
     std::vector<hipStream_t> sub;       // sub-streams
     std::vector<hipEvent_t> subDone;
     hipEvent_t forkEv = nullptr;
-    int *d_queue = nullptr;
-    size_t queueInts = 0;
-    bool fineTiming = false;            // HIP events around every k_pso_eval launch (bench.py)
-    std::vector<EventPair> evEval;
-    double evalMs = 0;
-    int64_t evalLaunches = 0;
     // fitness batch buffers
     pais_patch_state *d_states = nullptr;
     int32_t *d_idx = nullptr;
     double *d_particles = nullptr, *d_out = nullptr;
     size_t stateCap = 0, evalCap = 0;
-    // timing
-    std::vector<EventPair> evPso, evBegin, evAfter;
+    // neighbour count buffers
+    double *d_nbC = nullptr;
+    int32_t *d_nbN = nullptr;
+    size_t nbCap = 0;
+    // timing: HIP events are recorded only while profiling is on (pais_ctx_set_fine_timing); every pair is returned to
+    // evFree by pais_get_kernel_stats, so the number of live events is bounded by one instrumented batch
+    bool fineTiming = false;
+    std::vector<EventPair> evPso, evBegin, evAfter, evEval;
     std::vector<EventPair> evFree;
-    double psoMs = 0, beginMs = 0, afterMs = 0;
-    int64_t psoLaunches = 0;
+    double psoMs = 0, beginMs = 0, afterMs = 0, evalMs = 0;
+    int64_t psoLaunches = 0, evalLaunches = 0;
 };
 
 // MVS::initPatchDistanceWeighting, mvs.cpp:97-114 (host; same arithmetic as the reference)
@@ -251,8 +252,6 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     HIPCHK(hipMalloc(&ctx->d_stat, sizeof(unsigned long long) * 8));
     HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
     HIPCHK(hipHostMalloc((void **)&ctx->h_counters, sizeof(int) * 4, hipHostMallocDefault));
-    if (const char *e = getenv("PAIS_PSO_MODE"))
-        ctx->psoMode = (strcmp(e, "fused") == 0) ? 0 : (strcmp(e, "laststep") == 0) ? 2 : (strcmp(e, "persist") == 0) ? 3 : (strcmp(e, "split") == 0) ? 1 : 4;
     if (const char *e = getenv("PAIS_EVAL_PARTS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) ctx->evalParts = v; }
     if (const char *e = getenv("PAIS_PART_FILL")) { double v = atof(e); if (v > 0) ctx->partFill = v; }
     ctx->splitAbove = 3L * ctx->numCUs * 12;
@@ -283,7 +282,11 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     };
     freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evEval); freeEv(ctx->evFree);
     (void)hipFree(ctx->d_psoStates);
-    (void)hipFree(ctx->d_queue);
+    (void)hipFree(ctx->d_win);
+    (void)hipFree(ctx->d_nbC); (void)hipFree(ctx->d_nbN);
+    for (auto st : ctx->sub) (void)hipStreamDestroy(st);
+    for (auto ev : ctx->subDone) (void)hipEventDestroy(ev);
+    if (ctx->forkEv) (void)hipEventDestroy(ctx->forkEv);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_imgF); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
     (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active); (void)hipFree(ctx->d_evalBlocks); (void)hipHostFree(ctx->h_cands); (void)hipHostFree(ctx->h_recs);
@@ -320,99 +323,7 @@ extern "C" int pais_ctx_synchronize(pais_ctx *ctx)
     return 0;
 }
 
-// ------------------------------------------------------------ fitness batch --
-static int get_event_pair(pais_ctx *ctx, EventPair &p);
-static int get_event_pair(pais_ctx *ctx, EventPair &p);
-// MVS::neighborPatchFiltering's distance counts (mvs.cpp:448-524) -- see k_neighbor_count
-extern "C" int pais_neighbor_count(pais_ctx *ctx, int n, const double *centers, double radius, int32_t *counts, double *kernel_ms)
-{
-    if (!ctx || n < 0 || (n && (!centers || !counts))) return fail_msg("pais_neighbor_count: bad argument");
-    if (kernel_ms) *kernel_ms = 0;
-    if (n == 0) return 0;
-    HIPCHK(hipSetDevice(ctx->device));
-    double *d_c = nullptr;
-    int32_t *d_n = nullptr;
-    HIPCHK(hipMalloc(&d_c, sizeof(double) * 3 * (size_t)n));
-    if (hipMalloc(&d_n, sizeof(int32_t) * (size_t)n) != hipSuccess) { (void)hipFree(d_c); return fail_msg("pais_neighbor_count: out of device memory"); }
-    int rc = 0;
-    EventPair e{nullptr, nullptr};
-    if (get_event_pair(ctx, e)) rc = -2;
-    if (!rc && hipMemcpyAsync(d_c, centers, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -2;
-    if (!rc) {
-        (void)hipEventRecord(e.a, ctx->stream);
-        if (pais_launch::neighbor_count(d_c, n, radius, d_n, ctx->stream) != hipSuccess) rc = -2;
-        (void)hipEventRecord(e.b, ctx->stream);
-    }
-    if (!rc && hipMemcpyAsync(counts, d_n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = -2;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = -2;
-    if (!rc && kernel_ms) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) *kernel_ms = ms;
-    }
-    if (e.a) ctx->evFree.push_back(e);
-    (void)hipFree(d_c);
-    (void)hipFree(d_n);
-    if (rc) return fail_msg("pais_neighbor_count: HIP failure");
-    return 0;
-}
-
-extern "C" int pais_ctx_set_fine_timing(pais_ctx *ctx, int on)
-{
-    if (!ctx) return fail_msg("pais_ctx_set_fine_timing: bad argument");
-    ctx->fineTiming = on != 0;
-    return 0;
-}
-
-extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_state *states, int n_evals,
-                                  const int32_t *state_index, const double *particles, double *out)
-{
-    if (!ctx || n_states < 0 || n_evals < 0) return fail_msg("pais_fitness_batch: bad argument");
-    if (n_evals == 0) return 0;
-    if (!states || !state_index || !particles || !out) return fail_msg("pais_fitness_batch: null pointer");
-    HIPCHK(hipSetDevice(ctx->device));
-    int Kmax = 1;
-    for (int i = 0; i < n_states; ++i) {
-        const pais_patch_state &s = states[i];
-        if (s.num_cam < 1 || s.num_cam > PAIS_MAX_VIS) return fail_msg("pais_fitness_batch: num_cam out of range");
-        if (s.ref_cam < 0 || s.ref_cam >= ctx->sc.numCams || s.lod < 0 || s.lod >= PAIS_MAX_LEVELS) return fail_msg("pais_fitness_batch: bad ref_cam/lod");
-        for (int k = 0; k < s.num_cam; ++k)
-            if (s.cam_idx[k] < 0 || s.cam_idx[k] >= ctx->sc.numCams) return fail_msg("pais_fitness_batch: bad cam_idx");
-        if (s.num_cam > Kmax) Kmax = s.num_cam;
-    }
-    for (int e = 0; e < n_evals; ++e)
-        if (state_index[e] < 0 || state_index[e] >= n_states) return fail_msg("pais_fitness_batch: bad state_index");
-    if ((size_t)n_states > ctx->stateCap) {
-        (void)hipFree(ctx->d_states);
-        ctx->stateCap = (size_t)n_states * 2;
-        HIPCHK(hipMalloc(&ctx->d_states, sizeof(pais_patch_state) * ctx->stateCap));
-    }
-    if ((size_t)n_evals > ctx->evalCap) {
-        (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_particles); (void)hipFree(ctx->d_out);
-        ctx->evalCap = (size_t)n_evals * 2;
-        HIPCHK(hipMalloc(&ctx->d_idx, sizeof(int32_t) * ctx->evalCap));
-        HIPCHK(hipMalloc(&ctx->d_particles, sizeof(double) * 3 * ctx->evalCap));
-        HIPCHK(hipMalloc(&ctx->d_out, sizeof(double) * ctx->evalCap));
-    }
-    HIPCHK(hipMemcpyAsync(ctx->d_states, states, sizeof(pais_patch_state) * (size_t)n_states, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_idx, state_index, sizeof(int32_t) * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_particles, particles, sizeof(double) * 3 * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
-    EventPair ef;
-    if (ctx->fineTiming) {
-        if (get_event_pair(ctx, ef)) return -2;
-        HIPCHK(hipEventRecord(ef.a, ctx->stream));
-    }
-    HIPCHK(pais_launch::fitness(ctx->sc, ctx->d_states, ctx->d_idx, ctx->d_particles, ctx->d_out, n_evals, Kmax, ctx->stream));
-    if (ctx->fineTiming) { // kernel-only time of k_fitness, reported as eval_ms / eval_launches
-        HIPCHK(hipEventRecord(ef.b, ctx->stream));
-        ctx->evEval.push_back(ef);
-        ctx->evalLaunches++;
-    }
-    HIPCHK(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)n_evals, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return 0;
-}
-
-// ------------------------------------------------------------- refine batch --
+// ------------------------------------------------------------------- timing --
 static int get_event_pair(pais_ctx *ctx, EventPair &p)
 {
     if (!ctx->evFree.empty()) {
@@ -435,7 +346,136 @@ static int drain_events(pais_ctx *ctx, std::vector<EventPair> &v, double &acc)
     v.clear();
     return 0;
 }
+// brackets a region of `st` with an event pair while profiling is on
+struct Timed {
+    pais_ctx *ctx;
+    hipStream_t st;
+    std::vector<EventPair> *into;
+    EventPair e{nullptr, nullptr};
+    bool on;
+    int begin(pais_ctx *c, hipStream_t s, std::vector<EventPair> *v)
+    {
+        ctx = c; st = s; into = v; on = c->fineTiming;
+        if (!on) return 0;
+        if (get_event_pair(c, e)) return -2;
+        HIPCHK(hipEventRecord(e.a, s));
+        return 0;
+    }
+    int end()
+    {
+        if (!on) return 0;
+        HIPCHK(hipEventRecord(e.b, st));
+        into->push_back(e);
+        return 0;
+    }
+};
 
+template <typename T> static int grow(pais_ctx *ctx, T *&ptr, size_t &capBytes, size_t needBytes)
+{
+    if (needBytes <= capBytes) return 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ptr);
+    ptr = nullptr;
+    capBytes = 0;
+    const size_t want = needBytes + needBytes / 2 + 4096;
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, want));
+    ptr = (T *)q;
+    capBytes = want;
+    return 0;
+}
+
+// MVS::neighborPatchFiltering's distance counts (mvs.cpp:448-524) -- see k_neighbor_count
+extern "C" int pais_neighbor_count(pais_ctx *ctx, int n, const double *centers, double radius, int32_t *counts, double *kernel_ms)
+{
+    if (!ctx || n < 0 || (n && (!centers || !counts))) return fail_msg("pais_neighbor_count: bad argument");
+    if (kernel_ms) *kernel_ms = 0;
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    if ((size_t)n > ctx->nbCap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_nbC); (void)hipFree(ctx->d_nbN);
+        ctx->d_nbC = nullptr; ctx->d_nbN = nullptr; ctx->nbCap = 0;
+        const size_t cap = (size_t)n + (size_t)n / 2 + 256;
+        HIPCHK(hipMalloc(&ctx->d_nbC, sizeof(double) * 3 * cap));
+        HIPCHK(hipMalloc(&ctx->d_nbN, sizeof(int32_t) * cap));
+        ctx->nbCap = cap;
+    }
+    EventPair e{nullptr, nullptr};
+    if (get_event_pair(ctx, e)) return -2;
+    HIPCHK(hipMemcpyAsync(ctx->d_nbC, centers, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(e.a, ctx->stream));
+    HIPCHK(pais_launch::neighbor_count(ctx->d_nbC, n, radius, ctx->d_nbN, ctx->stream));
+    HIPCHK(hipEventRecord(e.b, ctx->stream));
+    HIPCHK(hipMemcpyAsync(counts, ctx->d_nbN, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) *kernel_ms = ms;
+    }
+    ctx->evFree.push_back(e);
+    return 0;
+}
+
+extern "C" int pais_ctx_set_fine_timing(pais_ctx *ctx, int on)
+{
+    if (!ctx) return fail_msg("pais_ctx_set_fine_timing: bad argument");
+    ctx->fineTiming = on != 0;
+    return 0;
+}
+
+// ------------------------------------------------------------ fitness batch --
+extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_state *states, int n_evals,
+                                  const int32_t *state_index, const double *particles, double *out)
+{
+    if (!ctx || n_states < 0 || n_evals < 0) return fail_msg("pais_fitness_batch: bad argument");
+    if (n_evals == 0) return 0;
+    if (!states || !state_index || !particles || !out) return fail_msg("pais_fitness_batch: null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    int Kmax = 1;
+    for (int i = 0; i < n_states; ++i) {
+        const pais_patch_state &s = states[i];
+        if (s.num_cam < 1 || s.num_cam > PAIS_MAX_VIS) return fail_msg("pais_fitness_batch: num_cam out of range");
+        if (s.ref_cam < 0 || s.ref_cam >= ctx->sc.numCams || s.lod < 0 || s.lod >= PAIS_MAX_LEVELS) return fail_msg("pais_fitness_batch: bad ref_cam/lod");
+        for (int k = 0; k < s.num_cam; ++k)
+            if (s.cam_idx[k] < 0 || s.cam_idx[k] >= ctx->sc.numCams) return fail_msg("pais_fitness_batch: bad cam_idx");
+        if (s.num_cam > Kmax) Kmax = s.num_cam;
+    }
+    for (int e = 0; e < n_evals; ++e)
+        if (state_index[e] < 0 || state_index[e] >= n_states) return fail_msg("pais_fitness_batch: bad state_index");
+    if ((size_t)n_states > ctx->stateCap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_states);
+        ctx->d_states = nullptr;
+        ctx->stateCap = (size_t)n_states * 2;
+        HIPCHK(hipMalloc(&ctx->d_states, sizeof(pais_patch_state) * ctx->stateCap));
+    }
+    if ((size_t)n_evals > ctx->evalCap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_particles); (void)hipFree(ctx->d_out);
+        ctx->d_idx = nullptr; ctx->d_particles = nullptr; ctx->d_out = nullptr;
+        ctx->evalCap = (size_t)n_evals * 2;
+        HIPCHK(hipMalloc(&ctx->d_idx, sizeof(int32_t) * ctx->evalCap));
+        HIPCHK(hipMalloc(&ctx->d_particles, sizeof(double) * 3 * ctx->evalCap));
+        HIPCHK(hipMalloc(&ctx->d_out, sizeof(double) * ctx->evalCap));
+    }
+    if (grow(ctx, ctx->d_evalBlocks, ctx->evalBlockCap, pais_launch::eval_block_bytes_host(Kmax) * (size_t)n_states)) return -2;
+    if (grow(ctx, ctx->d_win, ctx->winCap, pais_launch::win_bytes_per_candidate(ctx->sc) * (size_t)n_states)) return -2;
+    HIPCHK(hipMemcpyAsync(ctx->d_states, states, sizeof(pais_patch_state) * (size_t)n_states, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_idx, state_index, sizeof(int32_t) * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_particles, particles, sizeof(double) * 3 * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
+    Timed tf;
+    if (tf.begin(ctx, ctx->stream, &ctx->evEval)) return -2; // kernel-only time, reported as eval_ms / eval_launches
+    HIPCHK(pais_launch::fitness(ctx->sc, ctx->d_states, n_states, ctx->d_idx, ctx->d_particles, ctx->d_out, n_evals, Kmax,
+                                ctx->d_evalBlocks, ctx->d_win, ctx->stream));
+    if (tf.end()) return -2;
+    ctx->evalLaunches++;
+    HIPCHK(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)n_evals, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------- refine batch --
 extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out,
                                         int max_num_cam, int has_seeds)
 {
@@ -448,187 +488,95 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     if (Kmax > PAIS_MAX_VIS) Kmax = PAIS_MAX_VIS;
     if (Kmax > sc.numCams) Kmax = sc.numCams;
     if (Kmax < 1) Kmax = 1;
-    const int N = has_seeds ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
-    const int Nmax = N;
-    int W = pais_launch::pso_waves(N, Kmax, Nmax, ctx->ldsLimit);
-    if (const char *e = getenv("PAIS_PSO_WAVES")) { // tuning knob: waves (= concurrent particles) per candidate
-        int w = atoi(e);
-        if (w >= 1 && w <= 8 && pais_launch::pso_lds(w, Kmax, Nmax) <= ctx->ldsLimit) W = w;
-    }
-    if (pais_launch::pso_lds(W, Kmax, Nmax) > ctx->ldsLimit) return fail_msg("pais_refine_batch: LDS budget exceeded (too many visible cameras)");
+    const int Nmax = has_seeds ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
     const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
-    int afterGrid = n < 2048 ? n : 2048;
-    size_t hpNeed = (size_t)afterGrid * Kmax * S2 * sizeof(double);
-    if (hpNeed > ctx->hpBytes) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_hp);
-        ctx->d_hp = nullptr;
-        size_t full = (size_t)2048 * Kmax * S2 * sizeof(double);
-        if (full < ((size_t)1 << 31)) hpNeed = full;
-        HIPCHK(hipMalloc(&ctx->d_hp, hpNeed));
-        ctx->hpBytes = hpNeed;
-    }
-    // persistent PSO grid: as many workgroups as can be resident (launcher caps it)
-    int psoGrid = n < ctx->numCUs * 16 ? n : ctx->numCUs * 16;
-
-    EventPair eb, ep, ea;
-    if (get_event_pair(ctx, eb)) return -2;
-    HIPCHK(hipEventRecord(eb.a, ctx->stream));
-    HIPCHK(pais_launch::begin(sc, d_cands, d_out, n, ctx->stream));
-    HIPCHK(hipEventRecord(eb.b, ctx->stream));
-    ctx->evBegin.push_back(eb);
-
-    if ((size_t)n > ctx->activeCap) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_active);
-        ctx->d_active = nullptr;
-        ctx->activeCap = (size_t)n + (size_t)n / 2 + 64;
-        HIPCHK(hipMalloc(&ctx->d_active, sizeof(int) * ctx->activeCap));
+    const int afterGrid = n < 2048 ? n : 2048;
+    {
+        size_t hpNeed = (size_t)afterGrid * Kmax * S2 * sizeof(double);
+        const size_t full = (size_t)2048 * Kmax * S2 * sizeof(double);
+        if (hpNeed > ctx->hpBytes && full < ((size_t)1 << 31)) hpNeed = full;
+        if (grow(ctx, ctx->d_hp, ctx->hpBytes, hpNeed)) return -2;
     }
     {
-        const size_t needEb = pais_launch::pso_eval_block_bytes(Kmax) * (size_t)n;
-        if (needEb > ctx->evalBlockCap) {
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->d_evalBlocks);
-            ctx->d_evalBlocks = nullptr;
-            ctx->evalBlockCap = needEb + needEb / 2;
-            HIPCHK(hipMalloc(&ctx->d_evalBlocks, ctx->evalBlockCap));
-        }
+        size_t cap = ctx->activeCap * sizeof(int);
+        if (grow(ctx, ctx->d_active, cap, sizeof(int) * (size_t)n)) return -2;
+        ctx->activeCap = cap / sizeof(int);
     }
+    if (grow(ctx, ctx->d_evalBlocks, ctx->evalBlockCap, pais_launch::eval_block_bytes_host(Kmax) * (size_t)n)) return -2;
+    if (grow(ctx, ctx->d_win, ctx->winCap, pais_launch::win_bytes_per_candidate(sc) * (size_t)n)) return -2;
+    const size_t SB = pais_launch::pso_state_bytes_host(Nmax);
+    if (grow(ctx, ctx->d_psoStates, ctx->psoStateBytes, SB * (size_t)n)) return -2;
+    const size_t EB = pais_launch::eval_block_bytes_host(Kmax), WB = pais_launch::win_bytes_per_candidate(sc);
+
+    Timed tb;
+    if (tb.begin(ctx, ctx->stream, &ctx->evBegin)) return -2;
+    HIPCHK(pais_launch::begin(sc, d_cands, d_out, n, ctx->stream));
+    if (tb.end()) return -2;
+
     int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
     const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
+    const int maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
     for (int pass = 0; pass < maxPass; ++pass) {
         HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 3, ctx->stream)); // [2]: length of the active list
-        if (get_event_pair(ctx, ep)) return -2;
-        HIPCHK(hipEventRecord(ep.a, ctx->stream));
-        if (ctx->psoMode == 0) {
-            HIPCHK(pais_launch::pso(sc, d_out, n, ctx->d_counters, ctx->d_stat, Kmax, Nmax, W, psoGrid, ctx->stream));
-        } else {
-            // launch-per-iteration pipeline: init, eval, step(initFitness), then maxIt x (eval, step)
-            const size_t need = pais_launch::pso_split_state_bytes(Nmax) * (size_t)n;
-            if (need > ctx->psoStateBytes) {
-                HIPCHK(hipStreamSynchronize(ctx->stream));
-                (void)hipFree(ctx->d_psoStates);
-                ctx->d_psoStates = nullptr;
-                ctx->psoStateBytes = need + need / 2;
-                HIPCHK(hipMalloc(&ctx->d_psoStates, ctx->psoStateBytes));
+        Timed tp;
+        if (tp.begin(ctx, ctx->stream, &ctx->evPso)) return -2;
+        HIPCHK(pais_launch::pso_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, ctx->d_counters + 2, ctx->d_evalBlocks, ctx->d_win,
+                                     Kmax, ctx->stream));
+        // k_pso_iter needs the swarm of a candidate in the lanes of one wave; a batch of several residency passes
+        // (>= 3 x 12 waves per CU) is throughput bound: there the step replay in every evaluation wave (~13 % of a wave's
+        // time) costs more than a separate one-wave-per-candidate k_pso_step launch per iteration, whose latency the other
+        // sub-stream hides
+        const bool useIter = Nmax <= 64 && (long)n * Nmax < ctx->splitAbove;
+        // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
+        // its length is n at most in the first pass and exactly the "again" count afterwards
+        const int nRun = useIter ? (pass == 0 ? n : againCount) : n;
+        int S = ctx->psoStreams;
+        const int minPer = ctx->psoMinPer; // slices smaller than this only add launch overhead
+        if (nRun < S * minPer) S = (nRun + minPer - 1) / minPer;
+        if (S < 1) S = 1;
+        if (S > 1) HIPCHK(hipEventRecord(ctx->forkEv, ctx->stream));
+        for (int sI = 0; sI < S; ++sI) {
+            const int lo = (int)((long)nRun * sI / S), hi = (int)((long)nRun * (sI + 1) / S);
+            if (hi <= lo) continue;
+            // slice 0 stays on the context's own stream, the others fork to sub-streams and join back
+            const bool own = (S == 1) || (sI == 0);
+            hipStream_t st = own ? ctx->stream : ctx->sub[sI - 1];
+            if (!own) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
+            unsigned char *stp = ctx->d_psoStates + SB * (size_t)lo;
+            // waves per evaluation: a slice that leaves the GPU mostly empty is bound by the latency of
+            // one evaluation wave, so share each evaluation among 4 (2) waves while they all stay resident
+            int parts = 1;
+            if (useIter) {
+                const long waves = (long)(hi - lo) * Nmax, resident = (long)((double)ctx->numCUs * 16 * ctx->partFill);
+                parts = ctx->evalParts > 0 ? ctx->evalParts : (waves * 4 <= resident ? 4 : (waves * 2 <= resident ? 2 : 1));
             }
-            const int maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
-            HIPCHK(pais_launch::pso_split_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, ctx->d_counters + 2, ctx->d_evalBlocks, Kmax, ctx->stream));
-            if (ctx->psoMode == 3) {
-                const size_t qi = pais_launch::pso_queue_ints(n, Nmax, maxIt);
-                if (qi > ctx->queueInts) {
-                    HIPCHK(hipStreamSynchronize(ctx->stream));
-                    (void)hipFree(ctx->d_queue);
-                    ctx->d_queue = nullptr;
-                    ctx->queueInts = qi + qi / 2;
-                    HIPCHK(hipMalloc(&ctx->d_queue, ctx->queueInts * sizeof(int)));
-                }
-                EventPair ee;
-                if (ctx->fineTiming) {
-                    if (get_event_pair(ctx, ee)) return -2;
-                    HIPCHK(hipEventRecord(ee.a, ctx->stream));
-                }
-                HIPCHK(pais_launch::pso_persist(sc, ctx->d_psoStates, n, Nmax, Kmax, maxIt, d_out, ctx->d_stat, ctx->d_queue, ctx->numCUs, ctx->stream));
-                if (getenv("PAIS_DEBUG_QUEUE")) {
-                    int hq[4];
-                    HIPCHK(hipStreamSynchronize(ctx->stream));
-                    HIPCHK(hipMemcpy(hq, ctx->d_queue, sizeof(hq), hipMemcpyDeviceToHost));
-                    fprintf(stderr, "[ptrs] states %p (+%zu) queue %p (+%zu) recs %p hp %p (+%zu)\n", (void *)ctx->d_psoStates, ctx->psoStateBytes, (void *)ctx->d_queue, ctx->queueInts * 4, (void *)d_out, (void *)ctx->d_hp, ctx->hpBytes);
-                    fprintf(stderr, "[queue] n %d Nmax %d Kmax %d maxIt %d -> head %d tail %d active %d cap %d (err %s)\n", n, Nmax, Kmax, maxIt, hq[0], hq[1], hq[2], hq[3], hipGetErrorString(hipGetLastError()));
-                    const size_t SB = pais_launch::pso_split_state_bytes(Nmax);
-                    std::vector<unsigned char> hs(SB * (size_t)n);
-                    HIPCHK(hipMemcpy(hs.data(), ctx->d_psoStates, hs.size(), hipMemcpyDeviceToHost));
-                    // PsoState layout: 12 doubles, iw, gBestFitness, streamBase, then ints gIdx,N,maxIt,iteration,active,run,localK,started,arrived
-                    int cnt[4] = {0, 0, 0, 0};
-                    for (int c = 0; c < n && c < 100000; ++c) {
-                        const int *ip = (const int *)(hs.data() + SB * (size_t)c + 15 * 8);
-                        if (c < 6 || (c % 97) == 0) fprintf(stderr, "   cand %d: gIdx %d N %d maxIt %d it %d active %d run %d K %d started %d arrived %d\n", c, ip[0], ip[1], ip[2], ip[3], ip[4], ip[5], ip[6], ip[7], ip[8]);
-                        cnt[0] += ip[4]; cnt[1] += ip[7]; cnt[2] += (ip[8] != 0); cnt[3] += ip[3];
-                    }
-                    fprintf(stderr, "   still active %d started %d arrived!=0 %d sum(it) %d\n", cnt[0], cnt[1], cnt[2], cnt[3]);
-                }
-                if (ctx->fineTiming) {
-                    HIPCHK(hipEventRecord(ee.b, ctx->stream));
-                    ctx->evEval.push_back(ee);
-                }
+            for (int it = 0; it <= maxIt; ++it) {
+                Timed te; // events on the stream the kernel is launched on
+                if (te.begin(ctx, st, &ctx->evEval)) return -2;
+                if (useIter)
+                    HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat,
+                                                 it, 0, parts, ctx->d_evalBlocks, ctx->d_win, st));
+                else
+                    HIPCHK(pais_launch::pso_eval(sc, stp, hi - lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)lo, ctx->d_win + WB * (size_t)lo, st));
+                if (te.end()) return -2;
                 ctx->evalLaunches++;
-            } else if (ctx->psoMode == 2) {
-                for (int it = 0; it <= maxIt; ++it) {
-                    HIPCHK(pais_launch::pso_split_eval(sc, ctx->d_psoStates, n, Nmax, Kmax, d_out, ctx->d_stat, 1, nullptr, ctx->stream));
-                    ctx->evalLaunches++;
-                }
-            } else {
-                // default: the candidates are cut into contiguous slices; slice s runs its own
-                // (eval, step) x (maxIt+1) sequence on sub-stream s, so the step of one slice (a few
-                // waves, latency bound) overlaps the evaluations of the others and every evaluation
-                // launch fits into one residency pass of the GPU
-                const size_t SB = pais_launch::pso_split_state_bytes(Nmax);
-                // psoMode 4: one k_pso_iter launch per iteration (step folded into the evaluation waves);
-                // needs the swarm of a candidate in the lanes of one wave
-                // ... while the batch is small.  A batch of several residency passes (>= 3 x 12 waves per CU) is throughput
-                // bound: there the step replay in every evaluation wave (~13 % of a wave's time) costs more than a separate
-                // one-wave-per-candidate k_pso_step launch per iteration, whose latency the other sub-stream hides.
-                const bool useIter = ctx->psoMode == 4 && Nmax <= 64 && (long)n * Nmax < ctx->splitAbove;
-                // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
-                // its length is n at most in the first pass and exactly the "again" count afterwards
-                const int nRun = useIter ? (pass == 0 ? n : againCount) : n;
-                int S = ctx->psoStreams;
-                const int minPer = ctx->psoMinPer; // slices smaller than this only add launch overhead
-                if (nRun < S * minPer) S = (nRun + minPer - 1) / minPer;
-                if (S < 1) S = 1;
-                HIPCHK(hipEventRecord(ctx->forkEv, ctx->stream));
-                for (int sI = 0; sI < S; ++sI) {
-                    const int lo = (int)((long)nRun * sI / S), hi = (int)((long)nRun * (sI + 1) / S);
-                    if (hi <= lo) continue;
-                    // slice 0 stays on the context's own stream, the others fork to sub-streams and join back
-                    const bool own = (S == 1) || (sI == 0);
-                    hipStream_t st = own ? ctx->stream : ctx->sub[sI - 1];
-                    if (!own) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
-                    unsigned char *stp = ctx->d_psoStates + SB * (size_t)lo;
-                    // waves per evaluation: a slice that leaves the GPU mostly empty is bound by the latency of
-                    // one evaluation wave, so share each evaluation among 4 (2) waves while they all stay resident
-                    int parts = 1;
-                    if (useIter) {
-                        const long waves = (long)(hi - lo) * Nmax, resident = (long)((double)ctx->numCUs * 16 * ctx->partFill);
-                        parts = ctx->evalParts > 0 ? ctx->evalParts : (waves * 4 <= resident ? 4 : (waves * 2 <= resident ? 2 : 1));
-                    }
-                    for (int it = 0; it <= maxIt; ++it) {
-                        EventPair ee;
-                        const bool timeIt = ctx->fineTiming; // events on the stream the kernel is launched on
-                        if (timeIt) {
-                            if (get_event_pair(ctx, ee)) return -2;
-                            HIPCHK(hipEventRecord(ee.a, st));
-                        }
-                        if (useIter)
-                            HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, it, 0, parts, ctx->d_evalBlocks, st));
-                        else
-                            HIPCHK(pais_launch::pso_split_eval(sc, stp, hi - lo, Nmax, Kmax, d_out + lo, ctx->d_stat, 0,
-                                                             ctx->d_evalBlocks + pais_launch::pso_eval_block_bytes(Kmax) * (size_t)lo, st));
-                        if (timeIt) {
-                            HIPCHK(hipEventRecord(ee.b, st));
-                            ctx->evEval.push_back(ee);
-                        }
-                        ctx->evalLaunches++;
-                        if (!useIter) HIPCHK(pais_launch::pso_split_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
-                    }
-                    // the launch after the last possible iteration only ends the runs still active
-                    if (useIter) HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat, maxIt + 1, 1, parts, ctx->d_evalBlocks, st));
-                    if (!own) {
-                        HIPCHK(hipEventRecord(ctx->subDone[sI - 1], st));
-                        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
-                    }
-                }
+                if (!useIter) HIPCHK(pais_launch::pso_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
+            }
+            // the launch after the last possible iteration only ends the runs still active
+            if (useIter)
+                HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat,
+                                             maxIt + 1, 1, parts, ctx->d_evalBlocks, ctx->d_win, st));
+            if (!own) {
+                HIPCHK(hipEventRecord(ctx->subDone[sI - 1], st));
+                HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
             }
         }
-        HIPCHK(hipEventRecord(ep.b, ctx->stream));
-        ctx->evPso.push_back(ep);
+        if (tp.end()) return -2;
         ctx->psoLaunches++;
-        if (get_event_pair(ctx, ea)) return -2;
-        HIPCHK(hipEventRecord(ea.a, ctx->stream));
+        Timed ta;
+        if (ta.begin(ctx, ctx->stream, &ctx->evAfter)) return -2;
         HIPCHK(pais_launch::after(sc, d_out, n, ctx->d_hp, afterGrid, ctx->d_counters, ctx->d_stat, Kmax, ctx->stream));
-        HIPCHK(hipEventRecord(ea.b, ctx->stream));
-        ctx->evAfter.push_back(ea);
+        if (ta.end()) return -2;
         if (!has_seeds) break;
         HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,404 @@
+// pais_eval.hpp -- PAIS::getFitness (TMVS/mvs/patch.cpp:914-1047) for one particle, executed by one wave64.
+// Device-only; included by pais_kernels.hip.
+//
+// What a PSO run shares ("evaluation block", built ONCE per run by build_eval_block):
+//   * EvalPatch / EvalCam[M]: the matrices of the reference camera and of the M visible cameras other than the
+//     reference camera, the image offsets at the patch's LOD;
+//   * the reference window.  Every particle's centre is ray * depth + C_ref (patch.cpp:944): it lies on the reference
+//     camera's ray, so its projection into the reference camera (patch.cpp:952) is the same point for every particle
+//     and iteration of the run up to rounding.  The window origin (a0, b0) = project(ray + C_ref) - r is therefore
+//     evaluated once, and with it everything the cost reads from the reference camera per window pixel: the mask
+//     (patch.cpp:986), the reference camera's own colour (its homography is the identity, patch.cpp:317-320: a plain
+//     bilinear sample at (x, y)), the distance weight (patch.cpp:1031) and the gradient weight (patch.cpp:1037).
+//     They are stored as WinPix{refCol, wStat}[S*S] (wStat = -1 for a masked pixel) and read back coalesced.
+// Per particle: the plane-induced homographies of the M other cameras (patch.cpp:290-330), S*S * M bilinear taps,
+// mean / mean absolute deviation over the K colours, the difference weight, the weighted sums.
+//
+// "Kernel arithmetic" v5 (the CPU checker mirrors it statement by statement in its kernel-arithmetic
+// mode): homography rows with fma; ONE reciprocal per camera group (pairs, one triple for an odd count); tap bounds
+// tested on the truncated integer coordinate; bilinear as three lerps a + f (b - a); colours summed reference first,
+// then the other cameras in camIdx order; mean and SAD scaled by 1/K; weight = wStat * exp_poly(-sad^2 / diffW);
+// lane partial sums into four canonical sub-accumulators (64-pixel step mod 4), wave64 xor butterfly,
+// ((a0 + a1) + a2) + a3.
+#pragma once
+
+// ------------------------------------------------------- evaluation block ----
+struct EvalCam {        // one visible camera other than (the first occurrence of) the reference camera
+    double KR[9];
+    double KT[3];
+    uint64_t imgOff;    // into DevScene::imgBlob / imgF at the patch's LOD
+    int w, h;
+    int cam;
+    int qxmax, qymax;   // w - 4, h - 4: largest truncated tap coordinate that passes patch.cpp:999
+    int pad;
+};
+struct EvalPatch {
+    double ray[3], Cref[3], optNref[3], KRref[9], KTref[3];
+    double lodScale;
+    double a0, b0;      // window origin of the run: project(ray + C_ref) - patchRadius
+    int M;              // cameras in EvalCam[]
+    int K;              // visible cameras of the patch (divisor of mean / SAD)
+    int hasRef;         // the reference camera is among the visible ones (always, for patches refine() builds)
+    int valid;          // the window lies inside [2, dim-3) of the reference level (patch.cpp:952-962)
+    int LOD, refCam;
+};
+struct WinPix {
+    double refCol;      // bilinear sample of the reference level at (x, y)
+    double wStat;       // [dist] G(x, y) * [grad] exp(-1 / (edge * gradientWeighting)); -1: masked pixel
+};
+
+// median of three == clamp(v, lo, hi) for lo <= hi, one instruction
+__device__ __forceinline__ int clamp_i32(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+
+// two adjacent pixels of the float image with one 8-byte (4-byte aligned) global load
+struct PixPair { float a, b; };
+__device__ __forceinline__ PixPair load_pair(const float *p)
+{
+    PixPair v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// bilinear as three lerps a + f (b - a) from two row pairs; the pixel differences are exact in float
+__device__ __forceinline__ double lerp3(PixPair r0, PixPair r1, double bx, double by)
+{
+    const double i00 = (double)r0.a, d0 = (double)(r0.b - r0.a);
+    const double i01 = (double)r1.a, d1 = (double)(r1.b - r1.a);
+    const double t0 = fma(bx, d0, i00);
+    const double t1 = fma(bx, d1, i01);
+    return fma(by, t1 - t0, t0);
+}
+
+// 1 / w, correctly rounded for every w whose reciprocal is a normal number: hardware estimate, two Newton steps
+// (relative error ~2^-90 before rounding), one Markstein correction q = y + y (1 - w y) -- the sequence the
+// compiler's IEEE division ends with, without its range scaling (v_div_scale / v_div_fmas / v_div_fixup: 4 fewer
+// instructions per camera group).  Seed independent, i.e. the bits of the CPU's 1.0 / w.  w = 0, inf, NaN, denormal
+// give inf / 0 / NaN, never a finite wrong value of ordinary size: the tap is rejected by its bounds either way.
+__device__ __forceinline__ double rcp_cr(double w)
+{
+#if PAIS_RCP_NEWTON
+    double y = __builtin_amdgcn_rcp(w);
+    double e = fma(-w, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-w, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-w, y, 1.0);
+    return fma(y, e, y);
+#else
+    return 1.0 / w;
+#endif
+}
+
+// Builds the evaluation block of one PSO run; called by all 64 lanes of one wave.
+//   ep, cams : K <= PAIS_MAX_VIS = 64 cameras, one per lane
+//   win      : S*S WinPix
+__device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cams, WinPix *win, const double *ray, int refCam,
+                                 int LOD, int K, const int *camIdx, int lane)
+{
+    const DevCamera &rc = sc.cams[refCam];
+    // the first occurrence of the reference camera is served from the window block; every other camera gets a slot
+    const int myCam = lane < K ? camIdx[lane] : -1;
+    const unsigned long long isRef = __ballot(lane < K && myCam == refCam);
+    const int firstRef = isRef ? (__ffsll((long long)isRef) - 1) : -1;
+    const bool other = lane < K && lane != firstRef;
+    const unsigned long long om = __ballot(other);
+    const int slot = __popcll(om & ((1ull << lane) - 1ull));
+    if (other) {
+        const DevCamera &dc = sc.cams[myCam];
+        EvalCam &e = cams[slot];
+        for (int i = 0; i < 9; ++i) e.KR[i] = dc.KR[i];
+        for (int i = 0; i < 3; ++i) e.KT[i] = dc.KT[i];
+        e.imgOff = dc.imgOff[LOD];
+        e.w = dc.w[LOD];
+        e.h = dc.h[LOD];
+        e.cam = myCam;
+        e.qxmax = dc.w[LOD] - 4;
+        e.qymax = dc.h[LOD] - 4;
+        e.pad = 0;
+    }
+    const double s = sc.lodScale[LOD];
+    const int refW = rc.w[LOD], refH = rc.h[LOD];
+    const int r = sc.cfg.patchRadius;
+    double pt[2];
+    {
+        const double c1[3] = {ray[0] * 1.0 + rc.C[0], ray[1] * 1.0 + rc.C[1], ray[2] * 1.0 + rc.C[2]};
+        project_raw(rc.R, rc.T, rc.focal, rc.pp, s, c1, pt);
+    }
+    bool valid = LOD <= rc.maxLOD && in_image_d(pt, refW, refH);                                                  // :952
+    if (valid && (pt[0] - r < 2 || pt[0] + r >= refW - 3 || pt[1] - r < 2 || pt[1] + r >= refH - 3)) valid = false; // :957
+    const double a0 = pt[0] - r, b0 = pt[1] - r;
+    if (lane == 0) {
+        for (int i = 0; i < 3; ++i) {
+            ep->ray[i] = ray[i];
+            ep->Cref[i] = rc.C[i];
+            ep->optNref[i] = rc.optN[i];
+            ep->KTref[i] = rc.KT[i];
+        }
+        for (int i = 0; i < 9; ++i) ep->KRref[i] = rc.KR[i];
+        ep->lodScale = s;
+        ep->a0 = a0;
+        ep->b0 = b0;
+        ep->M = __popcll(om);
+        ep->K = K;
+        ep->hasRef = firstRef >= 0 ? 1 : 0;
+        ep->valid = valid ? 1 : 0;
+        ep->LOD = LOD;
+        ep->refCam = refCam;
+    }
+    if (!valid) return; // no pixel of the window is ever read
+    const int S = sc.cfg.patchSize, S2 = S * S;
+    const uint8_t *refImg = sc.imgBlob + rc.imgOff[LOD];
+    const float *refF = sc.imgF + rc.imgOff[LOD];
+    const double *refEdge = sc.edgeBlob + rc.edgeOff[LOD];
+    const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useGrad = sc.cfg.adaptiveGradientEnable != 0;
+    const double gradW = sc.cfg.gradientWeighting;
+    for (int k = lane; k < S2; k += 64) {
+        const int yi = k / S, xi = k - yi * S;
+        const double x = a0 + (double)xi, y = b0 + (double)yi; // == the reference's ++x / ++y walk
+        const int rx = cv_round(x), ry = cv_round(y);
+        const int qx = (int)x, qy = (int)y;                   // 2 <= x < w - 3: truncation == floor
+        const double bx = x - (double)qx, by = y - (double)qy;
+        const uint32_t off = (uint32_t)qy * (uint32_t)refW + (uint32_t)qx;
+        WinPix wp;
+        wp.refCol = lerp3(load_pair(refF + off), load_pair(refF + off + (uint32_t)refW), bx, by);
+        double ws = useDist ? sc.gauss[xi * S + yi] : 1.0;
+        if (useGrad) ws *= det_exp_poly(-1.0 / (refEdge[ry * refW + rx] * gradW));
+        wp.wStat = (refImg[ry * refW + rx] != 0) ? ws : -1.0; // :986
+        win[k] = wp;
+    }
+}
+
+// G consecutive cameras of NS window pixels of this lane: homography (fma), ONE reciprocal per (group, pixel),
+// bounds test, two 8-byte row loads and three fma lerps per tap.  No lane-dependent branches; the loads of the
+// G x NS taps are independent so they overlap.
+template <int G, int NS>
+__device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
+                                          int c0, double *x, double *y, uint32_t *badBits, double *sum)
+{
+    static_assert(G >= 1 && G <= 3, "kernel arithmetic is defined for groups of 1, 2, 3 cameras");
+    // opaque re-definition of the pixel coordinates per group: without it the register allocator splits the live
+    // ranges of x and y around the camera loop into one copy per use
+#pragma unroll
+    for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
+    double bx[NS][G], by[NS][G], nx[NS][G], ny[NS][G], w[NS][G], rw[NS][G];
+    const float *base[G];
+    uint32_t off[NS][G], cwv[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const double *H = Hbuf + 9 * (c0 + u);
+        const double h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6], h7 = H[7], h8 = H[8];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            w[q][u] = fma(h7, y[q], fma(h6, x[q], h8));
+            nx[q][u] = fma(h1, y[q], fma(h0, x[q], h2));
+            ny[q][u] = fma(h4, y[q], fma(h3, x[q], h5));
+        }
+    }
+    // one reciprocal per group and pixel (Montgomery batch inversion).  A zero / non-finite w poisons the whole
+    // group, which is right: any overflowing tap makes the whole call DBL_MAX.
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        if (G == 3) {
+            const double p01 = w[q][0] * w[q][G > 1 ? 1 : 0];
+            const double r = rcp_cr(p01 * w[q][G - 1]);
+            rw[q][G - 1] = r * p01;                // 1/w2
+            const double r01 = r * w[q][G - 1];    // 1/(w0 w1)
+            rw[q][0] = r01 * w[q][G > 1 ? 1 : 0];
+            rw[q][G > 1 ? 1 : 0] = r01 * w[q][0];
+        } else if (G == 2) {
+            const double r = rcp_cr(w[q][0] * w[q][G - 1]);
+            rw[q][0] = r * w[q][G - 1];
+            rw[q][G - 1] = r * w[q][0];
+        } else {
+            rw[q][0] = rcp_cr(w[q][0]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const int c = c0 + u;
+        const int qxmax = cams[c].qxmax, qymax = cams[c].qymax;
+        const uint32_t cw = (uint32_t)cams[c].w;
+        base[u] = sc.imgF + cams[c].imgOff; // wave-uniform
+        cwv[u] = cw;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const double ix = nx[q][u] * rw[q][u], iy = ny[q][u] * rw[q][u];
+            // patch.cpp:999 in the integer domain, without branches: for the truncated q = (int)ix,
+            // 2 <= ix < w-3  <=>  2 <= q <= w-4 (NaN converts to 0, +-inf / overflow saturate: all rejected;
+            // w == 0 needs no test of its own: the reciprocal is inf / NaN).  The clamped q addresses the tap,
+            // q != clamp(q) flags the overflow.  frac(ix) == ix - (double)q exactly for an accepted ix.
+            const int qx = (int)ix, qy = (int)iy;
+            const int px = clamp_i32(qx, 2, qxmax), py = clamp_i32(qy, 2, qymax);
+            badBits[q] |= (uint32_t)((px ^ qx) | (py ^ qy));
+            bx[q][u] = __builtin_amdgcn_fract(ix);
+            by[q][u] = __builtin_amdgcn_fract(iy);
+            off[q][u] = (uint32_t)py * cw + (uint32_t)px;
+        }
+    }
+    PixPair r0[NS][G], r1[NS][G];
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            r0[q][u] = load_pair(base[u] + off[q][u]);
+            r1[q][u] = load_pair(base[u] + (off[q][u] + cwv[u]));
+        }
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const double col = lerp3(r0[q][u], r1[q][u], bx[q][u], by[q][u]);
+            myc[((c0 + u) * NS + q) * 64] = col;
+            sum[q] += col;
+        }
+}
+
+// LDS scratch of one evaluating wave
+//   Hbuf : M*9 doubles            (homographies, patch.cpp:290-330)
+//   cbuf : (NS*M + 8)*64 doubles  (per-camera colour of the lane's NS pixels; last 8 rows: the lane's 4 x (fitness,
+//          weight) sub-accumulators)
+#define PAIS_CBUF_ROWS(NS, M) ((NS) * (M) + 8)
+__host__ __device__ inline size_t eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
+__host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax)
+{
+    return eval_block_bytes(Kmax) + sizeof(double) * 9 * (size_t)Kmax + sizeof(double) * 64 * (size_t)PAIS_CBUF_ROWS(NS, Kmax);
+}
+
+// Reduction shape (canonical, independent of how many waves share one evaluation): the 64-pixel steps of the
+// window are dealt round-robin to FOUR sub-accumulators (step mod 4); each is summed per lane over its steps,
+// butterfly-reduced over the 64 lanes, and the four results are added as ((a0 + a1) + a2) + a3.  One wave
+// computes all four (nparts = 1), or `nparts` (2 / 4) waves compute the sub-accumulators a with
+// a mod nparts == part and whoever consumes the fitness adds them -- the same bits either way.
+// Returns 0 and fills f4/w4 (zeros for the sub-accumulators of other parts), or 1 if the call is DBL_MAX.
+template <int NS>
+__device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
+                                  const WinPix *win, double theta, double phi, double depth, int lane, int part, int nparts,
+                                  double *f4, double *w4)
+{
+    f4[0] = f4[1] = f4[2] = f4[3] = 0;
+    w4[0] = w4[1] = w4[2] = w4[3] = 0;
+    double n[3];
+    spherical2normal(theta, phi, n);
+    {
+        double on[3] = {ep->optNref[0], ep->optNref[1], ep->optNref[2]};
+        if (dot3(n, on) > 0) return 1; // patch.cpp:939
+    }
+    if (!ep->valid) return 1;          // :952-962, the same for every particle of the run
+    if (!(fabs(depth) > 0)) return 1;  // centre == C_ref (or NaN): the reference's projection is 0/0 (:952)
+    double center[3];
+    for (int i = 0; i < 3; ++i) center[i] = ep->ray[i] * depth + ep->Cref[i]; // :944
+    const int M = ep->M, K = ep->K;
+    const double s = ep->lodScale;
+    {
+        const double d = -dot3(center, n);
+        double Mref[9], invH[9], kr[9], kt[3];
+        for (int i = 0; i < 9; ++i) kr[i] = ep->KRref[i];
+        for (int i = 0; i < 3; ++i) kt[i] = ep->KTref[i];
+        plane_matrix(d, s, kr, kt, n, Mref);
+        inv3(Mref, invH);
+        for (int c = lane; c < M; c += 64) {
+            double H[9];
+            if (cams[c].cam == ep->refCam) { // :317-320 (a second occurrence of the reference camera)
+                H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0; H[6] = 0; H[7] = 0; H[8] = 1;
+            } else {
+                double Mc[9];
+                for (int i = 0; i < 9; ++i) kr[i] = cams[c].KR[i];
+                for (int i = 0; i < 3; ++i) kt[i] = cams[c].KT[i];
+                plane_matrix(d, s, kr, kt, n, Mc);
+                mul33(Mc, invH, H);
+            }
+            for (int i = 0; i < 9; ++i) Hbuf[c * 9 + i] = H[i];
+        }
+    }
+    wave_sync();
+
+    const int S = sc.cfg.patchSize, S2 = S * S;
+    const double a0 = ep->a0, b0 = ep->b0;
+    const double invDiffW = 1.0 / sc.cfg.diffWeighting;
+    const bool useDiff = sc.cfg.adaptiveDifferenceEnable != 0;
+    const bool hasRef = ep->hasRef != 0;
+    const double invK = 1.0 / (double)K;
+    double *myc = cbuf + lane;
+    double *myacc = cbuf + (size_t)M * NS * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
+#pragma unroll
+    for (int a = 0; a < 8; ++a) myacc[a * 64] = 0;
+
+    // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel index / clamped
+    // addresses for lanes that have no pixel, a masked pixel or an overflowing tap); only wave-uniform
+    // conditions branch.  Contributions are selected at the end.
+    // This wave's steps are part, part + nparts, ...: NS of them per iteration.  The lane's window pixel is
+    // advanced by 64 * nparts pixels per step without a division.
+    const int adv = 64 * nparts;
+    const int qA = adv / S, rA = adv - qA * S; // uniform
+    int yw = (64 * part + lane) / S, xw = (64 * part + lane) - yw * S;
+    for (int st = part; 64 * st < S2; st += NS * nparts) {
+        double x[NS], y[NS], sum[NS];
+        WinPix wp[NS];
+        uint32_t badBits[NS];
+        bool valid[NS];
+        int gi[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int stq = st + q * nparts;
+            const int k = 64 * stq + lane;
+            valid[q] = k < S2; // steps past the window: every lane redoes the last pixel, unused
+            const int yi = valid[q] ? yw : (S - 1), xi = valid[q] ? xw : (S - 1);
+            wp[q] = win[valid[q] ? k : (S2 - 1)]; // requested before the taps so that the latency hides behind them
+            x[q] = a0 + (double)xi;
+            y[q] = b0 + (double)yi;
+            badBits[q] = 0; // != 0: some tap of this pixel left [2, w-3) x [2, h-3)
+            gi[q] = stq & 3; // canonical sub-accumulator of the step
+            xw += rA; yw += qA;
+            yw += (xw >= S) ? 1 : 0;
+            xw -= (xw >= S) ? S : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sum[q] = hasRef ? wp[q].refCol : 0.0;
+        int c0 = 0;
+        for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
+        if (M - c0 == 3) tap_group<3, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
+        else if (M - c0 == 1) tap_group<1, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // a single camera
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (64 * (st + q * nparts) >= S2) break; // uniform: the window has no such step
+            const bool act = valid[q] && (wp[q].wStat >= 0.0);
+            if (__any(act && badBits[q] != 0)) return 1; // :1001 -- whole call
+            const double mean = sum[q] * invK;
+            double sad = hasRef ? fabs(wp[q].refCol - mean) : 0.0;
+            for (int c = 0; c < M; ++c) sad += fabs(myc[(c * NS + q) * 64] - mean);
+            sad *= invK;
+            double weight = wp[q].wStat;
+            if (useDiff) weight *= det_exp_poly(-(sad * sad) * invDiffW);
+            double *pa = myacc + gi[q] * 128;
+            const double w0 = pa[64], f0 = pa[0];
+            pa[64] = act ? (w0 + weight) : w0;
+            pa[0] = act ? fma(weight, sad, f0) : f0;
+        }
+    }
+    // butterflies only for this wave's sub-accumulators (uniform conditions)
+    for (int a = part; a < 4; a += nparts) {
+        f4[a] = wave_sum(myacc[a * 128]);
+        w4[a] = wave_sum(myacc[a * 128 + 64]);
+    }
+    return 0;
+}
+__device__ __forceinline__ double combine_parts(const double *f4, const double *w4)
+{
+    const double F = ((f4[0] + f4[1]) + f4[2]) + f4[3];
+    const double W = ((w4[0] + w4[1]) + w4[2]) + w4[3];
+    return F / W; // NaN when every pixel was masked, as in the reference
+}
+
+// copies the candidate's [EvalPatch][EvalCam x M] block (global, prepared by build_eval_block) into this wave's LDS
+__device__ __forceinline__ void stage_eval_block(unsigned char *smem, const uint64_t *src, int nw, int lane, uint64_t v0, uint64_t v1)
+{
+    uint64_t *dst = (uint64_t *)smem;
+    if (lane < nw) dst[lane] = v0;
+    if (lane + 64 < nw) dst[lane + 64] = v1;
+    for (int q = lane + 128; q < nw; q += 64) dst[q] = src[q];
+}

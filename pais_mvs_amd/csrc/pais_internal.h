@@ -40,28 +40,23 @@ struct DevScene {
 };
 
 namespace pais_launch {
-hipError_t fitness(const DevScene &sc, const pais_patch_state *states, const int32_t *idx, const double *particles,
-                   double *out, int nEvals, int Kmax, hipStream_t stream);
+// evaluation block of a PSO run (pais_eval.hpp): EvalPatch + EvalCam[Kmax] bytes per candidate, and the reference window
+size_t eval_block_bytes_host(int Kmax);
+size_t win_bytes_per_candidate(const DevScene &sc);
+hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
+                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream);
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream);
 hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream);
-int pso_waves(int N, int Kmax, int Nmax, size_t ldsLimit);
-size_t pso_lds(int W, int Kmax, int Nmax);
-hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters, unsigned long long *stat, int Kmax,
-               int Nmax, int W, int grid, hipStream_t stream);
-size_t pso_split_state_bytes(int Nmax);
-hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax,
-                          int *activeList, int *activeCount, unsigned char *evalBlocks, int Kmax, hipStream_t stream);
-size_t pso_eval_block_bytes(int Kmax);
-hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
-                          unsigned long long *stat, int fuseStep, const unsigned char *evalBlocks, hipStream_t stream);
+size_t pso_state_bytes_host(int Nmax);
+hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
+                    int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);
+hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
+                    hipStream_t stream);
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                    int nparts, const unsigned char *evalBlocks, hipStream_t stream);
-size_t pso_queue_ints(int n, int Nmax, int maxIt);
-hipError_t pso_persist(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, int maxIt, pais_patch_result *recs,
-                       unsigned long long *stat, int *qmem, int numCUs, hipStream_t stream);
-hipError_t pso_split_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
-                          unsigned long long *stat, hipStream_t stream);
+                    int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream);
+hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
+                    unsigned long long *stat, hipStream_t stream);
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
                  unsigned long long *stat, int Kmax, hipStream_t stream);
 } // namespace pais_launch

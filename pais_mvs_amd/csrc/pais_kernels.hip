@@ -10,7 +10,6 @@
 //   k_after      : removeInvisibleCamera + setters + seed-loop control  (patch.cpp:156-175, 655-721; mvs.cpp:215,574)
 //   k_fitness    : batched PAIS::getFitness (pais_fitness_batch)
 //   k_neighbor_count : all-pairs neighbour counts of MVS::neighborPatchFiltering   (mvs.cpp:448-524)
-//   k_pso / k_pso_eval / k_pso_persist : measured alternative pipelines (PAIS_PSO_MODE), same results
 //
 // Mapping: one wave per cost evaluation, window pixels <-> lanes (row-major, so neighbouring
 // lanes read neighbouring pixels of the reprojected image rows), the swarm of a candidate <-> lanes in the step, FP64
@@ -26,31 +25,11 @@
 
 using namespace pais;
 
-// Tuning macro of the cost evaluation:
-//   PAIS_EVAL_MIN_WAVES  min waves per SIMD requested from the register allocator (0 = unconstrained)
-// Taps are issued per camera PAIR (measured best of groups of 1/2/4: 104 VGPRs -> 4 waves/SIMD); the
-// pairing is part of the kernel arithmetic (one reciprocal per pair), mirrored by the oracle.
-#ifndef PAIS_EVAL_MIN_WAVES
-#define PAIS_EVAL_MIN_WAVES 0
+// Compile-time tuning of the cost evaluation (scripts/sens_variants.py builds variants):
+//   PAIS_RCP_NEWTON  1: reciprocal of a camera group as estimate + Newton + Markstein correction (pais_eval.hpp rcp_cr)
+#ifndef PAIS_RCP_NEWTON
+#define PAIS_RCP_NEWTON 1
 #endif
-#if PAIS_EVAL_MIN_WAVES > 0
-#define PAIS_EVAL_BOUNDS __launch_bounds__(64, PAIS_EVAL_MIN_WAVES)
-#else
-#define PAIS_EVAL_BOUNDS __launch_bounds__(64)
-#endif
-// k_pso_iter / k_fitness: 3 waves per SIMD (<= 168 VGPRs): two window pixels per lane are in flight (tap_group<G, 2>)
-// and the LDS scratch of a wave (~11 KB at 5 cameras) allows 3.75 waves per SIMD anyway; measured better than
-// 4 waves with spills
-#ifndef PAIS_ITER_WAVES
-#define PAIS_ITER_WAVES 3
-#endif
-#define PAIS_ITER_BOUNDS __launch_bounds__(64, PAIS_ITER_WAVES)
-// rows of 64 doubles in a wave's colour buffer: two per camera (two window pixels per lane in flight) + the 8 lane
-// accumulators of eval_fitness_parts
-#ifndef PAIS_NS
-#define PAIS_NS 2 // window pixels per lane and loop iteration of the cost evaluation
-#endif
-#define PAIS_CBUF_ROWS(K) (PAIS_NS * (K) + 8)
 
 // --------------------------------------------------------------- helpers ---
 __device__ __forceinline__ void wave_sync()
@@ -73,356 +52,47 @@ __device__ __forceinline__ int wave_sum_i(int v)
     return v;
 }
 
-// ------------------------------------------------------- eval patch in LDS --
-struct EvalCam {
-    double KR[9];
-    double KT[3];
-    double xmax, ymax; // (double)(w - 3), (double)(h - 3): upper tap bounds of patch.cpp:999
-    uint64_t imgOff;   // into DevScene::imgBlob
-    int w, h;
-    int cam;
-    int pad;
-    int qxmax, qymax;  // w - 4, h - 4: largest truncated tap coordinate that passes patch.cpp:999
-    int pad2[2];
-};
-struct EvalPatch {
-    double ray[3], Cref[3], optNref[3], Rref[9], Tref[3], fref[2], ppref[2], KRref[9], KTref[3];
-    double lodScale;
-    uint64_t refImgOff, refEdgeOff;
-    int refW, refH;
-    int K, LOD, refCam, pad;
-};
-
-// threads t < K fill cams[t]; thread 0 fills *ep.  Caller synchronises.
-__device__ void fill_eval_patch(const DevScene &sc, EvalPatch *ep, EvalCam *cams, const double *ray,
-                                int refCam, int LOD, int K, const int *camIdx, int tid, int nthreads)
-{
-    for (int c = tid; c < K; c += nthreads) {
-        const DevCamera &dc = sc.cams[camIdx[c]];
-        for (int i = 0; i < 9; ++i) cams[c].KR[i] = dc.KR[i];
-        for (int i = 0; i < 3; ++i) cams[c].KT[i] = dc.KT[i];
-        cams[c].imgOff = dc.imgOff[LOD];
-        cams[c].w = dc.w[LOD];
-        cams[c].h = dc.h[LOD];
-        cams[c].xmax = (double)(dc.w[LOD] - 3);
-        cams[c].ymax = (double)(dc.h[LOD] - 3);
-        cams[c].qxmax = dc.w[LOD] - 4;
-        cams[c].qymax = dc.h[LOD] - 4;
-        cams[c].cam = camIdx[c];
-    }
-    if (tid == 0) {
-        const DevCamera &rc = sc.cams[refCam];
-        for (int i = 0; i < 3; ++i) {
-            ep->ray[i] = ray[i];
-            ep->Cref[i] = rc.C[i];
-            ep->optNref[i] = rc.optN[i];
-            ep->Tref[i] = rc.T[i];
-            ep->KTref[i] = rc.KT[i];
-        }
-        for (int i = 0; i < 9; ++i) {
-            ep->Rref[i] = rc.R[i];
-            ep->KRref[i] = rc.KR[i];
-        }
-        ep->fref[0] = rc.focal[0]; ep->fref[1] = rc.focal[1];
-        ep->ppref[0] = rc.pp[0]; ep->ppref[1] = rc.pp[1];
-        ep->lodScale = sc.lodScale[LOD];
-        ep->refImgOff = rc.imgOff[LOD];
-        ep->refEdgeOff = rc.edgeOff[LOD];
-        ep->refW = rc.w[LOD];
-        ep->refH = rc.h[LOD];
-        ep->K = K;
-        ep->LOD = LOD;
-        ep->refCam = refCam;
-    }
-}
-
-// median of three == clamp(v, lo, hi) for lo <= hi, one instruction
-__device__ __forceinline__ int clamp_i32(int v, int lo, int hi)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
-    return r;
-}
-
-// two adjacent pixels of the float image with one 8-byte (4-byte aligned) global load
-struct PixPair { float a, b; };
-__device__ __forceinline__ PixPair load_pair(const float *p)
-{
-    PixPair v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
-}
-
-// G consecutive cameras of NS window pixels of this lane: homography (fma), ONE reciprocal per (group, pixel),
-// bounds test, two 8-byte row loads and three fma lerps per tap.  No lane-dependent branches; the loads of the
-// G x NS taps are independent so they overlap.  Groups: pairs, and one triple when the camera count is odd
-// (K = 1: single).  NS = 2: the kernel is bound by LDS bandwidth as much as by the VALU -- the homographies and
-// camera constants are wave-uniform values that every lane reads from LDS -- so each read serves two pixels.
-template <int G, int NS>
-__device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
-                                          int c0, double *x, double *y, uint32_t *badBits, double *sum)
-{
-    static_assert(G >= 1 && G <= 3, "kernel arithmetic is defined for groups of 1, 2, 3 cameras");
-    // opaque re-definition of the pixel coordinates per group: without it the register allocator splits the live
-    // ranges of x and y around the camera loop into one copy per use
-#pragma unroll
-    for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
-    double bx[NS][G], by[NS][G], nx[NS][G], ny[NS][G], w[NS][G], rw[NS][G];
-    const float *base[G];
-    uint32_t off[NS][G], cwv[G];
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-        const double *H = Hbuf + 9 * (c0 + u);
-        const double h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6], h7 = H[7], h8 = H[8];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            w[q][u] = fma(h7, y[q], fma(h6, x[q], h8));
-            nx[q][u] = fma(h1, y[q], fma(h0, x[q], h2));
-            ny[q][u] = fma(h4, y[q], fma(h3, x[q], h5));
-        }
-    }
-    // one reciprocal per group and pixel (Montgomery batch inversion).  A zero / non-finite w poisons the whole
-    // group, which is right: any overflowing tap makes the whole call DBL_MAX.
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-        if (G == 3) {
-            const double p01 = w[q][0] * w[q][G > 1 ? 1 : 0];
-            const double r = 1.0 / (p01 * w[q][G - 1]);
-            rw[q][G - 1] = r * p01;                // 1/w2
-            const double r01 = r * w[q][G - 1];    // 1/(w0 w1)
-            rw[q][0] = r01 * w[q][G > 1 ? 1 : 0];
-            rw[q][G > 1 ? 1 : 0] = r01 * w[q][0];
-        } else if (G == 2) {
-            const double r = 1.0 / (w[q][0] * w[q][G - 1]);
-            rw[q][0] = r * w[q][G - 1];
-            rw[q][G - 1] = r * w[q][0];
-        } else {
-            rw[q][0] = 1.0 / w[q][0];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-        const int c = c0 + u;
-        const int qxmax = cams[c].qxmax, qymax = cams[c].qymax;
-        const uint32_t cw = (uint32_t)cams[c].w;
-        base[u] = sc.imgF + cams[c].imgOff; // wave-uniform
-        cwv[u] = cw;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const double ix = nx[q][u] * rw[q][u], iy = ny[q][u] * rw[q][u];
-            // patch.cpp:999 in the integer domain, without branches: for the truncated q = (int)ix,
-            // 2 <= ix < w-3  <=>  2 <= q <= w-4 (NaN converts to 0, +-inf / overflow saturate: all rejected;
-            // w == 0 needs no test of its own: the reciprocal is inf / NaN).  The clamped q addresses the tap,
-            // q != clamp(q) flags the overflow.  frac(ix) == ix - (double)q exactly for an accepted ix.
-            const int qx = (int)ix, qy = (int)iy;
-            const int px = clamp_i32(qx, 2, qxmax), py = clamp_i32(qy, 2, qymax);
-            badBits[q] |= (uint32_t)((px ^ qx) | (py ^ qy));
-            bx[q][u] = __builtin_amdgcn_fract(ix);
-            by[q][u] = __builtin_amdgcn_fract(iy);
-            off[q][u] = (uint32_t)py * cw + (uint32_t)px;
-        }
-    }
-    PixPair r0[NS][G], r1[NS][G];
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            r0[q][u] = load_pair(base[u] + off[q][u]);
-            r1[q][u] = load_pair(base[u] + (off[q][u] + cwv[u]));
-        }
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            // bilinear as three lerps a + f (b - a); the pixel differences are exact in float (integers < 2^24)
-            const double i00 = (double)r0[q][u].a, d0 = (double)(r0[q][u].b - r0[q][u].a);
-            const double i01 = (double)r1[q][u].a, d1 = (double)(r1[q][u].b - r1[q][u].a);
-            const double t0 = fma(bx[q][u], d0, i00);
-            const double t1 = fma(bx[q][u], d1, i01);
-            const double col = fma(by[q][u], t1 - t0, t0);
-            myc[((c0 + u) * NS + q) * 64] = col;
-            sum[q] += col;
-        }
-}
-
-// PAIS::getFitness for one particle, executed by ONE wave (all 64 lanes enter
-// with identical arguments and leave with the identical result).
-//   Hbuf : this wave's LDS scratch, K*9 doubles   (homographies, patch.cpp:290-330)
-//   cbuf : this wave's LDS scratch, (2K+8)*64 doubles (per-camera colour of the lane's two pixels; rows 2K..2K+7:
-//          the lane's 4 x (fitness, weight) sub-accumulators -- in LDS, not registers, to stay at 4 waves/SIMD)
-// Arithmetic ("kernel arithmetic"; mirrored bit for bit by the oracle's
-// detMath/treeSum mode): homography rows with fma, ONE reciprocal per camera group, bilinear as
-// three fma lerps a + f (b - a), mean/SAD scaled by 1/K, exp/sin/cos from pais_detmath.hpp, lane partial
-// sums in increasing pixel index followed by the wave64 xor butterfly.
-// Reduction shape (canonical, independent of how many waves share one evaluation): the 64-pixel steps of the
-// window are dealt round-robin to FOUR sub-accumulators (step mod 4); each is summed per lane over its steps,
-// butterfly-reduced over the 64 lanes, and the four results are added as ((a0 + a1) + a2) + a3.  One wave
-// computes all four (nparts = 1), or `nparts` (2 / 4) waves compute the sub-accumulators a with
-// a mod nparts == part and whoever consumes the fitness adds them -- the same bits either way.
-// Returns 0 and fills f4/w4 (zeros for the sub-accumulators of other parts), or 1 if the call is DBL_MAX.
-template <int NS>
-__device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf,
-                                  double *cbuf, double theta, double phi, double depth, int lane, int part, int nparts,
-                                  double *f4, double *w4)
-{
-    f4[0] = f4[1] = f4[2] = f4[3] = 0;
-    w4[0] = w4[1] = w4[2] = w4[3] = 0;
-    double n[3];
-    spherical2normal(theta, phi, n);
-    {
-        double on[3] = {ep->optNref[0], ep->optNref[1], ep->optNref[2]};
-        if (dot3(n, on) > 0) return 1; // patch.cpp:939
-    }
-    double center[3];
-    for (int i = 0; i < 3; ++i) center[i] = ep->ray[i] * depth + ep->Cref[i]; // :944
-    const int K = ep->K;
-    const double s = ep->lodScale;
-    {
-        const double d = -dot3(center, n);
-        double Mref[9], invH[9], kr[9], kt[3];
-        for (int i = 0; i < 9; ++i) kr[i] = ep->KRref[i];
-        for (int i = 0; i < 3; ++i) kt[i] = ep->KTref[i];
-        plane_matrix(d, s, kr, kt, n, Mref);
-        inv3(Mref, invH);
-        for (int c = lane; c < K; c += 64) {
-            double H[9];
-            if (cams[c].cam == ep->refCam) { // :317-320
-                H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0; H[6] = 0; H[7] = 0; H[8] = 1;
-            } else {
-                double M[9];
-                for (int i = 0; i < 9; ++i) kr[i] = cams[c].KR[i];
-                for (int i = 0; i < 3; ++i) kt[i] = cams[c].KT[i];
-                plane_matrix(d, s, kr, kt, n, M);
-                mul33(M, invH, H);
-            }
-            for (int i = 0; i < 9; ++i) Hbuf[c * 9 + i] = H[i];
-        }
-    }
-    wave_sync();
-
-    double pt[2];
-    {
-        double R[9], T[3], f[2], pp[2];
-        for (int i = 0; i < 9; ++i) R[i] = ep->Rref[i];
-        for (int i = 0; i < 3; ++i) T[i] = ep->Tref[i];
-        f[0] = ep->fref[0]; f[1] = ep->fref[1]; pp[0] = ep->ppref[0]; pp[1] = ep->ppref[1];
-        project_raw(R, T, f, pp, s, center, pt);
-    }
-    const int refW = ep->refW, refH = ep->refH;
-    if (!in_image_d(pt, refW, refH)) return 1; // :952
-    const int r = sc.cfg.patchRadius;
-    if (pt[0] - r < 2 || pt[0] + r >= refW - 3 || pt[1] - r < 2 || pt[1] + r >= refH - 3) return 1; // :957
-
-    const int S = sc.cfg.patchSize, S2 = S * S;
-    const double a0 = pt[0] - r, b0 = pt[1] - r;
-    const uint8_t *refImg = sc.imgBlob + ep->refImgOff;
-    const double *refEdge = sc.edgeBlob + ep->refEdgeOff;
-    const double invDiffW = 1.0 / sc.cfg.diffWeighting, gradW = sc.cfg.gradientWeighting;
-    const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useDiff = sc.cfg.adaptiveDifferenceEnable != 0,
-               useGrad = sc.cfg.adaptiveGradientEnable != 0;
-    const double invK = 1.0 / (double)K;
-    // NS: window pixels per lane and loop iteration (NS of this wave's 64-pixel steps)
-    double *myc = cbuf + lane;
-    double *myacc = cbuf + (size_t)K * NS * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
-#pragma unroll
-    for (int a = 0; a < 8; ++a) myacc[a * 64] = 0;
-
-    // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel index / clamped
-    // addresses for lanes that have no pixel, a masked pixel or an overflowing tap); only wave-uniform
-    // conditions branch.  Contributions are selected at the end.
-    // This wave's steps are part, part + nparts, ...: two of them per iteration.  The lane's window pixel is
-    // advanced by 64 * nparts pixels per step without a division.
-    const int adv = 64 * nparts;
-    const int qA = adv / S, rA = adv - qA * S; // uniform
-    int yw = (64 * part + lane) / S, xw = (64 * part + lane) - yw * S;
-    for (int st = part; 64 * st < S2; st += NS * nparts) {
-        double x[NS], y[NS], wDist[NS], eGrad[NS], sum[NS];
-        uint32_t badBits[NS];
-        uint8_t refMask[NS];
-        bool valid[NS];
-        int gi[NS];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            const int stq = st + q * nparts;
-            valid[q] = 64 * stq + lane < S2; // steps past the window: every lane redoes the last pixel, unused
-            const int yi = valid[q] ? yw : (S - 1), xi = valid[q] ? xw : (S - 1);
-            x[q] = a0 + (double)xi; // == the reference's ++x / ++y walk
-            y[q] = b0 + (double)yi;
-            const int rx = cv_round(x[q]), ry = cv_round(y[q]);
-            // per-pixel operands, requested before the taps so that their latency hides behind them
-            refMask[q] = refImg[ry * refW + rx]; // :986
-            wDist[q] = useDist ? sc.gauss[xi * S + yi] : 1.0;
-            eGrad[q] = useGrad ? refEdge[ry * refW + rx] : 1.0;
-            badBits[q] = 0; // != 0: some tap of this pixel left [2, w-3) x [2, h-3)
-            sum[q] = 0;
-            gi[q] = stq & 3; // canonical sub-accumulator of the step
-            xw += rA; yw += qA;
-            yw += (xw >= S) ? 1 : 0;
-            xw -= (xw >= S) ? S : 0;
-        }
-        int c0 = 0;
-        for (; K - c0 >= 4 || K - c0 == 2; c0 += 2) tap_group<2, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
-        if (K - c0 == 3) tap_group<3, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
-        else if (K - c0 == 1) tap_group<1, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // K == 1
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            if (64 * (st + q * nparts) >= S2) break; // uniform: the window has no such step
-            const bool act = valid[q] && (refMask[q] != 0);
-            if (__any(act && badBits[q] != 0)) return 1; // :1001 -- whole call
-            const double mean = sum[q] * invK;
-            double sad = 0;
-            for (int c = 0; c < K; ++c) sad += fabs(myc[(c * NS + q) * 64] - mean);
-            sad *= invK;
-            double weight = 1;
-            if (useDist) weight *= wDist[q];
-            if (useDiff) weight *= det_exp_poly(-(sad * sad) * invDiffW);
-            if (useGrad) weight *= det_exp_poly(-1.0 / (eGrad[q] * gradW));
-            double *pa = myacc + gi[q] * 128;
-            const double w0 = pa[64], f0 = pa[0];
-            pa[64] = act ? (w0 + weight) : w0;
-            pa[0] = act ? fma(weight, sad, f0) : f0;
-        }
-    }
-    // butterflies only for this wave's sub-accumulators (uniform conditions)
-    for (int a = part; a < 4; a += nparts) {
-        f4[a] = wave_sum(myacc[a * 128]);
-        w4[a] = wave_sum(myacc[a * 128 + 64]);
-    }
-    return 0;
-}
-__device__ __forceinline__ double combine_parts(const double *f4, const double *w4)
-{
-    const double F = ((f4[0] + f4[1]) + f4[2]) + f4[3];
-    const double W = ((w4[0] + w4[1]) + w4[2]) + w4[3];
-    return F / W; // NaN when every pixel was masked, as in the reference
-}
-// one wave evaluates the whole call
-__device__ double eval_fitness(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf,
-                               double *cbuf, double theta, double phi, double depth, int lane)
-{
-    double f4[4], w4[4];
-    if (eval_fitness_parts<PAIS_NS>(sc, ep, cams, Hbuf, cbuf, theta, phi, depth, lane, 0, 1, f4, w4)) return DBL_MAX;
-    return combine_parts(f4, w4);
-}
+#include "pais_eval.hpp"
 
 // ------------------------------------------------------------- k_fitness ---
+// pais_fitness_batch: k_state_blocks builds the evaluation block of every patch state (one wave per state), then
 // one wave (= one 64-thread workgroup) per evaluation
-__global__ PAIS_ITER_BOUNDS void k_fitness(DevScene sc, const pais_patch_state *states, const int32_t *stateIndex,
-                                                const double *particles, double *out, int nEvals, int Kmax)
+__global__ __launch_bounds__(64) void k_state_blocks(DevScene sc, const pais_patch_state *states, int nStates, unsigned char *evalBlocks,
+                                                     size_t evalBlockBytes, WinPix *win)
+{
+    const int lane = threadIdx.x;
+    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    for (int s = blockIdx.x; s < nStates; s += gridDim.x) {
+        const pais_patch_state *st = &states[s];
+        unsigned char *blk = evalBlocks + evalBlockBytes * (size_t)s;
+        build_eval_block(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), win + (size_t)s * S2, st->ray, st->ref_cam, st->lod,
+                         st->num_cam, st->cam_idx, lane);
+    }
+}
+template <int NS>
+__global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_fitness(DevScene sc, const int32_t *stateIndex, const double *particles, double *out,
+                                                                  int nEvals, int Kmax, const unsigned char *evalBlocks, size_t evalBlockBytes,
+                                                                  const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
-    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
+    double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
     double *cbuf = Hbuf + Kmax * 9;
     const int lane = threadIdx.x;
+    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    const int nw = (int)(eval_block_bytes(Kmax) / 8);
     for (int e = blockIdx.x; e < nEvals; e += gridDim.x) {
-        const pais_patch_state *st = &states[stateIndex[e]];
+        const int s = stateIndex[e];
+        const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)s);
+        const uint64_t v0 = lane < nw ? src[lane] : 0, v1 = lane + 64 < nw ? src[lane + 64] : 0;
         __syncthreads();
-        fill_eval_patch(sc, ep, cams, st->ray, st->ref_cam, st->lod, st->num_cam, st->cam_idx, lane, 64);
+        stage_eval_block(smem, src, nw, lane, v0, v1);
         __syncthreads();
-        double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, particles[3 * e], particles[3 * e + 1], particles[3 * e + 2], lane);
-        if (lane == 0) out[e] = v;
+        double f4[4], w4[4];
+        const int bad = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)s * S2, particles[3 * e], particles[3 * e + 1],
+                                               particles[3 * e + 2], lane, 0, 1, f4, w4);
+        if (lane == 0) out[e] = bad ? DBL_MAX : combine_parts(f4, w4);
     }
 }
 
@@ -852,224 +522,6 @@ __global__ __launch_bounds__(64) void k_begin(DevScene sc, const pais_candidate 
     }
 }
 
-// ------------------------------------------------------------------ k_pso ---
-// One workgroup per candidate (pulled from a global counter: PSO runs converge
-// after a data-dependent number of iterations, patch.cpp:180-219 + psosolver.cpp).
-struct PsoHeader {
-    double rangeL[3], rangeU[3], rangeInter[3], init[3];
-    double iw, gBestFitness;
-    uint64_t streamBase;
-    int gIdx, N, maxIt, iteration, conv, cur, run, localK;
-    EvalPatch ep;
-};
-
-__global__ __launch_bounds__(512) void k_pso(DevScene sc, pais_patch_result *recs, int n, int *counters,
-                                              unsigned long long *stat, int Kmax, int Nmax)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6, T = blockDim.x;
-    // carve
-    PsoHeader *hd = (PsoHeader *)smem;
-    size_t off = (sizeof(PsoHeader) + 15) & ~(size_t)15;
-    double(*pos)[3] = (double(*)[3])(smem + off); off += sizeof(double) * 3 * Nmax;
-    double(*vec)[3] = (double(*)[3])(smem + off); off += sizeof(double) * 3 * Nmax;
-    double(*pBest)[3] = (double(*)[3])(smem + off); off += sizeof(double) * 3 * Nmax;
-    double(*nBest)[3] = (double(*)[3])(smem + off); off += sizeof(double) * 3 * Nmax;
-    double *fit = (double *)(smem + off); off += sizeof(double) * Nmax;
-    double *pBestFit = (double *)(smem + off); off += sizeof(double) * Nmax;
-    EvalCam *cams = (EvalCam *)(smem + off); off += sizeof(EvalCam) * Kmax;
-    double *Hall = (double *)(smem + off); off += sizeof(double) * 9 * Kmax * W;
-    double *call = (double *)(smem + off);
-    double *Hbuf = Hall + (size_t)wave * 9 * Kmax;
-    double *cbuf = call + (size_t)wave * 64 * PAIS_CBUF_ROWS(Kmax);
-
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) hd->cur = atomicAdd(&counters[0], 1);
-        __syncthreads();
-        const int c = hd->cur;
-        if (c >= n) break;
-        pais_patch_result *P = &recs[c];
-        if (P->stage != PAIS_STAGE_PSO || P->dropped) continue;
-
-        // ---- Patch::psoOptimization set-up (patch.cpp:183-200)
-        const int type = P->type;
-        const int N = (type == PAIS_TYPE_SEED) ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
-        const int maxIt = (type == PAIS_TYPE_SEED) ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
-        if (tid == 0) {
-            const double ns0 = P->normalS[0], ns1 = P->normalS[1];
-            double L[3] = {0.0, ns1 - M_PI / 2.0, P->depthRange[0]};
-            double U[3] = {M_PI, ns1 + M_PI / 2.0, P->depthRange[1]};
-            if (type != PAIS_TYPE_SEED) {
-                double lo = ns0 - M_PI / sc.cfg.reduceNormalRange, hi = ns0 + M_PI / sc.cfg.reduceNormalRange;
-                L[0] = 0.0 < lo ? lo : 0.0;
-                U[0] = hi < M_PI ? hi : M_PI;
-                L[1] = ns1 - M_PI / sc.cfg.reduceNormalRange;
-                U[1] = ns1 + M_PI / sc.cfg.reduceNormalRange;
-            }
-            for (int d = 0; d < 3; ++d) {
-                hd->rangeL[d] = L[d];
-                hd->rangeU[d] = U[d];
-                hd->rangeInter[d] = U[d] - L[d]; // psosolver.cpp:38
-            }
-            hd->init[0] = ns0; hd->init[1] = ns1; hd->init[2] = P->depth;
-            hd->N = N;
-            hd->maxIt = maxIt;
-            hd->localK = N < 5 ? N : 5; // psosolver.cpp:26
-            hd->run = P->pso_runs;
-            hd->streamBase = stream_base(sc.seed, P->key);
-            hd->iw = 0.8;
-        }
-        fill_eval_patch(sc, &hd->ep, cams, P->ray, P->ref_cam, P->lod, P->num_cam, P->cam_idx, tid, T);
-        __syncthreads();
-
-        // ---- initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
-        {
-            const uint64_t sb = hd->streamBase;
-            const uint32_t run = (uint32_t)hd->run;
-            for (int i = tid; i < N; i += T) {
-                for (int d = 0; d < 3; ++d) {
-                    const double ri = hd->rangeInter[d];
-                    const double u1 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i)));
-                    const double u2 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i) + 1));
-                    double p = (ri * u1) + hd->rangeL[d];
-                    double v = (2.0 * ri * u2) - ri;
-                    if (i == 0) {
-                        p = hd->init[d];
-                        v = (2.0 * ri * uniform_from(sb, run, (uint32_t)(6 * N + d))) - ri;
-                    }
-                    pos[i][d] = p;
-                    vec[i][d] = v;
-                    pBest[i][d] = p;
-                    nBest[i][d] = 0; // particle.cpp:16
-                }
-            }
-        }
-        __syncthreads();
-        // ---- initFitness (:112-119)
-        for (int i = wave; i < N; i += W) {
-            double v = eval_fitness(sc, &hd->ep, cams, Hbuf, cbuf, pos[i][0], pos[i][1], pos[i][2], lane);
-            if (lane == 0) {
-                fit[i] = v;
-                pBestFit[i] = v;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) { // run(): gBest = particles[0].pBest; updateGbest (:137-149, '<=' -> last min)
-            int g = 0;
-            double gf = pBestFit[0];
-            for (int j = 0; j < N; ++j)
-                if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
-            hd->gIdx = g;
-            hd->gBestFitness = gf;
-        }
-        __syncthreads();
-
-        int it = 0;
-        for (; it < maxIt; ++it) {
-            if (tid == 0) { // getDispersionIDX / getVelocityIDX (:70-92), break test (:295)
-                const int g = hd->gIdx;
-                const double g0 = pBest[g][0], g1 = pBest[g][1], g2 = pBest[g][2];
-                double disp = 0;
-                for (int i = 0; i < N; ++i) {
-                    disp += fabs(pos[i][0] - g0);
-                    disp += fabs(pos[i][1] - g1);
-                    disp += fabs(pos[i][2] - g2);
-                }
-                disp /= (double)(3 * N);
-                int conv = 0;
-                if (disp < 0.01) {
-                    double vel = 0;
-                    for (int i = 0; i < N; ++i) {
-                        vel += fabs(vec[i][0]);
-                        vel += fabs(vec[i][1]);
-                        vel += fabs(vec[i][2]);
-                    }
-                    vel /= (double)(3 * N);
-                    conv = vel < 0.01;
-                }
-                hd->conv = conv;
-            }
-            __syncthreads();
-            if (hd->conv) break;
-            // ---- moveParticles (:220-265)
-            {
-                const int g = hd->gIdx;
-                const double gB[3] = {pBest[g][0], pBest[g][1], pBest[g][2]};
-                const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
-                const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
-                const uint64_t sb = hd->streamBase;
-                const uint32_t run = (uint32_t)hd->run;
-                const double iw = hd->iw;
-                const int localK = hd->localK;
-                for (int i = tid; i < N; i += T) {
-                    double u[4];
-                    const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
-                    for (int q = 0; q < 4; ++q) u[q] = uniform_from(sb, run, k0 + q);
-                    pso_move_particle(i, N, localK, iw, u, pos, vec, pBest, nBest, fit, pBestFit, gB, rl, ru);
-                }
-            }
-            __syncthreads();
-            // ---- updateFitness (:121-135)
-            for (int i = wave; i < N; i += W) {
-                double v = eval_fitness(sc, &hd->ep, cams, Hbuf, cbuf, pos[i][0], pos[i][1], pos[i][2], lane);
-                if (lane == 0) {
-                    fit[i] = v;
-                    if (v < pBestFit[i]) {
-                        pBestFit[i] = v;
-                        pBest[i][0] = pos[i][0];
-                        pBest[i][1] = pos[i][1];
-                        pBest[i][2] = pos[i][2];
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid == 0) { // updateGbest + inertia schedule (:301-304)
-                int g = hd->gIdx;
-                double gf = hd->gBestFitness;
-                for (int j = 0; j < N; ++j)
-                    if (pBestFit[j] <= gf) { gf = pBestFit[j]; g = j; }
-                hd->gIdx = g;
-                hd->gBestFitness = gf;
-                double niw = hd->iw - 1.0 / maxIt;
-                hd->iw = niw > 0.4 ? niw : 0.4;
-            }
-            __syncthreads();
-        }
-
-        // ---- write back (patch.cpp:208-213) and the maxFitness gate (:156-159)
-        if (tid == 0) {
-            const int g = hd->gIdx;
-            const double fitness = hd->gBestFitness;
-            const double th = pBest[g][0], ph = pBest[g][1], dp = pBest[g][2];
-            double nn[3];
-            spherical2normal(th, ph, nn);
-            P->fitness = fitness;
-            P->normalS[0] = th;
-            P->normalS[1] = ph;
-            for (int i = 0; i < 3; ++i) P->normal[i] = nn[i];
-            P->depth = dp;
-            for (int i = 0; i < 3; ++i) P->center[i] = hd->ep.ray[i] * dp + hd->ep.Cref[i];
-            P->pso_runs += 1;
-            P->pso_iterations += it;
-            const int evals = N * (1 + it);
-            P->pso_evals += evals;
-            if (fitness > sc.cfg.maxFitness) {
-                P->dropped = 1;
-                P->stage = PAIS_STAGE_DONE;
-            } else {
-                P->stage = PAIS_STAGE_AFTER;
-            }
-            const int K = hd->ep.K;
-            const unsigned long long perEval = (unsigned long long)(4 * K + 1 + (sc.cfg.adaptiveDistanceEnable ? 8 : 0) +
-                                                                    (sc.cfg.adaptiveGradientEnable ? 8 : 0));
-            atomicAdd(&stat[0], (unsigned long long)evals);
-            atomicAdd(&stat[1], (unsigned long long)evals * perEval);
-            atomicAdd(&stat[2], 1ULL);
-        }
-    }
-}
-
 // ------------------------------------- split PSO pipeline (large batches) ---
 // The same GLN-PSO as k_pso, as a launch-per-iteration pipeline:
 //   k_pso_init : per candidate, Patch::psoOptimization set-up + initParticles/setParticle
@@ -1084,7 +536,6 @@ struct PsoState { // one per candidate, in global memory; the per-particle array
     double iw, gBestFitness;
     uint64_t streamBase;
     int gIdx, N, maxIt, iteration, active, run, localK, started;
-    int arrived, pad0;  // particles evaluated in the current launch (last arriver runs the step)
     // what the evaluation reads from the patch (patch.cpp:922-944)
     double ray[3];
     int refCam, LOD, K, pad;
@@ -1123,15 +574,16 @@ __device__ __forceinline__ PsoArrays pso_arrays(unsigned char *base, int Nmax, i
 
 // activeList / activeCount (optional): compacted indices of the candidates that run a PSO in this pass, so that
 // the per-iteration launches create waves only for them (k_pso_iter)
-// evalBlocks (optional): per candidate the EvalPatch + EvalCam[K] image of what the evaluation keeps in LDS, built ONCE per
-// PSO run here; the evaluation waves of k_pso_iter copy it with a few coalesced loads instead of each re-deriving it
-// from the camera table through a serial chain of global loads (that was a quarter of a wave's latency)
+// evalBlocks / win: per candidate the evaluation block of the run (pais_eval.hpp): EvalPatch + EvalCam[M] exactly as the
+// evaluation keeps them in LDS, and the reference window WinPix[S*S]; built ONCE per PSO run here, copied / read coalesced
+// by every evaluation wave of the run
 __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_result *recs, int n, unsigned char *states,
                                                  int Nmax, int *activeList, int *activeCount, unsigned char *evalBlocks,
-                                                 size_t evalBlockBytes)
+                                                 size_t evalBlockBytes, WinPix *win)
 {
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
+    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
@@ -1176,7 +628,6 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
             hd->gBestFitness = DBL_MAX;
             hd->active = 1;
             hd->started = 0;
-            hd->arrived = 0;
             hd->dyn[0].iw = 0.8;
             hd->dyn[0].gBestFitness = DBL_MAX;
             hd->dyn[0].gIdx = 0;
@@ -1188,10 +639,10 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
             if (activeList) activeList[atomicAdd(activeCount, 1)] = c;
         }
         for (int k = lane; k < P->num_cam; k += 64) hd->camIdx[k] = P->cam_idx[k];
-        if (evalBlocks) {
+        {
             unsigned char *blk = evalBlocks + evalBlockBytes * (size_t)c;
-            fill_eval_patch(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), P->ray, P->ref_cam, P->lod, P->num_cam, P->cam_idx,
-                            lane, 64);
+            build_eval_block(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), win + (size_t)c * S2, P->ray, P->ref_cam, P->lod,
+                             P->num_cam, P->cam_idx, lane);
         }
         // initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
         for (int i = lane; i < N; i += 64) {
@@ -1214,117 +665,41 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
     }
 }
 
-__device__ void pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
-                              unsigned char *smem, unsigned long long *stat, int lane, bool fitShared);
-
-// one wave per (candidate, particle).  fuseStep != 0 (default pipeline): the wave that delivers the
-// last fitness of a candidate runs that candidate's step right away (no separate k_pso_step launch).
-// Cross-wave hand-off (MI355X: per-XCD L2s are not coherent, L1 never refreshed): the fitness is
-// published with an agent-scope (sc1, write-through) atomic store, drained with s_waitcnt vmcnt(0),
-// then the arrival counter is bumped with an agent-scope atomic; the last arriver reads the other
-// particles' fitness with agent-scope atomic loads (cdna_hip_programming.md G16, "8-B agent atomics
-// both sides").  Everything else the step reads was written by a previous launch.
-__global__ PAIS_EVAL_BOUNDS void k_pso_eval(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
-                                            pais_patch_result *recs, unsigned long long *stat, int fuseStep,
-                                            const unsigned char *evalBlocks, size_t evalBlockBytes)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    EvalPatch *ep = (EvalPatch *)smem;
-    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
-    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
-    double *cbuf = Hbuf + Kmax * 9;
-    unsigned char *stepSmem = (unsigned char *)(cbuf + (size_t)PAIS_CBUF_ROWS(Kmax) * 64);
-    const int lane = threadIdx.x;
-    const size_t SB = pso_state_bytes(Nmax);
-    const int total = n * Nmax;
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        // candidate-major task order: a candidate's particles are neighbours in the grid, so they finish
-        // together, its step runs early and overlaps with the evaluations of later candidates, and the
-        // waves of one CU gather from the same few image windows
-        const int c = t / Nmax, i = t - c * Nmax;
-        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
-        if (!hd->active || i >= hd->N) continue;
-        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
-        const int N = hd->N;
-        __syncthreads();
-        if (evalBlocks) { // the candidate's evaluation constants as prepared by k_pso_init (same layout as the LDS)
-            const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
-            uint64_t *dst = (uint64_t *)smem;
-            const int nw = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)hd->K) / 8);
-            for (int q = lane; q < nw; q += 64) dst[q] = src[q];
-        } else {
-            fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
-        }
-        __syncthreads();
-        const double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, A.pos[i][0], A.pos[i][1], A.pos[i][2], lane);
-        if (!fuseStep) {
-            if (lane == 0) A.fit[i] = v;
-            continue;
-        }
-        int last = 0;
-        if (lane == 0) {
-            __hip_atomic_store(&A.fit[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int prev = __hip_atomic_fetch_add(&hd->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (prev == N - 1) ? 1 : 0;
-        }
-        last = __shfl(last, 0, 64);
-        if (last) pso_step_wave(sc, recs, c, hd, Nmax, stepSmem, stat, lane, true);
-    }
-}
-
 // The evaluation launch of large batches (split pipeline): one wave per (candidate, particle), nothing but the cost.
 // The candidate's constants come from the block k_pso_init prepared; positions from swarm buffer 0 (k_pso_step).
 template <int NS>
 __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
-                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes)
+                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
-    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
+    double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
     double *cbuf = Hbuf + Kmax * 9;
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
     const int total = n * Nmax;
-    const int nwMax = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax) / 8);
+    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    const int nwMax = (int)(eval_block_bytes(Kmax) / 8);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int c = t / Nmax, i = t - c * Nmax; // candidate-major: a CU's waves gather from the same few image windows
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
         // everything this wave needs from global memory is requested at once -- the run's state flags, the particle and
-        // the first 192 words of the constants -- so that there is ONE memory round trip before the cost starts
+        // the first 128 words of the constants -- so that there is ONE memory round trip before the cost starts
         const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
         const int iLoad = i < Nmax ? i : 0;
         const int active = hd->active, Nrun = hd->N;
         const double p0 = A.pos[iLoad][0], p1 = A.pos[iLoad][1], p2 = A.pos[iLoad][2];
-        const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0,
-                       v2 = lane + 128 < nwMax ? src[lane + 128] : 0;
+        const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0;
         if (!active || i >= Nrun) continue;
         __syncthreads();
-        {
-            uint64_t *dst = (uint64_t *)smem;
-            if (lane < nwMax) dst[lane] = v0;
-            if (lane + 64 < nwMax) dst[lane + 64] = v1;
-            if (lane + 128 < nwMax) dst[lane + 128] = v2;
-            for (int q = lane + 192; q < nwMax; q += 64) dst[q] = src[q]; // more than 5 cameras
-        }
+        stage_eval_block(smem, src, nwMax, lane, v0, v1);
         __syncthreads();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane, 0, 1, f4, w4);
+        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * S2, p0, p1, p2, lane, 0, 1, f4, w4);
         if (lane == 0) A.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
     }
-}
-
-// Intra-launch sharing between waves on different CUs / XCDs (per-XCD L2s are not coherent, a CU's L1 is
-// never refreshed): 8-byte / 4-byte agent-scope relaxed atomics on both sides (cdna_hip_programming.md G16).
-template <typename T> __device__ __forceinline__ T ld_agent(const T *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T> __device__ __forceinline__ void st_agent(T *p, T v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------- k_pso_iter ---
@@ -1336,7 +711,7 @@ template <typename T> __device__ __forceinline__ void st_agent(T *p, T v)
 // :151-265), stores it into the other swarm buffer and evaluates the cost there.  Every wave of a candidate
 // derives the same loop-carried scalars from the same inputs; particle 0's wave stores them (and, when the run
 // ends, the result).  Comparisons and selections are reorganised over lanes, arithmetic is not: each value
-// is produced by the same operation sequence as in pso_step_wave_t / oracle po_pso_run.
+// is produced by the same operation sequence as in pso_step_wave / oracle po_pso_run.
 
 // lexicographic wave arg-min over (key, tie) of the lanes with valid != 0; returns the winner's tie or -1
 __device__ __forceinline__ int wave_argmin_lex(bool valid, double key, int tie)
@@ -1419,15 +794,16 @@ template <int nparts, int NS>
 __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
                                             const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                                            const unsigned char *evalBlocks, size_t evalBlockBytes)
+                                            const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
-    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
+    double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
     double *cbuf = Hbuf + Kmax * 9;
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
+    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
     // nparts (1, 2, 4) consecutive waves share one evaluation: small rounds are bound by the latency of a
     // single evaluation wave, not by throughput.  Every part replays the step (identical results), part 0
     // stores the moved particle, each part stores its sub-accumulators; the consumer -- the step replay of
@@ -1443,9 +819,8 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
         // the candidate's evaluation constants are requested now and stored to LDS after the step replay: their memory
         // round trip overlaps the replay's
         const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
-        const int nwMax = (int)((sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax) / 8);
-        const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0,
-                       v2 = lane + 128 < nwMax ? src[lane + 128] : 0;
+        const int nwMax = (int)(eval_block_bytes(Kmax) / 8);
+        const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0;
         // ... and so is everything the step replay reads: all addresses follow from c, i and the lane alone (particle
         // j of the swarm in lane j), so the run's flags, the swarm and the loop-carried scalars come back in ONE memory
         // round trip; a finished run wastes these loads
@@ -1605,16 +980,10 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
         }
         if (finishOnly) continue; // unreachable for a well-formed schedule: every run has ended by now
         __syncthreads();
-        {   // the candidate's evaluation constants, prepared by k_pso_init: [EvalPatch][EvalCam x K], same layout as the LDS
-            uint64_t *dst = (uint64_t *)smem;
-            if (lane < nwMax) dst[lane] = v0;
-            if (lane + 64 < nwMax) dst[lane + 64] = v1;
-            if (lane + 128 < nwMax) dst[lane + 128] = v2;
-            for (int q = lane + 192; q < nwMax; q += 64) dst[q] = src[q]; // more than 5 cameras
-        }
+        stage_eval_block(smem, src, nwMax, lane, v0, v1); // the run's evaluation block, prepared by k_pso_init
         __syncthreads();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane, part, nparts, f4, w4);
+        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * S2, p0, p1, p2, lane, part, nparts, f4, w4);
         if (lane == 0) {
             if (nparts == 1) {
                 Wb.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
@@ -1628,28 +997,12 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
     }
 }
 
-// task queue of the persistent PSO kernel: header + `cap` int slots (-1 = not yet produced)
-struct PsoQueue {
-    int head;        // next ticket handed to a consumer
-    int tail;        // next slot a producer reserves
-    int activeCands; // candidates whose PSO run has not ended
-    int cap;
-};
-
 // Everything of PsoSolver::run() between two fitness passes, for ONE candidate, by one wave.
 // smem: Nmax*(3*4+2) doubles of LDS scratch.
-//   MODE 0: state written by a previous launch (k_pso_step)
-//   MODE 1: only fit[] was produced in this launch (k_pso_eval with last-arriver step)
-//   MODE 2: persistent kernel -- the whole swarm state is handed from stepper to stepper inside one
-//           launch; returns 1 if the candidate continues (caller enqueues the next N evaluations)
-template <int MODE>
-__device__ int pso_step_wave_t(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
+// Everything it reads was written by a previous launch.  Returns 1 if the run continues.
+__device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
                                unsigned char *smem, unsigned long long *stat, int lane)
 {
-    constexpr bool fitShared = MODE >= 1;
-    // MODE 2: the caller brackets this function with agent-scope acquire / release fences, so the swarm state
-    // handed from the previous stepper can be read and written with plain (wide, cached) accesses
-    constexpr bool allShared = false;
     double(*pos)[3] = (double(*)[3])smem;
     double(*vec)[3] = pos + Nmax;
     double(*pBest)[3] = vec + Nmax;
@@ -1661,20 +1014,20 @@ __device__ int pso_step_wave_t(const DevScene &sc, pais_patch_result *recs, int 
     __syncthreads();
     for (int i = lane; i < N; i += 64) {
         for (int d = 0; d < 3; ++d) {
-            pos[i][d] = allShared ? ld_agent(&A.pos[i][d]) : A.pos[i][d];
-            vec[i][d] = allShared ? ld_agent(&A.vec[i][d]) : A.vec[i][d];
-            pBest[i][d] = allShared ? ld_agent(&A.pBest[i][d]) : A.pBest[i][d];
-            nBest[i][d] = allShared ? ld_agent(&A.nBest[i][d]) : A.nBest[i][d];
+            pos[i][d] = A.pos[i][d];
+            vec[i][d] = A.vec[i][d];
+            pBest[i][d] = A.pBest[i][d];
+            nBest[i][d] = A.nBest[i][d];
         }
-        fit[i] = fitShared ? ld_agent(&A.fit[i]) : A.fit[i];
-        pBestFit[i] = allShared ? ld_agent(&A.pBestFit[i]) : A.pBestFit[i];
+        fit[i] = A.fit[i];
+        pBestFit[i] = A.pBestFit[i];
     }
     __syncthreads();
-    int it = allShared ? ld_agent(&hd->iteration) : hd->iteration;
-    int g = allShared ? ld_agent(&hd->gIdx) : hd->gIdx;
-    double gf = allShared ? ld_agent(&hd->gBestFitness) : hd->gBestFitness;
-    double iw = allShared ? ld_agent(&hd->iw) : hd->iw;
-    const int started = allShared ? ld_agent(&hd->started) : hd->started;
+    int it = hd->iteration;
+    int g = hd->gIdx;
+    double gf = hd->gBestFitness;
+    double iw = hd->iw;
+    const int started = hd->started;
     if (!started) {
         // initFitness (:112-119) + run(): gBest = particles[0].pBest; updateGbest (:137-149)
         for (int i = lane; i < N; i += 64) pBestFit[i] = fit[i];
@@ -1740,36 +1093,19 @@ __device__ int pso_step_wave_t(const DevScene &sc, pais_patch_result *recs, int 
         __syncthreads();
         for (int i = lane; i < N; i += 64) {
             for (int d = 0; d < 3; ++d) {
-                if (allShared) {
-                    st_agent(&A.pos[i][d], pos[i][d]);
-                    st_agent(&A.vec[i][d], vec[i][d]);
-                    st_agent(&A.pBest[i][d], pBest[i][d]);
-                    st_agent(&A.nBest[i][d], nBest[i][d]);
-                } else {
-                    A.pos[i][d] = pos[i][d];
-                    A.vec[i][d] = vec[i][d];
-                    A.pBest[i][d] = pBest[i][d];
-                    A.nBest[i][d] = nBest[i][d];
-                }
+                A.pos[i][d] = pos[i][d];
+                A.vec[i][d] = vec[i][d];
+                A.pBest[i][d] = pBest[i][d];
+                A.nBest[i][d] = nBest[i][d];
             }
-            if (allShared) st_agent(&A.pBestFit[i], pBestFit[i]); else A.pBestFit[i] = pBestFit[i];
+            A.pBestFit[i] = pBestFit[i];
         }
         if (lane == 0) {
-            if (allShared) {
-                st_agent(&hd->iteration, it);
-                st_agent(&hd->gIdx, g);
-                st_agent(&hd->gBestFitness, gf);
-                st_agent(&hd->iw, iw);
-                st_agent(&hd->started, 1);
-                st_agent(&hd->arrived, 0);
-            } else {
-                hd->iteration = it;
-                hd->gIdx = g;
-                hd->gBestFitness = gf;
-                hd->iw = iw;
-                hd->started = 1;
-                hd->arrived = 0;
-            }
+            hd->iteration = it;
+            hd->gIdx = g;
+            hd->gBestFitness = gf;
+            hd->iw = iw;
+            hd->started = 1;
         }
         return 1;
     } else if (lane == 0) {
@@ -1796,7 +1132,6 @@ __device__ int pso_step_wave_t(const DevScene &sc, pais_patch_result *recs, int 
             P->stage = PAIS_STAGE_AFTER;
         }
         hd->active = 0;
-        hd->arrived = 0;
         const int K = hd->K;
         const unsigned long long perEval = (unsigned long long)(4 * K + 1 + (sc.cfg.adaptiveDistanceEnable ? 8 : 0) +
                                                                 (sc.cfg.adaptiveGradientEnable ? 8 : 0));
@@ -1806,120 +1141,7 @@ __device__ int pso_step_wave_t(const DevScene &sc, pais_patch_result *recs, int 
     }
     return 0;
 }
-__device__ void pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
-                              unsigned char *smem, unsigned long long *stat, int lane, bool fitShared)
-{
-    if (fitShared) pso_step_wave_t<1>(sc, recs, c, hd, Nmax, smem, stat, lane);
-    else pso_step_wave_t<0>(sc, recs, c, hd, Nmax, smem, stat, lane);
-}
-
-__device__ __forceinline__ int pso_step_wave_noinline(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd,
-                                                               int Nmax, unsigned char *smem, unsigned long long *stat, int lane)
-{
-    return pso_step_wave_t<2>(sc, recs, c, hd, Nmax, smem, stat, lane);
-}
-
-// ----------------------------------------------------------- persistent PSO ---
-// Resident waves pull (candidate, particle) evaluations from a global FIFO.  The wave that delivers a
-// candidate's last fitness of an iteration runs its step and appends the next N evaluations (or ends
-// the run).  No per-iteration launches, no fill/drain per iteration; every candidate advances at its
-// own pace and the machine stays full until the round's last few candidates finish.
-// Hand-offs: slot value (task id) published only after the producer drained its state stores
-// (s_waitcnt vmcnt(0)); consumers poll with agent-scope loads and read pos[] with agent-scope loads.
-__global__ PAIS_EVAL_BOUNDS void k_pso_persist(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
-                                               pais_patch_result *recs, unsigned long long *stat, int *qmem)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    EvalPatch *ep = (EvalPatch *)smem;
-    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
-    double *Hbuf = (double *)(smem + sizeof(EvalPatch) + sizeof(EvalCam) * Kmax);
-    double *cbuf = Hbuf + Kmax * 9;
-    unsigned char *stepSmem = (unsigned char *)(cbuf + (size_t)PAIS_CBUF_ROWS(Kmax) * 64);
-    PsoQueue *q = (PsoQueue *)qmem;
-    int *slots = qmem + (sizeof(PsoQueue) / sizeof(int));
-    const int lane = threadIdx.x;
-    const size_t SB = pso_state_bytes(Nmax);
-    const int cap = q->cap;
-    for (;;) {
-        int h = 0;
-        if (lane == 0) h = __hip_atomic_fetch_add(&q->head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h = __shfl(h, 0, 64);
-        if (h >= cap) break; // cannot happen for a correctly sized queue; never spin on memory we do not own
-        int task = -1;
-        for (;;) {
-            if (lane == 0) {
-                task = ld_agent(&slots[h]);
-                if (task < 0 && ld_agent(&q->activeCands) <= 0) task = -2;
-            }
-            task = __shfl(task, 0, 64);
-            if (task != -1) break;
-            // back off: thousands of pollers would eat the memory system (MI355X_MICROARCH polling-cost)
-            __builtin_amdgcn_s_sleep(100);
-        }
-        if (task == -3) continue; // placeholder of an inactive candidate / unused particle index
-        if (task < 0) break;      // every run has ended: no task will ever be written to this slot
-        const int c = task / Nmax, i = task - c * Nmax;
-        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
-        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
-        const int N = hd->N;
-        __syncthreads();
-        fill_eval_patch(sc, ep, cams, hd->ray, hd->refCam, hd->LOD, hd->K, hd->camIdx, lane, 64);
-        __syncthreads();
-        const double p0 = ld_agent(&A.pos[i][0]), p1 = ld_agent(&A.pos[i][1]), p2 = ld_agent(&A.pos[i][2]);
-        const double v = eval_fitness(sc, ep, cams, Hbuf, cbuf, p0, p1, p2, lane);
-        int last = 0;
-        if (lane == 0) {
-            st_agent(&A.fit[i], v);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int prev = __hip_atomic_fetch_add(&hd->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (prev == N - 1) ? 1 : 0;
-        }
-        last = __shfl(last, 0, 64);
-        if (!last) continue;
-        // acquire: drop this CU's L1 (and stale remote L2 lines) before reading what the previous stepper wrote
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const int more = pso_step_wave_noinline(sc, recs, c, hd, Nmax, stepSmem, stat, lane);
-        // release: write the new swarm state back before the next iteration's tasks become visible
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int moreU = __shfl(more, 0, 64); // `more` is wave-uniform by construction; keep the compiler honest
-        if (moreU) {
-            int t0 = 0;
-            if (lane == 0) t0 = __hip_atomic_fetch_add(&q->tail, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t0 = __shfl(t0, 0, 64);
-            for (int k = lane; k < N; k += 64)
-                if (t0 + k < cap) st_agent(&slots[t0 + k], c * Nmax + k);
-        } else if (lane == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(&q->activeCands, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// seeds the queue (slots were memset to -1): task ids of every active candidate's particles, -3 for
-// slots of inactive candidates / unused particle indices (consumers skip those)
-__global__ __launch_bounds__(256) void k_pso_enqueue_initial(unsigned char *states, int n, int Nmax, int *qmem, int cap)
-{
-    PsoQueue *q = (PsoQueue *)qmem;
-    int *slots = qmem + (sizeof(PsoQueue) / sizeof(int));
-    const size_t SB = pso_state_bytes(Nmax);
-    const int total = n * Nmax;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int c = t / Nmax, i = t - c * Nmax;
-        const PsoState *hd = (const PsoState *)(states + SB * (size_t)c);
-        const bool on = hd->active && i < hd->N;
-        slots[t] = on ? t : -3;
-        if (on && i == 0) atomicAdd(&q->activeCands, 1);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        q->head = 0;
-        q->tail = total;
-        q->cap = cap;
-    }
-}
-
-// stand-alone step kernel (PAIS_PSO_MODE=split): one wave per candidate
+// the step kernel of large batches: one wave per candidate
 __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result *recs, unsigned char *states, int n,
                                                  int Nmax, unsigned long long *stat)
 {
@@ -1932,7 +1154,7 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         if (!hd->active) continue;
-        pso_step_wave(sc, recs, c, hd, Nmax, smem, stat, lane, false);
+        pso_step_wave(sc, recs, c, hd, Nmax, smem, stat, lane);
     }
 }
 
@@ -2052,16 +1274,24 @@ __global__ __launch_bounds__(256) void k_neighbor_count(const double *centers, i
 // --------------------------------------------------------------- launchers ---
 namespace pais_launch {
 
-static size_t pso_lds_bytes(int W, int Kmax, int Nmax)
-{
-    size_t off = (sizeof(PsoHeader) + 15) & ~(size_t)15;
-    off += sizeof(double) * 3 * Nmax * 4;
-    off += sizeof(double) * Nmax * 2;
-    off += sizeof(EvalCam) * Kmax;
-    off += sizeof(double) * 9 * Kmax * W;
-    off += sizeof(double) * 64 * PAIS_CBUF_ROWS(Kmax) * W;
-    return off;
-}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: the largest size set so far is remembered per
+// (kernel, device), so a second context on another GPU of the same process sets it again
+struct LdsAttr {
+    size_t setFor[64] = {0};
+    hipError_t ensure(const void *fn, size_t lds)
+    {
+        if (lds <= 64 * 1024) return hipSuccess;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) dev = 0;
+        if (lds <= setFor[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) setFor[dev] = lds;
+        return e;
+    }
+};
+
 static size_t after_lds_bytes(int Kmax)
 {
     size_t off = (sizeof(pais_patch_result) + 15) & ~(size_t)15;
@@ -2070,23 +1300,35 @@ static size_t after_lds_bytes(int Kmax)
     off += sizeof(double) * (Kmax + 1); // region ratios + the drop flag of remove_invisible_camera
     return off;
 }
-static size_t fitness_lds_bytes(int Kmax)
-{
-    return sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * PAIS_CBUF_ROWS(Kmax);
-}
+// two window pixels per lane only while the LDS scratch leaves >= 3 waves per SIMD (M = K - 1 cameras are tapped)
+static inline bool two_pixels(int Kmax) { return Kmax <= 6; }
 
-hipError_t fitness(const DevScene &sc, const pais_patch_state *states, const int32_t *idx, const double *particles,
-                   double *out, int nEvals, int Kmax, hipStream_t stream)
+size_t eval_block_bytes_host(int Kmax) { return eval_block_bytes(Kmax); }
+size_t win_bytes_per_candidate(const DevScene &sc) { return sizeof(WinPix) * (size_t)sc.cfg.patchSize * sc.cfg.patchSize; }
+
+template <int NS>
+static hipError_t fitness_launch(const DevScene &sc, const int32_t *idx, const double *particles, double *out, int nEvals, int Kmax,
+                                 const unsigned char *evalBlocks, const void *win, hipStream_t stream)
+{
+    static LdsAttr attr;
+    const size_t lds = eval_lds_bytes(NS, Kmax);
+    hipError_t e = attr.ensure((const void *)k_fitness<NS>, lds);
+    if (e != hipSuccess) return e;
+    const int grid = nEvals < 262144 ? nEvals : 262144;
+    hipLaunchKernelGGL((k_fitness<NS>), dim3(grid), dim3(64), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win);
+    return hipGetLastError();
+}
+hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
+                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream)
 {
     if (nEvals <= 0) return hipSuccess;
-    size_t lds = fitness_lds_bytes(Kmax);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_fitness, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    int grid = nEvals < 65536 ? nEvals : 65536;
-    hipLaunchKernelGGL(k_fitness, dim3(grid), dim3(64), lds, stream, sc, states, idx, particles, out, nEvals, Kmax);
-    return hipGetLastError();
+    hipLaunchKernelGGL(k_state_blocks, dim3(nStates < 65536 ? nStates : 65536), dim3(64), 0, stream, sc, states, nStates, evalBlocks,
+                       eval_block_bytes(Kmax), (WinPix *)win);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return two_pixels(Kmax) ? fitness_launch<2>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream)
+                            : fitness_launch<1>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
 }
 
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream)
@@ -2097,157 +1339,74 @@ hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_res
     return hipGetLastError();
 }
 
-// picks the waves-per-workgroup so that particles divide evenly and the LDS fits
-int pso_waves(int N, int Kmax, int Nmax, size_t ldsLimit)
-{
-    int best = 1;
-    double bestScore = -1;
-    for (int W = 1; W <= 8; ++W) {
-        if (pso_lds_bytes(W, Kmax, Nmax) > ldsLimit) break;
-        int per = (N + W - 1) / W;
-        double eff = (double)N / (double)(per * W); // idle-wave efficiency
-        // prefer ~4..8 waves: enough waves to hide gather latency, several workgroups per CU
-        double score = eff - 0.02 * (W > 8 ? (W - 8) : 0) - 0.03 * (W < 4 ? (4 - W) : 0);
-        if (score > bestScore + 1e-9) {
-            bestScore = score;
-            best = W;
-        }
-    }
-    return best;
-}
-
-hipError_t pso(const DevScene &sc, pais_patch_result *recs, int n, int *counters, unsigned long long *stat, int Kmax,
-               int Nmax, int W, int grid, hipStream_t stream)
-{
-    if (n <= 0) return hipSuccess;
-    size_t lds = pso_lds_bytes(W, Kmax, Nmax);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_pso, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(k_pso, dim3(grid), dim3(64 * W), lds, stream, sc, recs, n, counters, stat, Kmax, Nmax);
-    return hipGetLastError();
-}
 hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_neighbor_count, dim3((n + 255) / 256), dim3(256), 0, stream, centers, n, radius, counts);
     return hipGetLastError();
 }
-size_t pso_lds(int W, int Kmax, int Nmax) { return pso_lds_bytes(W, Kmax, Nmax); }
 
-size_t pso_split_state_bytes(int Nmax) { return pso_state_bytes(Nmax); }
-size_t pso_eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
-hipError_t pso_split_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax,
-                          int *activeList, int *activeCount, unsigned char *evalBlocks, int Kmax, hipStream_t stream)
+size_t pso_state_bytes_host(int Nmax) { return pso_state_bytes(Nmax); }
+hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
+                    int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream)
 {
     int grid = n < 65536 ? n : 65536;
     hipLaunchKernelGGL(k_pso_init, dim3(grid), dim3(64), 0, stream, sc, recs, n, states, Nmax, activeList, activeCount, evalBlocks,
-                       pso_eval_block_bytes(Kmax));
+                       eval_block_bytes(Kmax), (WinPix *)win);
     return hipGetLastError();
 }
 template <int NS>
 static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
-                                   hipStream_t stream)
+                                   const void *win, hipStream_t stream)
 {
-    const size_t lds = sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * (NS * Kmax + 8);
-    static size_t attrFor = 0;
-    if (lds > 64 * 1024 && lds > attrFor) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_pso_eval2<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attrFor = lds;
-    }
+    static LdsAttr attr;
+    const size_t lds = eval_lds_bytes(NS, Kmax);
+    hipError_t e = attr.ensure((const void *)k_pso_eval2<NS>, lds);
+    if (e != hipSuccess) return e;
     const long total = (long)n * Nmax;
     const int grid = (int)(total < 262144 ? total : 262144);
-    hipLaunchKernelGGL((k_pso_eval2<NS>), dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks, pso_eval_block_bytes(Kmax));
+    hipLaunchKernelGGL((k_pso_eval2<NS>), dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks, eval_block_bytes(Kmax),
+                       (const WinPix *)win);
     return hipGetLastError();
 }
-hipError_t pso_split_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, pais_patch_result *recs,
-                          unsigned long long *stat, int fuseStep, const unsigned char *evalBlocks, hipStream_t stream)
+// the evaluation launch of large batches: `states`, `evalBlocks`, `win` point at the slice's first candidate
+hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
+                    hipStream_t stream)
 {
-    if (!fuseStep && evalBlocks) // the default split pipeline: lean evaluation kernel, pixels per lane by camera count
-        return Kmax <= 5 ? pso_eval2_launch<2>(sc, states, n, Nmax, Kmax, evalBlocks, stream)
-                         : pso_eval2_launch<1>(sc, states, n, Nmax, Kmax, evalBlocks, stream);
-    size_t lds = fitness_lds_bytes(Kmax) + sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
-    static bool attrSet = false;
-    if (lds > 64 * 1024 && !attrSet) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_pso_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attrSet = true;
-    }
-    long total = (long)n * Nmax;
-    int grid = (int)(total < 262144 ? total : 262144);
-    hipLaunchKernelGGL(k_pso_eval, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, fuseStep, evalBlocks,
-                       pso_eval_block_bytes(Kmax));
-    return hipGetLastError();
+    return two_pixels(Kmax) ? pso_eval2_launch<2>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream)
+                            : pso_eval2_launch<1>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream);
 }
 template <int P, int NS>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,
                                   int listLo, int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L,
-                                  int finishOnly, const unsigned char *evalBlocks, hipStream_t stream)
+                                  int finishOnly, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
-    const size_t lds = sizeof(EvalPatch) + sizeof(EvalCam) * Kmax + sizeof(double) * 9 * Kmax + sizeof(double) * 64 * (NS * Kmax + 8);
-    static size_t attrFor = 0;
-    if (lds > 64 * 1024 && lds > attrFor) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_pso_iter<P, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attrFor = lds;
-    }
+    static LdsAttr attr;
+    const size_t lds = eval_lds_bytes(NS, Kmax);
+    hipError_t e = attr.ensure((const void *)k_pso_iter<P, NS>, lds);
+    if (e != hipSuccess) return e;
     const long total = (long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P);
     const int grid = (int)(total < 262144 ? total : 262144);
     hipLaunchKernelGGL((k_pso_iter<P, NS>), dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax,
-                       Kmax, recs, stat, L, finishOnly, evalBlocks, pso_eval_block_bytes(Kmax));
+                       Kmax, recs, stat, L, finishOnly, evalBlocks, eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                    int nparts, const unsigned char *evalBlocks, hipStream_t stream)
+                    int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     if (listHi <= listLo) return hipSuccess;
-    const bool two = Kmax <= 5; // two window pixels per lane only while the LDS scratch leaves >= 3 waves per SIMD
+    const bool two = two_pixels(Kmax);
 #define PAIS_DISPATCH(P)                                                                                                            \
-    return two ? pso_iter_launch<P, 2>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, stream) \
-               : pso_iter_launch<P, 1>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, stream)
+    return two ? pso_iter_launch<P, 2>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, win, stream) \
+               : pso_iter_launch<P, 1>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, win, stream)
     if (nparts == 4) { PAIS_DISPATCH(4); }
     if (nparts == 2) { PAIS_DISPATCH(2); }
     PAIS_DISPATCH(1);
 #undef PAIS_DISPATCH
 }
-size_t pso_queue_ints(int n, int Nmax, int maxIt) { return sizeof(PsoQueue) / sizeof(int) + (size_t)n * Nmax * (size_t)(maxIt + 2); }
-hipError_t pso_persist(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, int maxIt, pais_patch_result *recs,
-                       unsigned long long *stat, int *qmem, int numCUs, hipStream_t stream)
-{
-    const size_t ints = pso_queue_ints(n, Nmax, maxIt);
-    const int cap = (int)(ints - sizeof(PsoQueue) / sizeof(int));
-    hipError_t e = hipMemsetAsync(qmem, 0xFF, ints * sizeof(int), stream); // slots = -1
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(qmem, 0, sizeof(PsoQueue), stream);
-    if (e != hipSuccess) return e;
-    const int total = n * Nmax;
-    int g0 = (total + 255) / 256;
-    hipLaunchKernelGGL(k_pso_enqueue_initial, dim3(g0 < 1024 ? g0 : 1024), dim3(256), 0, stream, states, n, Nmax, qmem, cap);
-    size_t lds = fitness_lds_bytes(Kmax) + sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
-    static int blocksPerCU = 0;
-    static size_t ldsFor = 0;
-    if (blocksPerCU == 0 || ldsFor != lds) {
-        if (lds > 64 * 1024) {
-            e = hipFuncSetAttribute((const void *)k_pso_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_pso_persist, 64, lds);
-        if (e != hipSuccess || nb <= 0) nb = 8;
-        blocksPerCU = nb;
-        ldsFor = lds;
-    }
-    long resident = (long)numCUs * blocksPerCU;
-    int grid = (int)(total < resident ? total : resident);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_pso_persist, dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, recs, stat, qmem);
-    return hipGetLastError();
-}
-hipError_t pso_split_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
-                          unsigned long long *stat, hipStream_t stream)
+hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
+                    unsigned long long *stat, hipStream_t stream)
 {
     int grid = n < 65536 ? n : 65536;
     size_t lds = sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
@@ -2259,11 +1418,10 @@ hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpS
                  unsigned long long *stat, int Kmax, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
+    static LdsAttr attr;
     size_t lds = after_lds_bytes(Kmax);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_after, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    hipError_t e = attr.ensure((const void *)k_after, lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_after, dim3(grid), dim3(128), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax);
     return hipGetLastError();
 }

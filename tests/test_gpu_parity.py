@@ -522,9 +522,9 @@ def test_pyramid_construction_on_gpu_is_the_host_restatement():
 
 
 @pytest.mark.gpu
-def test_alternative_pso_pipelines_are_bit_identical(pawn_small, monkeypatch):
-    """the measured alternatives (PAIS_PSO_MODE = split / laststep / persist / fused) and every
-    waves-per-evaluation setting of the default pipeline produce the same records bit for bit."""
+def test_pipeline_shapes_are_bit_identical(pawn_small, monkeypatch):
+    """the two per-iteration pipelines (k_pso_iter for small batches, k_pso_eval2 + k_pso_step for
+    large ones) and every waves-per-evaluation setting of k_pso_iter produce the same records bit for bit."""
     from pais_mvs_amd.config import readme_config
     from pais_mvs_amd.context import Context
     cfg = readme_config()
@@ -542,10 +542,9 @@ def test_alternative_pso_pipelines_are_bit_identical(pawn_small, monkeypatch):
 
     ref = run()
     assert any(not r[0] for r in ref)
-    for mode in ("split", "laststep", "persist", "fused"):
-        monkeypatch.setenv("PAIS_PSO_MODE", mode)
-        assert run() == ref, mode
-    monkeypatch.delenv("PAIS_PSO_MODE")
+    monkeypatch.setenv("PAIS_SPLIT_ABOVE", "1")       # every batch takes the large-batch pipeline
+    assert run() == ref, "split"
+    monkeypatch.delenv("PAIS_SPLIT_ABOVE")
     for parts in ("1", "2", "4"):
         monkeypatch.setenv("PAIS_EVAL_PARTS", parts)
         assert run() == ref, parts
