@@ -9,9 +9,10 @@ patches taken through refine() that the reference's sequential order evaluates
 separately and never counted.
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU;
-a round's candidates are sharded across ranks and the records all-gathered over RCCL.
-Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU -- started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) or, when WORLD_SIZE is not set, by this file itself; it refuses to run when the number of ranks differs
+from N or a rank has no GPU of its own.  Under the C ABI (include/pais_mvs.h) every round's candidates are sharded
+over the ranks and the records exchanged with one ncclAllGather (RCCL) per round.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -149,62 +150,75 @@ def cpu_baseline(cfg, scene, budget_s: float, n_seed_units: int, n_expand_units:
                                          "structure; the stronger CPU arrangement)" % m_par}}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this file, one per GPU, and relay rank 0's line."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if "PAIS_FORCE_DEVICE" not in os.environ and ndev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; refusing to report a smaller job as n_gpus=%d"
+                         % (args.gpus, ndev, args.gpus))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PAIS_NO_BUILD="1")
+        # rank 0 inherits stdout (its single JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+        return
     # stdout carries exactly ONE line, the JSON of rank 0: libraries that write to the C-level stdout (RCCL prints a
     # version banner there) are sent to stderr for the whole run, the JSON goes out through the saved descriptor
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the PAIS HIP path has no CPU fallback")
-    # test hooks (one-GPU boxes): PAIS_FORCE_DEVICE puts every rank on that device, PAIS_DIST_BACKEND=gloo exchanges the
-    # records through host memory -- RCCL refuses two ranks on one GPU.  The driver never sets them.
-    if "PAIS_FORCE_DEVICE" in os.environ:
-        local = int(os.environ["PAIS_FORCE_DEVICE"])
-    torch.cuda.set_device(local)
-    dist = None
-    force_dist = os.environ.get("PAIS_FORCE_DIST") == "1"   # test hook: the multi-rank code path with one rank
-    if force_dist and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PAIS_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-
     from pais_mvs_amd import _lib
     from pais_mvs_amd.mvs import MVS
     from pais_mvs_amd import distributed as D
+    # test hooks (one-GPU boxes): PAIS_FORCE_DEVICE puts every rank on that device and PAIS_DIST_TRANSPORT=host exchanges
+    # the records through host memory -- RCCL refuses two ranks on one GPU; PAIS_FORCE_DIST=1 runs the multi-rank code
+    # path (RCCL communicator, sharding) with a world of one rank.  The driver never sets them.
+    force_dist = os.environ.get("PAIS_FORCE_DIST") == "1"
+    job = D.job_from_env(force_group=force_dist)
+    rank, world, local = job.rank, job.world, job.local_rank
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: refusing to report the wrong n_gpus" % (args.gpus, world))
+    if "PAIS_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["PAIS_FORCE_DEVICE"])
+    elif local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local, torch.cuda.device_count()))
+    torch.cuda.set_device(local)
 
     cfg, scene, wname = build_scene(args)
     m = MVS(cfg, scene.cameras, device=local, seed=42)
-    ex = D.torch_gpu_exchange(m, rank, world) if (world > 1 or force_dist) else None
+    if world > 1 or force_dist:
+        D.attach(m, job, transport=os.environ.get("PAIS_DIST_TRANSPORT", "rccl"))
     B = args.parents_per_round
 
     def step():
         m.reset()
         for X, vis in scene.seeds:
             m.add_seed(X, vis)
-        if ex is None:
-            m.refineSeedPatches()
-            m.expansionPatches(B, args.max_rounds)
-        else:
-            D.reconstruct(m, B, ex, args.max_rounds)
+        m.refineSeedPatches()       # sharded over the ranks under the C ABI when a communicator is attached
+        m.expansionPatches(B, args.max_rounds)
         return m.stats()
 
     def fence():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        job.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -225,10 +239,7 @@ def main():
         last = st
     fence()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = job.max_over_ranks(dt)
     # Roofline leg (not part of `value`): ONE more step of the same workload with every cost-evaluation launch
     # bracketed by HIP events on the stream it is launched on (two overlapping sub-streams by default).
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 1)
@@ -269,7 +280,11 @@ def main():
                        "speculative_extra_refines_per_step": spec // max(args.steps, 1),
                        "rounds_per_step": int(last.rounds) if last else 0,
                        "pso_evals_per_patch": evals_eff / max(units, 1),
-                       "parallelism": "candidates sharded over %d GPU(s), 1 all-gather per round" % world},
+                       "batches_sharded_per_step": int(last.batches_sharded) if last else 0,
+                       "batches_replicated_per_step": int(last.batches_replicated) if last else 0,
+                       "exchange_ms_per_step": float(last.exchange_ms) if last else 0.0,
+                       "parallelism": "1 process per GPU, candidates of a round sharded over %d GPU(s), one ncclAllGather of the "
+                                      "records per sharded round (thin rounds replicated)" % world},
             "roofline": {"bound": "hbm", "kernel": "cost evaluation (k_pso_eval in large batches, k_pso_iter in small ones)", "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pso_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": k_launches, "avg_launch_ms": k_ms / k_launches,
@@ -288,9 +303,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, scene, args.cpu_seconds, int(last.seeds_refined), int(last.candidates_effective))
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.destroy_process_group()
     m.close()
+    job.close()
 
 
 if __name__ == "__main__":

@@ -45,6 +45,9 @@ typedef struct pais_mvs_stats {
     int64_t parents_popped;
     int64_t pso_evals_effective;  /* getFitness calls of the effective refines                  */
     double  host_enumerate_ms, host_commit_ms, gpu_refine_ms;
+    int64_t batches_sharded;      /* batches whose candidates were split across the ranks (one all-gather each) */
+    int64_t batches_replicated;   /* multi-rank batches too small to split: every rank refined all of them      */
+    double  exchange_ms;          /* host time spent in the all-gathers (incl. waiting for the slowest rank)    */
 } pais_mvs_stats;
 
 /* Creates the driver and its own pais_ctx on `device` (MVS::getInstance(config),
@@ -82,7 +85,41 @@ int  pais_mvs_expansion_patches(pais_mvs *m, int parents_per_round, int max_roun
 #define PAIS_DEFAULT_THIN_FRONT 64
 int  pais_mvs_set_thin_front(pais_mvs *m, int thin_front);
 
-/* ---- stepwise (multi-GPU) --------------------------------------------- */
+/* ---- multi-GPU: one process per GPU, replicated driver, sharded refinement ----
+ * Every rank creates the same driver on its own GPU (same cameras, config, seeds, pso_seed) and joins a
+ * communicator.  From then on pais_mvs_refine_seed_patches / pais_mvs_expansion_patches split every batch of
+ * candidates into `world` contiguous, count-balanced shards; a rank refines its shard (pais_refine_batch_device,
+ * records stay in HBM) and the fixed-size pais_patch_result records are exchanged with ONE all-gather per batch --
+ * ncclAllGather (RCCL over xGMI) on the context's stream -- after which every rank replays the identical
+ * host bookkeeping.  Batches with fewer than PAIS_REPLICATE_BELOW_PER_RANK candidates per rank are latency bound
+ * on one GPU already: every rank refines all of them itself (the refinement is deterministic, so the replicas agree
+ * bit for bit) and no collective is issued.  The cloud is identical for every world size.
+ * This is what shards MVS::expansionPatches (mvs.cpp:233-275) and MVS::refineSeedPatches (:196-231). */
+#define PAIS_UNIQUE_ID_BYTES 128          /* == NCCL_UNIQUE_ID_BYTES */
+#define PAIS_REPLICATE_BELOW_PER_RANK 64
+typedef struct pais_unique_id { char bytes[PAIS_UNIQUE_ID_BYTES]; } pais_unique_id;
+/* ncclGetUniqueId: call on ONE rank, hand the 128 bytes to the others (MPI_Bcast, a file, a TCP store ...) */
+int  pais_comm_get_unique_id(pais_unique_id *out);
+/* ncclCommInitRank on the driver's GPU (collective over all ranks of the job). */
+int  pais_mvs_comm_init_rccl(pais_mvs *m, int rank, int world, const pais_unique_id *id);
+/* pais_mvs_create + pais_mvs_comm_init_rccl in one call (device = this rank's GPU). */
+int  pais_mvs_create_ranked(const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device,
+                            uint64_t pso_seed, int rank, int world, const pais_unique_id *id, pais_mvs **out);
+/* Any other transport (MPI, a test's host-memory all-gather for several ranks that share ONE GPU, which RCCL
+ * refuses): send = this rank's bytes_per_rank bytes, recv = world * bytes_per_rank bytes in rank order, both HOST
+ * pointers; returns 0 on success.  The driver stages the records through pinned host memory around the call. */
+typedef int (*pais_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int  pais_mvs_comm_init_callback(pais_mvs *m, int rank, int world, pais_allgather_fn fn, void *user);
+/* Candidates per rank below which a multi-rank batch is replicated instead of sharded (default
+ * PAIS_REPLICATE_BELOW_PER_RANK; 0 = always shard).  Must be the same on every rank. */
+int  pais_mvs_set_replicate_below(pais_mvs *m, int per_rank);
+/* A driver created with device < 0 owns no GPU and never computes a record.  This callback lets the owner of the
+ * records (a process that has the GPU, a test's checker) feed the monolithic entry points above -- the stepwise
+ * entry points below folded into a callback; n candidates in, n records out, host pointers. */
+typedef int (*pais_record_source_fn)(void *user, int n, const pais_candidate *cands, pais_patch_result *out, int has_seeds);
+int  pais_mvs_set_record_source(pais_mvs *m, pais_record_source_fn fn, void *user);
+
+/* ---- stepwise ---------------------------------------------------------- */
 /* seeds: candidates of all seeds with camNum >= minCamNum (others are deleted) */
 int  pais_mvs_seed_begin(pais_mvs *m, const pais_candidate **cands, int *n);
 int  pais_mvs_seed_commit(pais_mvs *m, const pais_patch_result *results, int n);

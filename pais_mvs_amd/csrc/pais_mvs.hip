@@ -25,6 +25,9 @@
 #include <unordered_set>
 #include <vector>
 
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
 #include "../../include/pais_mvs.h"
 #include "pais_dev.hpp"
 
@@ -79,9 +82,64 @@ struct WorstFirst { bool operator()(const QItem &a, const QItem &b) const { retu
 
 } // namespace
 
+// ------------------------------------------------------------------- RCCL ---
+// librccl is loaded on first use (a single-GPU user never needs it); in a process that already holds a copy under the
+// same soname (PyTorch bundles one) the loader hands that copy back.
+namespace rccl {
+typedef struct { char internal[PAIS_UNIQUE_ID_BYTES]; } UniqueId; // == ncclUniqueId
+typedef void *Comm;                                              // ncclComm_t
+typedef int (*GetUniqueIdFn)(UniqueId *);
+typedef int (*CommInitRankFn)(Comm *, int, UniqueId, int);
+typedef int (*CommDestroyFn)(Comm);
+typedef int (*AllGatherFn)(const void *, void *, size_t, int /*ncclDataType_t*/, Comm, hipStream_t);
+typedef const char *(*GetErrorStringFn)(int);
+struct Api {
+    void *lib = nullptr;
+    GetUniqueIdFn getUniqueId = nullptr;
+    CommInitRankFn commInitRank = nullptr;
+    CommDestroyFn commDestroy = nullptr;
+    AllGatherFn allGather = nullptr;
+    GetErrorStringFn errorString = nullptr;
+};
+static Api *api(std::string &err)
+{
+    static Api a;
+    if (a.lib) return &a;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return nullptr; }
+    a.getUniqueId = (GetUniqueIdFn)dlsym(h, "ncclGetUniqueId");
+    a.commInitRank = (CommInitRankFn)dlsym(h, "ncclCommInitRank");
+    a.commDestroy = (CommDestroyFn)dlsym(h, "ncclCommDestroy");
+    a.allGather = (AllGatherFn)dlsym(h, "ncclAllGather");
+    a.errorString = (GetErrorStringFn)dlsym(h, "ncclGetErrorString");
+    if (!a.getUniqueId || !a.commInitRank || !a.commDestroy || !a.allGather) { err = "librccl lacks an expected symbol"; return nullptr; }
+    a.lib = h;
+    return &a;
+}
+const int kInt8 = 0; // ncclInt8 / ncclChar
+} // namespace rccl
+
 struct pais_mvs {
     pais_config cfg;
     pais_ctx *ctx = nullptr;
+    int device = -1;
+    // ---- multi-GPU
+    int rank = 0, world = 1;
+    rccl::Comm nccl = nullptr;
+    pais_allgather_fn gatherCb = nullptr;
+    void *gatherUser = nullptr;
+    int replicateBelow = PAIS_REPLICATE_BELOW_PER_RANK;
+    pais_record_source_fn recordSource = nullptr;
+    void *recordUser = nullptr;
+    pais_candidate *d_shardC = nullptr, *h_shardC = nullptr;       // this rank's shard of a batch (device / pinned)
+    pais_patch_result *d_shardR = nullptr, *d_allR = nullptr, *h_allR = nullptr;
+    size_t shardCap = 0, allCap = 0;
+    std::vector<pais_patch_result> sendBuf;
     std::vector<HostCamera> cams;
     std::vector<HostPatch *> patches; // index == id; nullptr once deleted  (map<int,Patch>, mvs.h:86)
     int alive = 0;
@@ -112,6 +170,15 @@ struct pais_mvs {
     ~pais_mvs()
     {
         for (auto *p : patches) delete p;
+        if (device >= 0) {
+            (void)hipSetDevice(device);
+            if (nccl) {
+                std::string e;
+                if (rccl::Api *a = rccl::api(e)) a->commDestroy(nccl);
+            }
+            (void)hipFree(d_shardC); (void)hipFree(d_shardR); (void)hipFree(d_allR);
+            (void)hipHostFree(h_shardC); (void)hipHostFree(h_allR);
+        }
         if (ctx) pais_ctx_destroy(ctx);
     }
 
@@ -437,7 +504,8 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
     // GPU then fail; nothing is ever computed on the host instead.
     if (device >= 0) {
         int rc = pais_ctx_create(cfg, num_cams, cams, device, pso_seed, &m->ctx);
-        if (rc) { delete m; return rc; }
+        if (rc) { g_mvs_err = pais_last_error(); delete m; return rc; }
+        m->device = device;
     }
     m->cams.resize((size_t)num_cams);
     for (int c = 0; c < num_cams; ++c) {
@@ -593,6 +661,180 @@ extern "C" int pais_mvs_add_seed_measured(pais_mvs *m, const double center[3], i
     return id;
 }
 
+// ------------------------------------------------------- sharded refinement ---
+#define MHIP(call)                                                                  \
+    do {                                                                            \
+        hipError_t e__ = (call);                                                    \
+        if (e__ != hipSuccess) { g_mvs_err = std::string(#call ": ") + hipGetErrorString(e__); return -2; } \
+    } while (0)
+
+// n candidates -> n records on one rank: the GPU context, or the record source of a GPU-less driver
+static int refine_local(pais_mvs *m, int n, const pais_candidate *c, pais_patch_result *out, int has_seeds)
+{
+    if (n <= 0) return 0;
+    if (m->ctx) {
+        int rc = pais_refine_batch(m->ctx, n, c, out);
+        if (rc) g_mvs_err = pais_last_error();
+        return rc;
+    }
+    if (m->recordSource) {
+        if (m->recordSource(m->recordUser, n, c, out, has_seeds)) return mfail("record source failed");
+        return 0;
+    }
+    return mfail("this driver has neither a GPU context nor a record source");
+}
+
+static int all_gather_host(pais_mvs *m, const void *send, void *recv, size_t bytes)
+{
+    if (!m->gatherCb) return mfail("no host all-gather installed");
+    if (m->gatherCb(m->gatherUser, send, recv, bytes)) return mfail("all-gather callback failed");
+    return 0;
+}
+
+// The batch entry of the drivers: one rank -> pais_refine_batch; several ranks -> shard, refine, all-gather.
+static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_result *out, int has_seeds)
+{
+    if (n <= 0) return 0;
+    const int world = m->world;
+    if (world <= 1 && !m->nccl && !m->gatherCb) return refine_local(m, n, c, out, has_seeds);
+    if ((long)n < (long)m->replicateBelow * world) { // thin batch: replicated, no collective
+        m->st.batches_replicated++;
+        return refine_local(m, n, c, out, has_seeds);
+    }
+    m->st.batches_sharded++;
+    const int per = (n + world - 1) / world;
+    const int lo = std::min(m->rank * per, n), hi = std::min(lo + per, n), cnt = hi - lo;
+    const size_t SZ_R = sizeof(pais_patch_result);
+    if (!m->ctx || !m->nccl) {
+        // records through host memory: GPU-less driver, or a caller-supplied transport
+        m->sendBuf.assign((size_t)per, pais_patch_result());
+        if (cnt > 0) {
+            int rc = refine_local(m, cnt, c + lo, m->sendBuf.data(), has_seeds);
+            if (rc) return rc;
+        }
+        std::vector<pais_patch_result> all((size_t)per * world);
+        const double t0 = now_ms();
+        int rc = all_gather_host(m, m->sendBuf.data(), all.data(), SZ_R * (size_t)per);
+        m->st.exchange_ms += now_ms() - t0;
+        if (rc) return rc;
+        memcpy(out, all.data(), SZ_R * (size_t)n); // shards are contiguous and in rank order
+        return 0;
+    }
+    // RCCL: candidates up, records stay in HBM, one ncclAllGather on the context's stream, gathered records down
+    MHIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)pais_ctx_stream(m->ctx);
+    if ((size_t)per > m->shardCap) {
+        MHIP(hipStreamSynchronize(st));
+        (void)hipFree(m->d_shardC); (void)hipFree(m->d_shardR); (void)hipHostFree(m->h_shardC);
+        m->d_shardC = nullptr; m->d_shardR = nullptr; m->h_shardC = nullptr;
+        const size_t cap = (size_t)per + (size_t)per / 2 + 64;
+        MHIP(hipMalloc((void **)&m->d_shardC, sizeof(pais_candidate) * cap));
+        MHIP(hipMalloc((void **)&m->d_shardR, SZ_R * cap));
+        MHIP(hipHostMalloc((void **)&m->h_shardC, sizeof(pais_candidate) * cap, hipHostMallocDefault));
+        m->shardCap = cap;
+    }
+    if ((size_t)per * world > m->allCap) {
+        MHIP(hipStreamSynchronize(st));
+        (void)hipFree(m->d_allR); (void)hipHostFree(m->h_allR);
+        m->d_allR = nullptr; m->h_allR = nullptr;
+        const size_t cap = (size_t)per * world + (size_t)per * world / 2 + 64;
+        MHIP(hipMalloc((void **)&m->d_allR, SZ_R * cap));
+        MHIP(hipHostMalloc((void **)&m->h_allR, SZ_R * cap, hipHostMallocDefault));
+        m->allCap = cap;
+    }
+    if (cnt > 0) {
+        int Kmax = 1;
+        for (int i = lo; i < hi; ++i) Kmax = std::max(Kmax, c[i].num_cam);
+        memcpy(m->h_shardC, c + lo, sizeof(pais_candidate) * (size_t)cnt);
+        MHIP(hipMemcpyAsync(m->d_shardC, m->h_shardC, sizeof(pais_candidate) * (size_t)cnt, hipMemcpyHostToDevice, st));
+        int rc = pais_refine_batch_device(m->ctx, cnt, m->d_shardC, m->d_shardR, Kmax, has_seeds);
+        if (rc) { g_mvs_err = pais_last_error(); return rc; }
+    }
+    std::string err;
+    rccl::Api *a = rccl::api(err);
+    if (!a) return mfail(err.c_str());
+    const double t0 = now_ms();
+    // the tail of the last rank's shard is padding: never read back
+    int nr = a->allGather(m->d_shardR, m->d_allR, SZ_R * (size_t)per, rccl::kInt8, m->nccl, st);
+    if (nr != 0) { g_mvs_err = std::string("ncclAllGather: ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
+    MHIP(hipMemcpyAsync(m->h_allR, m->d_allR, SZ_R * (size_t)n, hipMemcpyDeviceToHost, st));
+    MHIP(hipStreamSynchronize(st));
+    m->st.exchange_ms += now_ms() - t0;
+    memcpy(out, m->h_allR, SZ_R * (size_t)n);
+    return 0;
+}
+
+extern "C" int pais_comm_get_unique_id(pais_unique_id *out)
+{
+    if (!out) return mfail("pais_comm_get_unique_id: bad argument");
+    std::string err;
+    rccl::Api *a = rccl::api(err);
+    if (!a) return mfail(err.c_str());
+    rccl::UniqueId id;
+    int nr = a->getUniqueId(&id);
+    if (nr != 0) { g_mvs_err = std::string("ncclGetUniqueId: ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
+    memcpy(out->bytes, id.internal, PAIS_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+extern "C" int pais_mvs_comm_init_rccl(pais_mvs *m, int rank, int world, const pais_unique_id *id)
+{
+    if (!m || !id || world < 1 || rank < 0 || rank >= world) return mfail("pais_mvs_comm_init_rccl: bad argument");
+    if (!m->ctx) return mfail("pais_mvs_comm_init_rccl: this driver owns no GPU");
+    if (m->nccl || m->gatherCb) return mfail("pais_mvs_comm_init_rccl: a communicator is already attached");
+    std::string err;
+    rccl::Api *a = rccl::api(err);
+    if (!a) return mfail(err.c_str());
+    MHIP(hipSetDevice(m->device));
+    rccl::UniqueId uid;
+    memcpy(uid.internal, id->bytes, PAIS_UNIQUE_ID_BYTES);
+    rccl::Comm comm = nullptr;
+    int nr = a->commInitRank(&comm, world, uid, rank);
+    if (nr != 0) { g_mvs_err = std::string("ncclCommInitRank: ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
+    m->nccl = comm;
+    m->rank = rank;
+    m->world = world;
+    return 0;
+}
+
+extern "C" int pais_mvs_create_ranked(const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device,
+                                      uint64_t pso_seed, int rank, int world, const pais_unique_id *id, pais_mvs **out)
+{
+    if (device < 0) return mfail("pais_mvs_create_ranked: a rank needs a GPU");
+    int rc = pais_mvs_create(cfg, num_cams, cams, device, pso_seed, out);
+    if (rc) return rc;
+    rc = pais_mvs_comm_init_rccl(*out, rank, world, id);
+    if (rc) { pais_mvs_destroy(*out); *out = nullptr; }
+    return rc;
+}
+
+extern "C" int pais_mvs_comm_init_callback(pais_mvs *m, int rank, int world, pais_allgather_fn fn, void *user)
+{
+    if (!m || !fn || world < 1 || rank < 0 || rank >= world) return mfail("pais_mvs_comm_init_callback: bad argument");
+    if (m->nccl || m->gatherCb) return mfail("pais_mvs_comm_init_callback: a communicator is already attached");
+    m->gatherCb = fn;
+    m->gatherUser = user;
+    m->rank = rank;
+    m->world = world;
+    return 0;
+}
+
+extern "C" int pais_mvs_set_replicate_below(pais_mvs *m, int per_rank)
+{
+    if (!m || per_rank < 0) return mfail("pais_mvs_set_replicate_below: bad argument");
+    m->replicateBelow = per_rank;
+    return 0;
+}
+
+extern "C" int pais_mvs_set_record_source(pais_mvs *m, pais_record_source_fn fn, void *user)
+{
+    if (!m) return mfail("pais_mvs_set_record_source: bad argument");
+    if (m->ctx) return mfail("pais_mvs_set_record_source: this driver owns a GPU context; records come from its kernels only");
+    m->recordSource = fn;
+    m->recordUser = user;
+    return 0;
+}
+
 extern "C" int pais_mvs_seed_begin(pais_mvs *m, const pais_candidate **cands, int *n)
 {
     if (!m || !cands || !n) return mfail("pais_mvs_seed_begin: bad argument");
@@ -643,10 +885,10 @@ extern "C" int pais_mvs_refine_seed_patches(pais_mvs *m)
     int rc = pais_mvs_seed_begin(m, &c, &n);
     if (rc) return rc;
     if (n == 0) return 0;
-    if (!m->ctx) return mfail("pais_mvs_refine_seed_patches: this driver was created without a GPU context");
+    if (!m->ctx && !m->recordSource) return mfail("pais_mvs_refine_seed_patches: this driver was created without a GPU context");
     m->results.resize((size_t)n);
     double t0 = now_ms();
-    rc = pais_refine_batch(m->ctx, n, c, m->results.data());
+    rc = refine_any(m, n, c, m->results.data(), 1);
     m->st.gpu_refine_ms += now_ms() - t0;
     if (rc) return rc;
     return pais_mvs_seed_commit(m, m->results.data(), n);
@@ -966,7 +1208,7 @@ extern "C" int pais_mvs_expansion_end(pais_mvs *m)
 
 extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
 {
-    if (!m || !m->ctx) return mfail("pais_mvs_expansion_patches: no GPU context");
+    if (!m || (!m->ctx && !m->recordSource)) return mfail("pais_mvs_expansion_patches: no GPU context");
     int rc = pais_mvs_expansion_begin(m);
     if (rc) return rc;
     int rounds = 0;
@@ -979,7 +1221,7 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         m->results.resize((size_t)(n > 0 ? n : 1));
         if (n > 0) {
             double t0 = now_ms();
-            rc = pais_refine_batch(m->ctx, n, c, m->results.data());
+            rc = refine_any(m, n, c, m->results.data(), 0);
             m->st.gpu_refine_ms += now_ms() - t0;
             if (rc) return rc;
         }

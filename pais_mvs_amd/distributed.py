@@ -1,155 +1,110 @@
-"""Multi-GPU reconstruction: one process per GPU, replicated scheduler, sharded refinement.
+"""Multi-GPU reconstruction: one process per GPU, replicated driver, sharded refinement.
 
-Every rank holds the full scene in its own HBM and an identical driver (pais_mvs).
-Per round (and once for the seeds) each rank refines a contiguous shard of the
-round's candidate list on its GPU; the fixed-size result records are exchanged with
-ONE all-gather (RCCL over xGMI when the backend is "nccl"); every rank then runs the
-same deterministic host replay, so cell maps / queue stay replicated without further
-traffic.  The accepted cloud is bit-identical for any world size.
+The sharding, the replicate-thin-batches rule and the per-batch all-gather live UNDER the C ABI
+(include/pais_mvs.h: pais_mvs_comm_init_rccl / pais_mvs_comm_init_callback; ncclAllGather of
+pais_patch_result records on the context's stream) so that a C++ host bound as in INTEGRATION.md gets
+multi-GPU with no Python.  This module only sets a job up from a Python launcher:
+
+* `job_from_env()` reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run, bench.py's own
+  spawner) and opens a small gloo group for the control plane: handing out the RCCL unique id, barriers,
+  the max-over-ranks of a timing.  The data path never goes through torch.
+* `attach(m, job)` joins a driver to the job: RCCL when every rank has its own GPU; the callback transport
+  (records through host memory, gloo all_gather) when several ranks share one GPU -- RCCL refuses that --
+  which is how the 2-rank path is exercised on a 1-GPU box and on the CPU.
 """
 from __future__ import annotations
 
-import ctypes as C
-from typing import Callable, Optional
+import os
+from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 
-from . import _lib
-from .mvs import MVS
-
-SZ_C = C.sizeof(_lib.Candidate)
-SZ_R = C.sizeof(_lib.PatchResult)
+from .mvs import MVS, get_unique_id, UNIQUE_ID_BYTES
 
 
 def shard_bounds(n: int, rank: int, world: int):
+    """The contiguous, count-balanced shard of rank `rank` (the rule pais_mvs.hip applies)."""
     per = (n + world - 1) // world if n > 0 else 0
     lo = min(rank * per, n)
     hi = min(lo + per, n)
     return per, lo, hi
 
 
-REPLICATE_BELOW_PER_RANK = 64
+@dataclass
+class Job:
+    rank: int
+    world: int
+    local_rank: int
+    dist: object = None          # torch.distributed (gloo group) when world > 1
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.dist is None:
+            return float(v)
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def broadcast_bytes(self, b: Optional[bytes], n: int) -> bytes:
+        if self.dist is None:
+            return b
+        import torch
+        t = torch.zeros(n, dtype=torch.uint8)
+        if self.rank == 0:
+            t[:] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        self.dist.broadcast(t, src=0)
+        return bytes(t.numpy().tobytes())
+
+    def all_gather_bytes(self, send, nbytes: int) -> bytes:
+        import torch
+        t = torch.frombuffer(bytearray(bytes(send)), dtype=torch.uint8)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return torch.cat(outs).numpy().tobytes()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None
 
 
-def replicate_round(n: int, world: int) -> bool:
-    """Rounds with fewer than 64 candidates per rank are latency bound on one GPU already: sharding them cannot
-    make them faster and the all-gather + synchronisation only adds to the round.  Every rank then refines the whole
-    round itself -- the refinement is deterministic, so the replicas agree bit for bit and no exchange is needed."""
-    return world > 1 and n < REPLICATE_BELOW_PER_RANK * world
+def job_from_env(force_group: bool = False) -> Job:
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    d = None
+    if world > 1 or force_group:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the container's hostname may not resolve
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only
+        d = dist
+    return Job(rank, world, local, d)
 
 
-def _cand_bytes(cands_ptr, n: int) -> np.ndarray:
-    if n == 0:
-        return np.zeros(0, dtype=np.uint8)
-    return np.ctypeslib.as_array(C.cast(cands_ptr, C.POINTER(C.c_uint8)), shape=(n * SZ_C,))
+def attach(m: MVS, job: Job, transport: str = "rccl"):
+    """Join driver `m` to the job.  transport "rccl": ncclCommInitRank under the C ABI (one GPU per rank);
+    "host": the callback transport, records through host memory with a gloo all_gather."""
+    if job.world <= 1 and transport != "rccl":
+        return
+    if transport == "rccl":
+        uid = get_unique_id() if job.rank == 0 else None
+        uid = job.broadcast_bytes(uid, UNIQUE_ID_BYTES)
+        m.comm_init_rccl(job.rank, job.world, uid)
+    elif transport == "host":
+        m.comm_init_callback(job.rank, job.world, job.all_gather_bytes)
+    else:
+        raise ValueError(transport)
 
 
-class Exchange:
-    """refine_shard(cand_bytes[lo:hi], count, has_seeds, max_cam) -> uint8 array of count records;
-    all_gather(padded uint8 array of per*SZ_R) -> uint8 array of world*per*SZ_R."""
-
-    def __init__(self, rank: int, world: int, refine_shard: Callable, all_gather: Callable):
-        self.rank, self.world = rank, world
-        self.refine_shard, self.all_gather = refine_shard, all_gather
-
-    def run(self, cands_ptr, n: int, has_seeds: bool, max_cam: int):
-        cb = _cand_bytes(cands_ptr, n)
-        if replicate_round(n, self.world):
-            # thin round: every rank refines all of it (bit-identical results on every GPU), no collective
-            return np.frombuffer(self.refine_shard(cb, n, has_seeds, max_cam), dtype=np.uint8, count=n * SZ_R).copy()
-        per, lo, hi = shard_bounds(n, self.rank, self.world)
-        mine = self.refine_shard(cb[lo * SZ_C:hi * SZ_C], hi - lo, has_seeds, max_cam)
-        buf = np.zeros(per * SZ_R, dtype=np.uint8)
-        if hi > lo:
-            buf[:(hi - lo) * SZ_R] = np.frombuffer(mine, dtype=np.uint8, count=(hi - lo) * SZ_R)
-        allb = np.ascontiguousarray(self.all_gather(buf))
-        return allb   # first n records (shards are contiguous, in rank order) are the round's results
-
-
-def reconstruct(m: MVS, parents_per_round: int, ex: Exchange, max_rounds: int = 0):
-    """MVS::refineSeedPatches + MVS::expansionPatches with sharded refinement."""
-    ncam = len(m.cameras)
-    cands, n = m.seed_begin()
-    if n:
-        allb = ex.run(cands, n, True, min(ncam, _lib.MAX_VIS))
-        m.seed_commit(C.cast(allb.ctypes.data, C.POINTER(_lib.PatchResult)), n)
-    m.expansion_begin()
-    rounds = 0
-    while True:
-        done, cands, n = m.round_begin(parents_per_round)
-        if done:
-            break
-        if n:
-            allb = ex.run(cands, n, False, min(ncam, _lib.MAX_VIS))
-            m.round_commit(C.cast(allb.ctypes.data, C.POINTER(_lib.PatchResult)), n)
-        else:
-            m.round_commit(None, 0)
-        rounds += 1
-        if max_rounds and rounds >= max_rounds:
-            break
-    m.expansion_end()
-
-
-def torch_gpu_exchange(m: MVS, rank: int, world: int) -> Exchange:
-    """Refinement on this rank's GPU through the C ABI's device entry point; all-gather
-    through torch.distributed (backend "nccl" == RCCL) on device buffers."""
-    import torch
-    import torch.distributed as dist
-
-    L = m.L
-    ctx = m.ctx_handle
-    dev = torch.device("cuda", torch.cuda.current_device())
-    nccl = dist.get_backend() == "nccl"
-    # buffers reused across rounds (grown on demand): pinned host staging for the candidates and the gathered records,
-    # device buffers for this rank's shard and for the gathered result
-    bufs = {"h_c": None, "d_c": None, "d_o": None, "d_all": None, "h_all": None}
-
-    def ensure(name, nbytes, device, pinned=False):
-        t = bufs[name]
-        if t is None or t.numel() < nbytes:
-            cap = int(nbytes * 1.5) + 4096
-            t = torch.empty(cap, dtype=torch.uint8, device=device, pin_memory=pinned)
-            bufs[name] = t
-        return t
-
-    def refine_into(d_o, cb: np.ndarray, count: int, has_seeds: bool, max_cam: int):
-        """candidates (host bytes) -> records in d_o[:count*SZ_R] on the device"""
-        if count == 0:
-            return
-        nb = count * SZ_C
-        h_c = ensure("h_c", nb, "cpu", pinned=True)
-        h_c[:nb].numpy()[:] = cb
-        d_c = ensure("d_c", nb, dev)
-        d_c[:nb].copy_(h_c[:nb], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        _lib.check(L.pais_refine_batch_device(ctx, count, d_c.data_ptr(), d_o.data_ptr(), max_cam, 1 if has_seeds else 0),
-                   "pais_refine_batch_device")
-        _lib.check(L.pais_ctx_synchronize(ctx), "pais_ctx_synchronize")
-
-    def to_host(d_t, nbytes):
-        h = ensure("h_all", nbytes, "cpu", pinned=True)
-        h[:nbytes].copy_(d_t[:nbytes], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        return h[:nbytes].numpy()
-
-    def run(cands_ptr, n, has_seeds, max_cam):
-        cb = _cand_bytes(cands_ptr, n)
-        if replicate_round(n, world):
-            d_o = ensure("d_o", n * SZ_R, dev)
-            refine_into(d_o, cb, n, has_seeds, max_cam)
-            return to_host(d_o, n * SZ_R)
-        per, lo, hi = shard_bounds(n, rank, world)
-        d_o = ensure("d_o", per * SZ_R, dev)            # the tail of the last rank's shard is never read
-        refine_into(d_o, cb[lo * SZ_C:hi * SZ_C], hi - lo, has_seeds, max_cam)
-        if not nccl:                                    # test hook: gloo has no device collectives
-            hb = d_o[:per * SZ_R].cpu()
-            ho = torch.empty(world * per * SZ_R, dtype=torch.uint8)
-            dist.all_gather_into_tensor(ho, hb)
-            return ho.numpy()
-        d_all = ensure("d_all", world * per * SZ_R, dev)
-        dist.all_gather_into_tensor(d_all[:world * per * SZ_R], d_o[:per * SZ_R])   # the one collective of the round
-        return to_host(d_all, world * per * SZ_R)
-
-    ex = Exchange(rank, world, None, None)
-    ex.run = run  # device-resident variant
-    return ex
+def reconstruct(m: MVS, parents_per_round: int, max_rounds: int = 0):
+    """MVS::refineSeedPatches + MVS::expansionPatches; sharded under the C ABI when a communicator is attached."""
+    m.refineSeedPatches()
+    m.expansionPatches(parents_per_round, max_rounds)

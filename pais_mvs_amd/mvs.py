@@ -17,7 +17,21 @@ class MvsStats(C.Structure):
     _fields_ = [("seeds_refined", C.c_int64), ("candidates_refined", C.c_int64), ("candidates_effective", C.c_int64),
                 ("patches_inserted", C.c_int64), ("patches_deleted", C.c_int64), ("rounds", C.c_int64),
                 ("parents_popped", C.c_int64), ("pso_evals_effective", C.c_int64),
-                ("host_enumerate_ms", C.c_double), ("host_commit_ms", C.c_double), ("gpu_refine_ms", C.c_double)]
+                ("host_enumerate_ms", C.c_double), ("host_commit_ms", C.c_double), ("gpu_refine_ms", C.c_double),
+                ("batches_sharded", C.c_int64), ("batches_replicated", C.c_int64), ("exchange_ms", C.c_double)]
+
+
+UNIQUE_ID_BYTES = 128
+
+
+class UniqueId(C.Structure):
+    _fields_ = [("bytes", C.c_char * UNIQUE_ID_BYTES)]
+
+
+# int fn(void *user, const void *send, void *recv, size_t bytes_per_rank)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+# int fn(void *user, int n, const pais_candidate *cands, pais_patch_result *out, int has_seeds)
+RECORD_SOURCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(_lib.Candidate), C.POINTER(_lib.PatchResult), C.c_int)
 
 
 def _bind(L):
@@ -54,7 +68,24 @@ def _bind(L):
     L.pais_mvs_neighbor_radius.argtypes = [vp]
     L.pais_mvs_get_stats.argtypes = [vp, C.POINTER(MvsStats)]
     L.pais_mvs_last_error.restype = C.c_char_p
+    L.pais_comm_get_unique_id.argtypes = [C.POINTER(UniqueId)]
+    L.pais_mvs_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.POINTER(UniqueId)]
+    L.pais_mvs_create_ranked.argtypes = [C.POINTER(_lib.Config), C.c_int, C.POINTER(_lib.CameraDesc), C.c_int, C.c_uint64,
+                                         C.c_int, C.c_int, C.POINTER(UniqueId), C.POINTER(vp)]
+    L.pais_mvs_comm_init_callback.argtypes = [vp, C.c_int, C.c_int, ALLGATHER_FN, vp]
+    L.pais_mvs_set_replicate_below.argtypes = [vp, C.c_int]
+    L.pais_mvs_set_record_source.argtypes = [vp, RECORD_SOURCE_FN, vp]
     L._mvs_bound = True
+
+
+def get_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI: call on ONE rank and hand the 128 bytes to the others."""
+    L = _lib.load()
+    _bind(L)
+    u = UniqueId()
+    if L.pais_comm_get_unique_id(C.byref(u)) != 0:
+        raise RuntimeError("pais_comm_get_unique_id failed: %s" % L.pais_mvs_last_error().decode())
+    return bytes(bytearray(u))
 
 
 class MVS:
@@ -138,6 +169,41 @@ class MVS:
         ms = C.c_double(0)
         self._check(self.L.pais_mvs_neighbor_patch_filtering(self.h, float(neighbor_ratio), C.byref(ms)), "pais_mvs_neighbor_patch_filtering")
         return ms.value
+
+    # ---- multi-GPU (include/pais_mvs.h): one process per GPU, sharded refinement, one all-gather per batch
+    def comm_init_rccl(self, rank: int, world: int, unique_id: bytes):
+        u = UniqueId.from_buffer_copy(unique_id)
+        self._check(self.L.pais_mvs_comm_init_rccl(self.h, rank, world, C.byref(u)), "pais_mvs_comm_init_rccl")
+
+    def comm_init_callback(self, rank: int, world: int, all_gather):
+        """all_gather(send: bytes-like view, bytes_per_rank) -> bytes of world * bytes_per_rank (rank order); host memory."""
+        def cb(_user, send, recv, nbytes):
+            try:
+                out = all_gather((C.c_char * nbytes).from_address(send), nbytes)
+                C.memmove(recv, bytes(out), nbytes * world)
+                return 0
+            except Exception:   # the C side reports the failure
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._gather_cb = ALLGATHER_FN(cb)       # keep the trampoline alive
+        self._check(self.L.pais_mvs_comm_init_callback(self.h, rank, world, self._gather_cb, None), "pais_mvs_comm_init_callback")
+
+    def set_replicate_below(self, per_rank: int):
+        self._check(self.L.pais_mvs_set_replicate_below(self.h, int(per_rank)), "pais_mvs_set_replicate_below")
+
+    def set_record_source(self, fn):
+        """GPU-less drivers (device < 0) only: fn(n, cands_ptr, out_ptr, has_seeds) fills out[0:n]."""
+        def cb(_user, n, cands, out, has_seeds):
+            try:
+                fn(n, cands, out, bool(has_seeds))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._record_cb = RECORD_SOURCE_FN(cb)
+        self._check(self.L.pais_mvs_set_record_source(self.h, self._record_cb, None), "pais_mvs_set_record_source")
 
     def set_thin_front(self, thin_front: int):
         """Rounds with <= thin_front active parents take all remaining camera slots of each parent (0 = never)."""

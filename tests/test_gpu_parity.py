@@ -312,40 +312,76 @@ def test_ring_all_weights_many_cameras(ring_small):
     m.close()
 
 
-def test_distributed_path_single_rank_on_gpu(pawn_small, tmp_path):
-    """The multi-GPU code path (device-resident shard refinement + all_gather_into_tensor over RCCL) with a
-    world of one rank must give the cloud of the direct path."""
-    import subprocess, sys, os, textwrap
-    script = tmp_path / "dist1.py"
-    script.write_text(textwrap.dedent("""
-        import os, sys, hashlib
-        sys.path.insert(0, %r)
-        import torch, torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-        from pais_mvs_amd import synth, distributed as D
-        from pais_mvs_amd.config import readme_config
-        from pais_mvs_amd.mvs import MVS
-        scene = synth.pawn_scene(width=320, height=240, n_seeds=24)
-        cfg = readme_config()
-        clouds = []
-        for mode in ("direct", "dist"):
-            m = MVS(cfg, scene.cameras, device=0, seed=42)
-            for X, vis in scene.seeds: m.add_seed(X, vis)
-            if mode == "direct":
-                m.refineSeedPatches(); m.expansionPatches(16, 8)
-            else:
-                D.reconstruct(m, 16, D.torch_gpu_exchange(m, 0, 1), max_rounds=8)
-            clouds.append(hashlib.sha1(m.cloud().tobytes()).hexdigest() + " %%d" %% m.num_patches())
-            m.close()
-        print("CLOUDS", clouds[0], "|", clouds[1])
-        assert clouds[0] == clouds[1]
-        dist.destroy_process_group()
-    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert "CLOUDS" in r.stdout
+_DIST_SCRIPT = """
+import os, sys, hashlib
+sys.path.insert(0, %r)
+from pais_mvs_amd import synth, distributed as D
+from pais_mvs_amd.config import readme_config
+from pais_mvs_amd.mvs import MVS
+job = D.job_from_env(force_group=True)
+scene = synth.pawn_scene(width=320, height=240, n_seeds=24)
+cfg = readme_config()
+m = MVS(cfg, scene.cameras, device=0, seed=42)
+mode = os.environ["PAIS_TEST_MODE"]
+if mode != "direct":
+    D.attach(m, job, transport=mode)
+    m.set_replicate_below(int(os.environ.get("PAIS_TEST_REPLICATE", "0")))
+for X, vis in scene.seeds: m.add_seed(X, vis)
+D.reconstruct(m, 16, max_rounds=8)
+st = m.stats()
+print("CLOUD", job.rank, hashlib.sha1(m.cloud().tobytes()).hexdigest(), m.num_patches(), st.batches_sharded, st.batches_replicated, flush=True)
+m.close(); job.close()
+"""
+
+
+def _run_dist(tmp_path, mode, world, replicate=0, port=29541):
+    import subprocess, sys, os
+    script = tmp_path / "dist_job.py"
+    script.write_text(_DIST_SCRIPT % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PAIS_TEST_MODE=mode, PAIS_TEST_REPLICATE=str(replicate), PAIS_NO_BUILD="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, o[-2000:] + e[-3000:]
+        outs.append([l.split() for l in o.splitlines() if l.startswith("CLOUD")][0])
+    return outs
+
+
+def test_multi_rank_paths_under_the_c_abi_on_one_gpu(tmp_path):
+    """SURVEY 8e on a one-GPU box: (a) the RCCL transport (ncclCommInitRank + one ncclAllGather per batch under the C ABI)
+    with a world of one rank and every batch forced through the sharded path; (b) two ranks sharing the GPU with the
+    host-memory transport (RCCL refuses two ranks on one device), sharding every batch / replicating thin ones.
+    All must produce the cloud of the plain single-process driver, byte for byte."""
+    direct = _run_dist(tmp_path, "direct", 1, port=29541)[0]
+    assert int(direct[3]) > 24
+    rccl1 = _run_dist(tmp_path, "rccl", 1, replicate=0, port=29542)[0]
+    assert rccl1[2] == direct[2] and int(rccl1[4]) > 0 and int(rccl1[5]) == 0, (direct, rccl1)
+    for rep in (0, 40):
+        two = _run_dist(tmp_path, "host", 2, replicate=rep, port=29543 + rep)
+        for o in two:
+            assert o[2] == direct[2], (rep, direct, o)
+            assert int(o[4]) > 0 and (rep == 0 or int(o[5]) > 0), o
+
+
+def test_bench_refuses_a_rank_count_it_cannot_run():
+    """`bench.py --gpus 2` on a box with one GPU must fail loudly instead of reporting n_gpus 1 (or 2)."""
+    import subprocess, sys, os, torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PAIS_FORCE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "GPU" in (r.stderr + r.stdout)
+    # a launcher that starts the wrong number of ranks is refused too
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env2)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout
 
 
 def test_dome_radius25_many_cameras(dome_small):
