@@ -46,7 +46,7 @@ struct pais_ctx {
     DevScene sc;
     DevCamera *d_cams = nullptr;
     uint8_t *d_img = nullptr;
-    float *d_imgF = nullptr;            // float copy of d_img (element offsets identical)
+    PaisImgT *d_imgF = nullptr;         // tap copy of d_img (element offsets identical; pais_internal.h PAIS_IMG_MODE)
     double *d_edge = nullptr;
     double *d_gauss = nullptr;
     size_t imgBytes = 0, edgeBytes = 0;
@@ -203,10 +203,20 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     HIPCHK(hipMemcpy(ctx->d_img, himg.data(), imgBytes, hipMemcpyHostToDevice));
     ctx->imgBytes = imgBytes;
     {
-        std::vector<float> hf(imgBytes);
-        for (size_t i = 0; i < imgBytes; ++i) hf[i] = (float)himg[i];
-        HIPCHK(hipMalloc(&ctx->d_imgF, imgBytes * sizeof(float)));
-        HIPCHK(hipMemcpy(ctx->d_imgF, hf.data(), imgBytes * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<PaisImgT> hf(imgBytes);
+        for (size_t i = 0; i < imgBytes; ++i) {
+#if PAIS_IMG_MODE == 0
+            hf[i] = (float)himg[i];
+#elif PAIS_IMG_MODE == 3
+            hf[i] = himg[i];
+#else
+            const int a = himg[i], b = (i + 1 < imgBytes) ? himg[i + 1] : 0; // the last column's difference is never tapped
+            hf[i].x = a;
+            hf[i].y = b - a;
+#endif
+        }
+        HIPCHK(hipMalloc(&ctx->d_imgF, imgBytes * sizeof(PaisImgT)));
+        HIPCHK(hipMemcpy(ctx->d_imgF, hf.data(), imgBytes * sizeof(PaisImgT), hipMemcpyHostToDevice));
     }
     if (wantEdge && edgeBytes) {
         HIPCHK(hipMalloc(&ctx->d_edge, edgeBytes));

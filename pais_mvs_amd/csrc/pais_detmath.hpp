@@ -141,18 +141,30 @@ PAIS_HD double det_exp_poly(double x)
     const double k = rint(xs * invln2);
     double r = fma(-k, ln2HI, xs);
     r = fma(-k, ln2LO, r);
+    // Horner step q = q * r + c.  On the GPU the three-operand VOP3 form is forced: left alone the compiler emits
+    // v_mov_b64 + v_fmac_f64 per step (the coefficients sit in VGPRs), i.e. 11 extra instructions per window pixel.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PAIS_HORNER(c)                                                                        \
+    {                                                                                         \
+        const double c_ = (c);                                                                \
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(q), "v"(r), "v"(c_));                  \
+    }
+#else
+#define PAIS_HORNER(c) q = fma(q, r, (c));
+#endif
     double q = 1.6059043836821613e-10;       // 1/13!
-    q = fma(q, r, 2.08767569878681e-09);     // 1/12!
-    q = fma(q, r, 2.505210838544172e-08);    // 1/11!
-    q = fma(q, r, 2.755731922398589e-07);    // 1/10!
-    q = fma(q, r, 2.7557319223985893e-06);   // 1/9!
-    q = fma(q, r, 2.48015873015873e-05);     // 1/8!
-    q = fma(q, r, 1.984126984126984e-04);    // 1/7!
-    q = fma(q, r, 1.388888888888889e-03);    // 1/6!
-    q = fma(q, r, 8.333333333333333e-03);    // 1/5!
-    q = fma(q, r, 4.1666666666666664e-02);   // 1/4!
-    q = fma(q, r, 1.6666666666666666e-01);   // 1/3!
-    q = fma(q, r, 0.5);                      // 1/2!
+    PAIS_HORNER(2.08767569878681e-09)        // 1/12!
+    PAIS_HORNER(2.505210838544172e-08)       // 1/11!
+    PAIS_HORNER(2.755731922398589e-07)       // 1/10!
+    PAIS_HORNER(2.7557319223985893e-06)      // 1/9!
+    PAIS_HORNER(2.48015873015873e-05)        // 1/8!
+    PAIS_HORNER(1.984126984126984e-04)       // 1/7!
+    PAIS_HORNER(1.388888888888889e-03)       // 1/6!
+    PAIS_HORNER(8.333333333333333e-03)       // 1/5!
+    PAIS_HORNER(4.1666666666666664e-02)      // 1/4!
+    PAIS_HORNER(1.6666666666666666e-01)      // 1/3!
+    PAIS_HORNER(0.5)                         // 1/2!
+#undef PAIS_HORNER
     const double s = fma(r * r, q, r);       // exp(r) - 1
     const double y = ldexp(1.0 + s, (int)k);
     // outside (-746, 710): 0 / +inf / NaN as exp gives them

@@ -44,8 +44,11 @@ struct EvalPatch {
 };
 struct WinPix {
     double refCol;      // bilinear sample of the reference level at (x, y)
-    double wStat;       // [dist] G(x, y) * [grad] exp(-1 / (edge * gradientWeighting)); -1: masked pixel
+    double wStat;       // [dist] G(x, y) * [grad] exp(-1 / (edge * gradientWeighting)); -1: masked pixel / padding
 };
+// WinPix entries per candidate: S*S rounded up to whole 64-pixel steps; the padding entries are "masked", so that the
+// evaluation needs no lane-level validity test
+__host__ __device__ inline int win_stride(const DevScene &sc) { return (sc.cfg.patchSize * sc.cfg.patchSize + 63) & ~63; }
 
 // median of three == clamp(v, lo, hi) for lo <= hi, one instruction
 __device__ __forceinline__ int clamp_i32(int v, int lo, int hi)
@@ -55,20 +58,46 @@ __device__ __forceinline__ int clamp_i32(int v, int lo, int hi)
     return r;
 }
 
-// two adjacent pixels of the float image with one 8-byte (4-byte aligned) global load
-struct PixPair { float a, b; };
-__device__ __forceinline__ PixPair load_pair(const float *p)
+// one row of a bilinear tap: the left pixel and the (exact) difference to its right neighbour, with one global load
+#if PAIS_IMG_MODE == 0
+struct RowTap { float a, b; };   // two adjacent pixels (8 bytes, 4-byte aligned)
+#elif PAIS_IMG_MODE == 1
+typedef float2 RowTap;           // {I, dI}
+#elif PAIS_IMG_MODE == 2
+typedef double2 RowTap;          // {I, dI}
+#else
+typedef uint16_t RowTap;         // two adjacent bytes
+#endif
+__device__ __forceinline__ RowTap load_row(const PaisImgT *p)
 {
-    PixPair v;
-    __builtin_memcpy(&v, p, 8);
+    RowTap v;
+    __builtin_memcpy(&v, p, sizeof(RowTap));
+    return v;
+}
+// the same from a wave-uniform level base + a 32-bit BYTE offset inside the level (a level is far below 4 GB): the form
+// global_load ... v_off, s[base:base+1] needs no 64-bit VALU address arithmetic
+__device__ __forceinline__ RowTap load_row_at(const PaisImgT *levelBase, uint32_t byteOff)
+{
+    RowTap v;
+    __builtin_memcpy(&v, (const unsigned char *)levelBase + byteOff, sizeof(RowTap));
     return v;
 }
 
-// bilinear as three lerps a + f (b - a) from two row pairs; the pixel differences are exact in float
-__device__ __forceinline__ double lerp3(PixPair r0, PixPair r1, double bx, double by)
+// bilinear as three lerps a + f (b - a) from two rows; the pixel differences are exact (small integers)
+__device__ __forceinline__ double lerp3(RowTap r0, RowTap r1, double bx, double by)
 {
+#if PAIS_IMG_MODE == 0
     const double i00 = (double)r0.a, d0 = (double)(r0.b - r0.a);
     const double i01 = (double)r1.a, d1 = (double)(r1.b - r1.a);
+#elif PAIS_IMG_MODE == 3
+    const int a0 = (int)(r0 & 0xff), b0 = (int)(r0 >> 8);
+    const int a1 = (int)(r1 & 0xff), b1 = (int)(r1 >> 8);
+    const double i00 = (double)a0, d0 = (double)(b0 - a0);
+    const double i01 = (double)a1, d1 = (double)(b1 - a1);
+#else
+    const double i00 = (double)r0.x, d0 = (double)r0.y;
+    const double i01 = (double)r1.x, d1 = (double)r1.y;
+#endif
     const double t0 = fma(bx, d0, i00);
     const double t1 = fma(bx, d1, i01);
     return fma(by, t1 - t0, t0);
@@ -152,8 +181,14 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
     }
     if (!valid) return; // no pixel of the window is ever read
     const int S = sc.cfg.patchSize, S2 = S * S;
+    if (lane >= (S2 & 63) && (S2 & 63) != 0) { // padding of the last step
+        WinPix pad;
+        pad.refCol = 0.0;
+        pad.wStat = -1.0;
+        win[(S2 & ~63) + lane] = pad;
+    }
     const uint8_t *refImg = sc.imgBlob + rc.imgOff[LOD];
-    const float *refF = sc.imgF + rc.imgOff[LOD];
+    const PaisImgT *refF = sc.imgF + rc.imgOff[LOD];
     const double *refEdge = sc.edgeBlob + rc.edgeOff[LOD];
     const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useGrad = sc.cfg.adaptiveGradientEnable != 0;
     const double gradW = sc.cfg.gradientWeighting;
@@ -165,7 +200,7 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
         const double bx = x - (double)qx, by = y - (double)qy;
         const uint32_t off = (uint32_t)qy * (uint32_t)refW + (uint32_t)qx;
         WinPix wp;
-        wp.refCol = lerp3(load_pair(refF + off), load_pair(refF + off + (uint32_t)refW), bx, by);
+        wp.refCol = lerp3(load_row(refF + off), load_row(refF + off + (uint32_t)refW), bx, by);
         double ws = useDist ? sc.gauss[xi * S + yi] : 1.0;
         if (useGrad) ws *= det_exp_poly(-1.0 / (refEdge[ry * refW + rx] * gradW));
         wp.wStat = (refImg[ry * refW + rx] != 0) ? ws : -1.0; // :986
@@ -186,7 +221,7 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 #pragma unroll
     for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
     double bx[NS][G], by[NS][G], nx[NS][G], ny[NS][G], w[NS][G], rw[NS][G];
-    const float *base[G];
+    const PaisImgT *base[G];
     uint32_t off[NS][G], cwv[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -223,7 +258,11 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
         const int c = c0 + u;
         const int qxmax = cams[c].qxmax, qymax = cams[c].qymax;
         const uint32_t cw = (uint32_t)cams[c].w;
-        base[u] = sc.imgF + cams[c].imgOff; // wave-uniform
+        {   // wave-uniform: keep the base in SGPRs so that the taps are global_load ... v_off, s[base] (no 64-bit VALU address math)
+            const uint64_t io = cams[c].imgOff;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)io), hi = __builtin_amdgcn_readfirstlane((uint32_t)(io >> 32));
+            base[u] = sc.imgF + (((uint64_t)hi << 32) | lo);
+        }
         cwv[u] = cw;
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
@@ -234,19 +273,19 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
             // q != clamp(q) flags the overflow.  frac(ix) == ix - (double)q exactly for an accepted ix.
             const int qx = (int)ix, qy = (int)iy;
             const int px = clamp_i32(qx, 2, qxmax), py = clamp_i32(qy, 2, qymax);
-            badBits[q] |= (uint32_t)((px ^ qx) | (py ^ qy));
+            badBits[q] = badBits[q] | (uint32_t)(px ^ qx) | (uint32_t)(py ^ qy);
             bx[q][u] = __builtin_amdgcn_fract(ix);
             by[q][u] = __builtin_amdgcn_fract(iy);
-            off[q][u] = (uint32_t)py * cw + (uint32_t)px;
+            off[q][u] = (__umul24((uint32_t)py, cw) + (uint32_t)px) * (uint32_t)sizeof(PaisImgT); // byte offset in the level (w < 2^24)
         }
     }
-    PixPair r0[NS][G], r1[NS][G];
+    RowTap r0[NS][G], r1[NS][G];
 #pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            r0[q][u] = load_pair(base[u] + off[q][u]);
-            r1[q][u] = load_pair(base[u] + (off[q][u] + cwv[u]));
+            r0[q][u] = load_row_at(base[u], off[q][u]);
+            r1[q][u] = load_row_at(base[u], off[q][u] + cwv[u] * (uint32_t)sizeof(PaisImgT));
         }
 #pragma unroll
     for (int q = 0; q < NS; ++q)
@@ -262,7 +301,11 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 //   Hbuf : M*9 doubles            (homographies, patch.cpp:290-330)
 //   cbuf : (NS*M + 8)*64 doubles  (per-camera colour of the lane's NS pixels; last 8 rows: the lane's 4 x (fitness,
 //          weight) sub-accumulators)
+#if PAIS_ACC_REG
+#define PAIS_CBUF_ROWS(NS, M) ((NS) * (M))
+#else
 #define PAIS_CBUF_ROWS(NS, M) ((NS) * (M) + 8)
+#endif
 __host__ __device__ inline size_t eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
 __host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax)
 {
@@ -324,9 +367,13 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     const bool hasRef = ep->hasRef != 0;
     const double invK = 1.0 / (double)K;
     double *myc = cbuf + lane;
+#if PAIS_ACC_REG
+    double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0}; // the lane's sub-accumulators
+#else
     double *myacc = cbuf + (size_t)M * NS * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
 #pragma unroll
     for (int a = 0; a < 8; ++a) myacc[a * 64] = 0;
+#endif
 
     // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel index / clamped
     // addresses for lanes that have no pixel, a masked pixel or an overflowing tap); only wave-uniform
@@ -340,17 +387,17 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
         double x[NS], y[NS], sum[NS];
         WinPix wp[NS];
         uint32_t badBits[NS];
-        bool valid[NS];
         int gi[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const int stq = st + q * nparts;
             const int k = 64 * stq + lane;
-            valid[q] = k < S2; // steps past the window: every lane redoes the last pixel, unused
-            const int yi = valid[q] ? yw : (S - 1), xi = valid[q] ? xw : (S - 1);
-            wp[q] = win[valid[q] ? k : (S2 - 1)]; // requested before the taps so that the latency hides behind them
-            x[q] = a0 + (double)xi;
-            y[q] = b0 + (double)yi;
+            // requested before the taps so that the latency hides behind them.  A whole step past the window (uniform:
+            // skipped below) re-reads the last one; the padding lanes of the last step are masked entries whose taps are
+            // clamped for addressing like any overflowing tap
+            wp[q] = win[64 * stq < S2 ? k : (S2 - 1)];
+            x[q] = a0 + (double)xw;
+            y[q] = b0 + (double)yw;
             badBits[q] = 0; // != 0: some tap of this pixel left [2, w-3) x [2, h-3)
             gi[q] = stq & 3; // canonical sub-accumulator of the step
             xw += rA; yw += qA;
@@ -363,28 +410,57 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
         for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
         if (M - c0 == 3) tap_group<3, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
         else if (M - c0 == 1) tap_group<1, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // a single camera
+        // mean and mean absolute deviation of the K colours: one pass over the cameras serves the lane's NS pixels
+        double mean[NS], sad[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            mean[q] = sum[q] * invK;
+            sad[q] = hasRef ? fabs(wp[q].refCol - mean[q]) : 0.0;
+        }
+        for (int c = 0; c < M; ++c) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) sad[q] += fabs(myc[(c * NS + q) * 64] - mean[q]);
+        }
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             if (64 * (st + q * nparts) >= S2) break; // uniform: the window has no such step
-            const bool act = valid[q] && (wp[q].wStat >= 0.0);
+            const bool act = wp[q].wStat >= 0.0;
             if (__any(act && badBits[q] != 0)) return 1; // :1001 -- whole call
-            const double mean = sum[q] * invK;
-            double sad = hasRef ? fabs(wp[q].refCol - mean) : 0.0;
-            for (int c = 0; c < M; ++c) sad += fabs(myc[(c * NS + q) * 64] - mean);
-            sad *= invK;
+            const double sadq = sad[q] * invK;
             double weight = wp[q].wStat;
-            if (useDiff) weight *= det_exp_poly(-(sad * sad) * invDiffW);
+            if (useDiff) weight *= det_exp_poly(-(sadq * sadq) * invDiffW);
+#if PAIS_ACC_REG
+            // the sub-accumulator index is wave-uniform: a scalar branch selects the registers
+#define PAIS_ACC(a)                                          \
+    {                                                        \
+        accW[a] = act ? (accW[a] + weight) : accW[a];        \
+        accF[a] = act ? fma(weight, sadq, accF[a]) : accF[a]; \
+    }
+            const int ga = __builtin_amdgcn_readfirstlane(gi[q]);
+            if (ga == 0) PAIS_ACC(0) else if (ga == 1) PAIS_ACC(1) else if (ga == 2) PAIS_ACC(2) else PAIS_ACC(3)
+#undef PAIS_ACC
+#else
             double *pa = myacc + gi[q] * 128;
             const double w0 = pa[64], f0 = pa[0];
             pa[64] = act ? (w0 + weight) : w0;
-            pa[0] = act ? fma(weight, sad, f0) : f0;
+            pa[0] = act ? fma(weight, sadq, f0) : f0;
+#endif
         }
     }
     // butterflies only for this wave's sub-accumulators (uniform conditions)
+#if PAIS_ACC_REG
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if ((a - part) % nparts != 0 || a < part) continue;
+        f4[a] = wave_sum(accF[a]);
+        w4[a] = wave_sum(accW[a]);
+    }
+#else
     for (int a = part; a < 4; a += nparts) {
         f4[a] = wave_sum(myacc[a * 128]);
         w4[a] = wave_sum(myacc[a * 128 + 64]);
     }
+#endif
     return 0;
 }
 __device__ __forceinline__ double combine_parts(const double *f4, const double *w4)

@@ -26,11 +26,31 @@ struct DevCamera {
     uint64_t edgeOff[PAIS_MAX_LEVELS];
 };
 
+// What the cost taps read: a copy of the byte blob with identical element offsets (imgOff), in a layout that needs no
+// unpacking.  PAIS_IMG_MODE (compile time; the sampled values are identical in every mode):
+//   0  float I(x)                      -- a tap row = two adjacent floats, one 8-byte load, b - a in float
+//   1  float2 {I(x), I(x+1) - I(x)}    -- a tap row = one aligned 8-byte load, no subtraction
+//   2  double2 {I(x), I(x+1) - I(x)}   -- a tap row = one aligned 16-byte load, no conversion either (4x the bytes)
+//   3  the byte blob itself            -- a tap row = one 2-byte load + two byte->float conversions; a quarter of the
+//                                         float copy's cache footprint
+#ifndef PAIS_IMG_MODE
+#define PAIS_IMG_MODE 0
+#endif
+#if PAIS_IMG_MODE == 0
+typedef float PaisImgT;
+#elif PAIS_IMG_MODE == 1
+typedef float2 PaisImgT;
+#elif PAIS_IMG_MODE == 2
+typedef double2 PaisImgT;
+#else
+typedef uint8_t PaisImgT;
+#endif
+
 struct DevScene {
     pais_config cfg;
     const DevCamera *cams;
     const uint8_t *imgBlob;
-    const float *imgF;   // the same pixels as floats, same element offsets (imgOff): what the cost taps read
+    const PaisImgT *imgF;   // tap copy of imgBlob, same element offsets (imgOff)
     const double *edgeBlob;
     const double *gauss; // patchDistWeight, S*S, indexed [x*S + y] (mvs.cpp:104-109)
     double lodScale[PAIS_MAX_LEVELS]; // pow(lodRatio, LOD) (camera.cpp:157, patch.cpp:309)

@@ -30,8 +30,39 @@ using namespace pais;
 #ifndef PAIS_RCP_NEWTON
 #define PAIS_RCP_NEWTON 1
 #endif
+//   PAIS_ACC_REG     1: the lane's four (fitness, weight) sub-accumulators live in registers instead of LDS rows
+#ifndef PAIS_ACC_REG
+#define PAIS_ACC_REG 0
+#endif
+//   PAIS_WG_WAVES    waves (= consecutive evaluation tasks: particles of one candidate) per workgroup of the evaluation
+//                    kernels: the waves of a workgroup run on one CU and share its L1 -- the taps of a candidate's particles
+//                    fall into the same few image windows.  LDS scratch stays private to each wave: no barriers.
+#ifndef PAIS_WG_WAVES
+#define PAIS_WG_WAVES 1
+#endif
+//   PAIS_XCD_SWIZZLE 1: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); remap so that consecutive tasks share an XCD's L2
+#ifndef PAIS_XCD_SWIZZLE
+#define PAIS_XCD_SWIZZLE 0
+#endif
+#define PAIS_EVAL_BOUNDS(NS) __launch_bounds__(64 * PAIS_WG_WAVES, (NS) == 1 ? 4 : 3)
+//   PAIS_TWO_PIXELS_MAXK  largest camera count of a batch that still runs two window pixels per lane (NS = 2)
+#ifndef PAIS_TWO_PIXELS_MAXK
+#define PAIS_TWO_PIXELS_MAXK 6
+#endif
 
 // --------------------------------------------------------------- helpers ---
+// first task / task stride of this wave in the evaluation kernels (grid-stride over tasks; PAIS_WG_WAVES tasks per workgroup)
+__device__ __forceinline__ int eval_first_task()
+{
+    int b = (int)blockIdx.x;
+#if PAIS_XCD_SWIZZLE
+    const int per = (int)gridDim.x >> 3; // the launchers make the grid a multiple of 8
+    b = (b & 7) * per + (b >> 3);
+#endif
+    return b * PAIS_WG_WAVES + (int)(threadIdx.x >> 6);
+}
+__device__ __forceinline__ int eval_task_stride() { return (int)gridDim.x * PAIS_WG_WAVES; }
+
 __device__ __forceinline__ void wave_sync()
 {
     // LDS/global traffic of one wave is processed in issue order; a
@@ -61,36 +92,37 @@ __global__ __launch_bounds__(64) void k_state_blocks(DevScene sc, const pais_pat
                                                      size_t evalBlockBytes, WinPix *win)
 {
     const int lane = threadIdx.x;
-    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    const int WS = win_stride(sc);
     for (int s = blockIdx.x; s < nStates; s += gridDim.x) {
         const pais_patch_state *st = &states[s];
         unsigned char *blk = evalBlocks + evalBlockBytes * (size_t)s;
-        build_eval_block(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), win + (size_t)s * S2, st->ray, st->ref_cam, st->lod,
+        build_eval_block(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), win + (size_t)s * WS, st->ray, st->ref_cam, st->lod,
                          st->num_cam, st->cam_idx, lane);
     }
 }
 template <int NS>
-__global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_fitness(DevScene sc, const int32_t *stateIndex, const double *particles, double *out,
+__global__ PAIS_EVAL_BOUNDS(NS) void k_fitness(DevScene sc, const int32_t *stateIndex, const double *particles, double *out,
                                                                   int nEvals, int Kmax, const unsigned char *evalBlocks, size_t evalBlockBytes,
                                                                   const WinPix *win)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
     double *cbuf = Hbuf + Kmax * 9;
-    const int lane = threadIdx.x;
-    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    const int lane = threadIdx.x & 63;
+    const int WS = win_stride(sc);
     const int nw = (int)(eval_block_bytes(Kmax) / 8);
-    for (int e = blockIdx.x; e < nEvals; e += gridDim.x) {
+    for (int e = eval_first_task(); e < nEvals; e += eval_task_stride()) {
         const int s = stateIndex[e];
         const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)s);
         const uint64_t v0 = lane < nw ? src[lane] : 0, v1 = lane + 64 < nw ? src[lane + 64] : 0;
-        __syncthreads();
+        wave_sync();
         stage_eval_block(smem, src, nw, lane, v0, v1);
-        __syncthreads();
+        wave_sync();
         double f4[4], w4[4];
-        const int bad = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)s * S2, particles[3 * e], particles[3 * e + 1],
+        const int bad = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)s * WS, particles[3 * e], particles[3 * e + 1],
                                                particles[3 * e + 2], lane, 0, 1, f4, w4);
         if (lane == 0) out[e] = bad ? DBL_MAX : combine_parts(f4, w4);
     }
@@ -583,7 +615,7 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 {
     const int lane = threadIdx.x;
     const size_t SB = pso_state_bytes(Nmax);
-    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    const int WS = win_stride(sc);
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
@@ -641,7 +673,7 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
         for (int k = lane; k < P->num_cam; k += 64) hd->camIdx[k] = P->cam_idx[k];
         {
             unsigned char *blk = evalBlocks + evalBlockBytes * (size_t)c;
-            build_eval_block(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), win + (size_t)c * S2, P->ray, P->ref_cam, P->lod,
+            build_eval_block(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), win + (size_t)c * WS, P->ray, P->ref_cam, P->lod,
                              P->num_cam, P->cam_idx, lane);
         }
         // initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
@@ -668,20 +700,21 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 // The evaluation launch of large batches (split pipeline): one wave per (candidate, particle), nothing but the cost.
 // The candidate's constants come from the block k_pso_init prepared; positions from swarm buffer 0 (k_pso_step).
 template <int NS>
-__global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+__global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                                                     const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
     double *cbuf = Hbuf + Kmax * 9;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const size_t SB = pso_state_bytes(Nmax);
     const int total = n * Nmax;
-    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    const int WS = win_stride(sc);
     const int nwMax = (int)(eval_block_bytes(Kmax) / 8);
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int t = eval_first_task(); t < total; t += eval_task_stride()) {
         const int c = t / Nmax, i = t - c * Nmax; // candidate-major: a CU's waves gather from the same few image windows
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
@@ -693,11 +726,11 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_eval2(DevScene sc, 
         const double p0 = A.pos[iLoad][0], p1 = A.pos[iLoad][1], p2 = A.pos[iLoad][2];
         const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0;
         if (!active || i >= Nrun) continue;
-        __syncthreads();
+        wave_sync();
         stage_eval_block(smem, src, nwMax, lane, v0, v1);
-        __syncthreads();
+        wave_sync();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * S2, p0, p1, p2, lane, 0, 1, f4, w4);
+        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
         if (lane == 0) A.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
     }
 }
@@ -791,19 +824,20 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 // NS = 2 (3 waves per SIMD) for patches seen by few cameras, NS = 1 (4 waves per SIMD) beyond: a wave's LDS scratch
 // grows with NS * K and caps the occupancy (measured: K ~ 4: NS 2 +3 %, K ~ 7: NS 1 +9 %)
 template <int nparts, int NS>
-__global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
+__global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
                                             const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                                             const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
     double *cbuf = Hbuf + Kmax * 9;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const size_t SB = pso_state_bytes(Nmax);
-    const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
+    const int WS = win_stride(sc);
     // nparts (1, 2, 4) consecutive waves share one evaluation: small rounds are bound by the latency of a
     // single evaluation wave, not by throughput.  Every part replays the step (identical results), part 0
     // stores the moved particle, each part stores its sub-accumulators; the consumer -- the step replay of
@@ -811,7 +845,7 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
     const int per = finishOnly ? 1 : Nmax * nparts;
     const int nAct = *activeCount;
     const int total = ((listHi < nAct ? listHi : nAct) - listLo) * per;
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int t = eval_first_task(); t < total; t += eval_task_stride()) {
         const int lp = t / per, ip = t - lp * per;
         const int c = activeList[listLo + lp];
         const int i = ip / nparts, part = ip - i * nparts;
@@ -979,11 +1013,11 @@ __global__ __launch_bounds__(64, NS == 1 ? 4 : 3) void k_pso_iter(DevScene sc, u
             p2 = nP[2];
         }
         if (finishOnly) continue; // unreachable for a well-formed schedule: every run has ended by now
-        __syncthreads();
+        wave_sync();
         stage_eval_block(smem, src, nwMax, lane, v0, v1); // the run's evaluation block, prepared by k_pso_init
-        __syncthreads();
+        wave_sync();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * S2, p0, p1, p2, lane, part, nparts, f4, w4);
+        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, part, nparts, f4, w4);
         if (lane == 0) {
             if (nparts == 1) {
                 Wb.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
@@ -1301,21 +1335,31 @@ static size_t after_lds_bytes(int Kmax)
     return off;
 }
 // two window pixels per lane only while the LDS scratch leaves >= 3 waves per SIMD (M = K - 1 cameras are tapped)
-static inline bool two_pixels(int Kmax) { return Kmax <= 6; }
+// workgroups of an evaluation launch over `tasks` waves (grid-stride beyond 262144 workgroups)
+static inline int eval_grid(long tasks)
+{
+    long g = (tasks + PAIS_WG_WAVES - 1) / PAIS_WG_WAVES;
+    if (g > 262144) g = 262144;
+#if PAIS_XCD_SWIZZLE
+    g = (g + 7) & ~7L;
+#endif
+    return (int)(g < 1 ? 1 : g);
+}
+static inline bool two_pixels(int Kmax) { return Kmax <= PAIS_TWO_PIXELS_MAXK; }
 
 size_t eval_block_bytes_host(int Kmax) { return eval_block_bytes(Kmax); }
-size_t win_bytes_per_candidate(const DevScene &sc) { return sizeof(WinPix) * (size_t)sc.cfg.patchSize * sc.cfg.patchSize; }
+size_t win_bytes_per_candidate(const DevScene &sc) { return sizeof(WinPix) * (size_t)win_stride(sc); }
 
 template <int NS>
 static hipError_t fitness_launch(const DevScene &sc, const int32_t *idx, const double *particles, double *out, int nEvals, int Kmax,
                                  const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax);
+    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
     hipError_t e = attr.ensure((const void *)k_fitness<NS>, lds);
     if (e != hipSuccess) return e;
-    const int grid = nEvals < 262144 ? nEvals : 262144;
-    hipLaunchKernelGGL((k_fitness<NS>), dim3(grid), dim3(64), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
+    const int grid = eval_grid(nEvals);
+    hipLaunchKernelGGL((k_fitness<NS>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
                        eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }
@@ -1360,12 +1404,11 @@ static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, in
                                    const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax);
+    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
     hipError_t e = attr.ensure((const void *)k_pso_eval2<NS>, lds);
     if (e != hipSuccess) return e;
-    const long total = (long)n * Nmax;
-    const int grid = (int)(total < 262144 ? total : 262144);
-    hipLaunchKernelGGL((k_pso_eval2<NS>), dim3(grid), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks, eval_block_bytes(Kmax),
+    const int grid = eval_grid((long)n * Nmax);
+    hipLaunchKernelGGL((k_pso_eval2<NS>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks, eval_block_bytes(Kmax),
                        (const WinPix *)win);
     return hipGetLastError();
 }
@@ -1382,12 +1425,11 @@ static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, con
                                   int finishOnly, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax);
+    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
     hipError_t e = attr.ensure((const void *)k_pso_iter<P, NS>, lds);
     if (e != hipSuccess) return e;
-    const long total = (long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P);
-    const int grid = (int)(total < 262144 ? total : 262144);
-    hipLaunchKernelGGL((k_pso_iter<P, NS>), dim3(grid), dim3(64), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax,
+    const int grid = eval_grid((long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P));
+    hipLaunchKernelGGL((k_pso_iter<P, NS>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax,
                        Kmax, recs, stat, L, finishOnly, evalBlocks, eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }

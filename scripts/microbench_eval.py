@@ -23,7 +23,8 @@ for p in ps:
     states.append(st)
 rng = np.random.default_rng(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
-idx = rng.integers(0, len(states), n).astype(np.int32)
+group = int(sys.argv[2]) if len(sys.argv) > 2 else 15   # consecutive evaluations of one patch state: the particles of a candidate
+idx = np.repeat(rng.integers(0, len(states), (n + group - 1) // group), group)[:n].astype(np.int32)
 parts = np.array([[ps[i].normalS[0] + rng.normal(0, .05), ps[i].normalS[1] + rng.normal(0, .05), ps[i].depth * (1 + rng.normal(0, 1e-3))] for i in idx])
 K = np.mean([ps[i].num_cam for i in idx])
 for rep in range(3):
