@@ -35,7 +35,9 @@ extern "C" {
 #endif
 
 #define PAIS_MAX_LEVELS 16  /* LOD 0..15; MvsConfig::maxLOD <= 15 (TMVS.cpp:42) */
-#define PAIS_MAX_VIS    64  /* visible cameras tracked per patch (camIdx)      */
+#define PAIS_MAX_VIS    64  /* visible cameras tracked per patch (camIdx).  The reference's vector<int> is unbounded;
+                             * a patch whose visibility cone (patch.cpp:723-761) holds more cameras than this is an
+                             * error here (pais_mvs_round_begin fails), never a silent truncation. */
 #define PAIS_MAX_PARTICLES 128 /* 2*particleNum for seeds must fit             */
 
 #define PAIS_TYPE_SEED   0  /* Patch::TYPE_SEED,   mvs/patch.h:17 */

@@ -63,6 +63,9 @@ pais_io_scene *pais_io_load_nvm(const char *path, int nvm2);
 /* MVS_V2 / MVS_V3; for V3 *has_config is set and *cfg filled from the embedded MvsConfig blob. */
 pais_io_scene *pais_io_load_mvs(const char *path, pais_config *cfg, int *has_config);
 void pais_io_free(pais_io_scene *s);
+/* Lists longer than PAIS_MAX_VIS (include/pais_hip.h) are cut when loading; this is how many were.  A non-zero count
+ * means the scene exceeds what the refine path tracks per patch: results would differ from the reference's. */
+int  pais_io_num_truncated(const pais_io_scene *s);
 int  pais_io_num_cameras(const pais_io_scene *s);
 int  pais_io_num_points(const pais_io_scene *s);    /* NVM points */
 int  pais_io_num_patches(const pais_io_scene *s);   /* MVS patches */

@@ -1809,7 +1809,13 @@ int po_runtime_filtering(const po_mvs *m, const po_patch *pth)
     for (int i = 0; i < s->numCams; i++) {
         const po_camera *cam = &s->cams[i];
         if (!po_project(s, i, pth->center, pt, 0)) return 0;
-        if (cam->img[0][(size_t)cv_round(pt[1]) * cam->width[0] + cv_round(pt[0])] == 0) return 0;
+        /* mvs.cpp:860 reads at(cvRound(y), cvRound(x)) after 0 <= pt < dim only: a projection within half a pixel of the
+         * right / bottom edge rounds to x == cols / y == rows, an out-of-bounds read in the reference.  Defined here
+         * (and in the product's driver) as the edge pixel. */
+        int rx = cv_round(pt[0]), ry = cv_round(pt[1]);
+        if (rx > cam->width[0] - 1) rx = cam->width[0] - 1;
+        if (ry > cam->height[0] - 1) ry = cam->height[0] - 1;
+        if (cam->img[0][(size_t)ry * cam->width[0] + rx] == 0) return 0;
     }
     const int camNum = pth->numCam;
     int count = 0;

@@ -89,6 +89,7 @@ struct pais_io_scene {
     std::vector<pais_io_camera> cams;
     std::vector<pais_io_point> points;
     std::vector<pais_io_patch> patches;
+    int truncated = 0; // camera / measurement lists longer than PAIS_MAX_VIS that were cut
 };
 
 extern "C" size_t pais_io_sizeof_mvsconfig_disk(void) { return sizeof(MvsConfigDisk); }
@@ -151,7 +152,7 @@ static bool parse_nvm_camera(char *line, bool nvm2, pais_io_camera &c)
 }
 
 // loadNvmPatch, fileloader.cpp:112-165 (image-centre offset is applied by the caller, who knows the image size)
-static bool parse_nvm_point(char *line, pais_io_point &p)
+static bool parse_nvm_point(char *line, pais_io_point &p, int *truncated = nullptr)
 {
     memset(&p, 0, sizeof(p));
     char *t = strtok(line, DELIM);
@@ -165,6 +166,7 @@ static bool parse_nvm_point(char *line, pais_io_point &p)
     p.rgb[0] = (uint8_t)r; p.rgb[1] = (uint8_t)g; p.rgb[2] = (uint8_t)b;
     if (n < 0) n = 0;
     p.num_meas = n > PAIS_MAX_VIS ? PAIS_MAX_VIS : n;
+    if (n > PAIS_MAX_VIS && truncated) ++*truncated;
     for (int i = 0; i < n; ++i) {
         int ci, fi; double x, y;
         if (!ni(ci) || !ni(fi) || !nd(x) || !nd(y)) return false;
@@ -205,7 +207,7 @@ extern "C" pais_io_scene *pais_io_load_nvm(const char *path, int nvm2)
             for (int i = 0; i < num && !file.eof(); ++i) {
                 file.getline(buf.data(), BUF);
                 pais_io_point p;
-                if (parse_nvm_point(buf.data(), p)) s->points.push_back(p);
+                if (parse_nvm_point(buf.data(), p, &s->truncated)) s->points.push_back(p);
             }
             break;
         }
@@ -266,6 +268,7 @@ extern "C" pais_io_scene *pais_io_load_mvs(const char *path, pais_config *cfg, i
                 int camNum = 0;
                 if (!rd(p.center, 24) || !rd(p.normalS, 16) || !rd(&camNum, sizeof(int)) || camNum < 0 || camNum > 100000) break;
                 p.num_cam = camNum > PAIS_MAX_VIS ? PAIS_MAX_VIS : camNum;
+                if (camNum > PAIS_MAX_VIS) s->truncated++;
                 bool ok = true;
                 for (int k = 0; k < camNum; ++k) {
                     int idx;
@@ -282,6 +285,7 @@ extern "C" pais_io_scene *pais_io_load_mvs(const char *path, pais_config *cfg, i
 }
 
 extern "C" void pais_io_free(pais_io_scene *s) { delete s; }
+extern "C" int pais_io_num_truncated(const pais_io_scene *s) { return s ? s->truncated : 0; }
 extern "C" int pais_io_num_cameras(const pais_io_scene *s) { return s ? (int)s->cams.size() : 0; }
 extern "C" int pais_io_num_points(const pais_io_scene *s) { return s ? (int)s->points.size() : 0; }
 extern "C" int pais_io_num_patches(const pais_io_scene *s) { return s ? (int)s->patches.size() : 0; }

@@ -164,6 +164,7 @@ struct pais_mvs {
     std::vector<pais_patch_result> results;
     std::vector<int> seedIds;
     bool strictTail = true;
+    long truncatedVisible = 0;         // cameras dropped because a visibility cone held more than PAIS_MAX_VIS of them
     pais_mvs_stats st;
     std::string err;
 
@@ -277,7 +278,7 @@ struct pais_mvs {
     }
 
     // ---- Patch(center, parent) constructor, patch.cpp:36-43 incl. expandVisibleCamera :723-761
-    void makeExpandCandidate(const pais_patch_result &parent, const double *center, uint64_t key, pais_candidate *c) const
+    void makeExpandCandidate(const pais_patch_result &parent, const double *center, uint64_t key, pais_candidate *c)
     {
         memset(c, 0, sizeof(*c));
         for (int i = 0; i < 3; ++i) { c->center[i] = center[i]; c->normal[i] = parent.normal[i]; }
@@ -288,7 +289,10 @@ struct pais_mvs {
         int n = 0;
         for (int i = 0; i < (int)cams.size(); ++i) {
             double neg[3] = {-cams[i].optN[0], -cams[i].optN[1], -cams[i].optN[2]};
-            if (dot3h(c->normal, neg) >= cfg.visibleCorrelation && n < PAIS_MAX_VIS) exp[n++] = i;
+            if (dot3h(c->normal, neg) >= cfg.visibleCorrelation) {
+                if (n < PAIS_MAX_VIS) exp[n++] = i;
+                else ++truncatedVisible; // more than PAIS_MAX_VIS cameras in the cone: the reference would keep them all
+            }
         }
         if (n < cfg.minCamNum) {
             for (int i = 0; i < parent.num_cam; ++i) {
@@ -320,7 +324,11 @@ struct pais_mvs {
         for (int i = 0; i < (int)cams.size(); i++) {
             if (!project0(i, p.center, pt)) return false;
             const HostCamera &cam = cams[i];
-            if (cam.img0[(size_t)cv_round_h(pt[1]) * cam.w0 + cv_round_h(pt[0])] == 0) return false;
+            // mvs.cpp:860 reads at(cvRound(y), cvRound(x)) after 0 <= pt < dim only: within half a pixel of the right /
+            // bottom edge that is x == cols / y == rows, out of bounds in the reference.  Defined as the edge pixel, so
+            // that replicated drivers can never disagree on what lies behind the buffer.
+            const int rx = std::min(cv_round_h(pt[0]), cam.w0 - 1), ry = std::min(cv_round_h(pt[1]), cam.h0 - 1);
+            if (cam.img0[(size_t)ry * cam.w0 + rx] == 0) return false;
         }
         int count = 0;
         for (int i = 0; i < p.num_cam; ++i) {
@@ -974,6 +982,11 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
             for (int j = 0; j < 4; ++j) consider(Unit{a.id, sl, j});
         a.slot = sEnd - 1; // round_commit advances past it
     }
+    if (m->truncatedVisible > 0) {
+        m->truncatedVisible = 0;
+        return mfail("a candidate's visibility cone holds more than PAIS_MAX_VIS cameras (patch.cpp:723-761 keeps them all): "
+                     "this rig needs a larger PAIS_MAX_VIS or a larger visibleCorrelation");
+    }
     *cands = m->candRecs.data();
     *n = (int)m->candRecs.size();
     m->st.host_enumerate_ms += now_ms() - t0;
@@ -1040,7 +1053,16 @@ extern "C" int pais_mvs_load_patch(pais_mvs *m, const double center[3], const do
     r.type = PAIS_TYPE_SEED;
     r.fitness = fitness;
     r.correlation = correlation;
+    // setReferenceCameraIndex (patch.cpp:415-445) as the loader constructor runs it: first maximum of normal . (-optN)
     r.ref_cam = -1;
+    {
+        double maxCorr = -DBL_MAX;
+        for (int i = 0; i < num_cam; ++i) {
+            const HostCamera &cam = m->cams[cam_idx[i]];
+            const double corr = r.normal[0] * (-cam.optN[0]) + r.normal[1] * (-cam.optN[1]) + r.normal[2] * (-cam.optN[2]);
+            if (corr > maxCorr) { maxCorr = corr; r.ref_cam = cam_idx[i]; }
+        }
+    }
     r.lod = -1;
     r.key = (uint64_t)m->patches.size();
     const int id = m->storePatch(r);

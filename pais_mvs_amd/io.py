@@ -42,7 +42,7 @@ def _L():
     L.pais_io_load_mvs.argtypes = [C.c_char_p, C.POINTER(_lib.Config), C.POINTER(C.c_int)]
     L.pais_io_free.argtypes = [vp]
     L.pais_io_free.restype = None
-    for n in ("pais_io_num_cameras", "pais_io_num_points", "pais_io_num_patches"):
+    for n in ("pais_io_num_cameras", "pais_io_num_points", "pais_io_num_patches", "pais_io_num_truncated"):
         getattr(L, n).argtypes = [vp]
     L.pais_io_get_camera.argtypes = [vp, C.c_int, C.POINTER(IoCamera)]
     L.pais_io_get_point.argtypes = [vp, C.c_int, C.POINTER(IoPoint)]
@@ -72,6 +72,13 @@ def load_config(path: str, base: MvsConfig) -> MvsConfig:
     return config_from_c(c)
 
 
+def _check_truncation(h, path):
+    n = _L().pais_io_num_truncated(h)
+    if n:
+        raise IOError("%s: %d camera / measurement list(s) exceed PAIS_MAX_VIS = %d entries; this rig is beyond what the "
+                      "refine path tracks per patch" % (path, n, MAX_VIS))
+
+
 def _collect(h, what):
     L = _L()
     if what == "cameras":
@@ -95,6 +102,7 @@ def load_nvm(path: str, nvm2: bool = False) -> Tuple[List[IoCamera], List[IoPoin
     if not h:
         raise IOError("cannot open NVM file %s" % path)
     try:
+        _check_truncation(h, path)
         return _collect(h, "cameras"), _collect(h, "points")
     finally:
         L.pais_io_free(h)
@@ -109,6 +117,7 @@ def load_mvs(path: str):
     if not h:
         raise IOError("cannot open MVS file %s" % path)
     try:
+        _check_truncation(h, path)
         return (config_from_c(c) if has.value else None), _collect(h, "cameras"), _collect(h, "patches")
     finally:
         L.pais_io_free(h)

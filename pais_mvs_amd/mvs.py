@@ -283,8 +283,10 @@ class MVS:
         the rounded projection of the centre (gray pipelines replicate the gray value)."""
         out = []
         for p in self.patches():
+            if p.ref_cam < 0 or p.ref_cam not in p.cams():
+                raise RuntimeError("patch without a reference camera: colours are defined through it (patch.cpp:649-652)")
             cam = self.cameras[p.ref_cam]
-            k = p.cams().index(p.ref_cam) if p.ref_cam in p.cams() else 0
+            k = p.cams().index(p.ref_cam)
             x, y = int(np.rint(p.imgPoint[k][0])), int(np.rint(p.imgPoint[k][1]))
             x = min(max(x, 0), cam.width - 1); y = min(max(y, 0), cam.height - 1)
             if cam.rgb is not None:

@@ -186,15 +186,15 @@ def test_expand_candidates_match_oracle(pawn_small):
     ctx.close()
 
 
-@pytest.mark.parametrize("B,max_rounds", [(1, 40), (16, 20)])
-def test_reconstruction_rounds_match_oracle(pawn_small, B, max_rounds):
+@pytest.mark.parametrize("B,max_rounds,strategy", [(1, 40, 0), (16, 20, 0), (8, 10, 1), (8, 10, 2), (8, 10, 3), (1, 30, 3)])
+def test_reconstruction_rounds_match_oracle(pawn_small, B, max_rounds, strategy):
     """End to end through the driver (include/pais_mvs.h): seeds + expansion rounds on the GPU
     against the oracle's R(B) loop (B = 1: the reference's own order).  The accepted clouds must
     be identical patch by patch (same order, same camera sets, same bits)."""
     from oracle import po
     from pais_mvs_amd.config import readme_config
     from pais_mvs_amd.mvs import MVS
-    cfg = readme_config()
+    cfg = readme_config(expansionStrategy=strategy)   # 0 best-first ... 3 depth-first (mvs.cpp:632-788)
     S = common.oracle_scene(cfg, pawn_small)
     S.set_kernel_arithmetic(True)
     L = po.lib()

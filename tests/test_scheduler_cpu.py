@@ -122,6 +122,88 @@ def test_scheduler_reproduces_oracle_rounds(pawn_small, B, max_rounds, thin):
     m.close()
 
 
+@pytest.mark.parametrize("strategy", [1, 2, 3])
+@pytest.mark.parametrize("B,max_rounds", [(1, 80), (8, 20)])
+def test_expansion_strategies_reproduce_oracle(pawn_small, strategy, B, max_rounds):
+    """MvsConfig::expansionStrategy 1 worst-first (mvs.cpp:695-732), 2 breadth-first (:734-759), 3 depth-first (:761-788,
+    which never examines queue[0]): the driver's containers (heap with lazy deletion / deque) against the oracle's literal
+    vector<int> scans, patch by patch, for the reference's one-parent order and for rounds of 8."""
+    from pais_mvs_amd.config import readme_config
+    cfg = readme_config(particleNum=6, maxIteration=8, expansionStrategy=strategy)
+    want, oracle_calls, _S = _run_oracle(cfg, pawn_small, B, max_rounds)
+    m = _run_product_with_oracle_records(cfg, pawn_small, B, max_rounds)
+    got = [(list(p.center[:]), list(p.normal[:]), p.cams(), p.fitness, p.priority) for p in m.patches()]
+    assert len(got) == len(want) and len(got) > len(pawn_small.seeds) // 2
+    for a, b in zip(got, want):
+        assert a == b
+    st = m.stats()
+    assert st.candidates_effective + st.seeds_refined == oracle_calls
+    m.close()
+
+
+def test_strategies_pop_in_their_own_order(pawn_small):
+    """The four strategies really are different schedules: after the same number of one-parent rounds the clouds differ,
+    and the popped parents follow the strategy (best-first pops ascending priority among the seeds, worst-first descending,
+    breadth-first in insertion order, depth-first from the back without ever taking the first seed while others remain)."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    L = po.lib()
+    clouds = {}
+    for strategy in (0, 1, 2, 3):
+        cfg = readme_config(particleNum=6, maxIteration=8, expansionStrategy=strategy)
+        pats, _, _ = _run_oracle(cfg, pawn_small, 1, 6)
+        clouds[strategy] = pats
+    assert len({str(v) for v in clouds.values()}) == 4
+
+
+def test_queue_tail_quirks_of_the_reference_loop(pawn_small):
+    """mvs.cpp:241-272 pops BEFORE testing `while (!queue.empty())`, so the parent whose pop empties the queue is never
+    expanded; depth-first (mvs.cpp:761-788) scans from the back and stops at queue.begin() without examining it, so the
+    FIRST queued patch is never expanded while any other is live.  Children are suppressed here (every candidate record
+    is `dropped`), which leaves exactly the seeds in the queue."""
+    from pais_mvs_amd import _lib
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    for strategy in (0, 1, 2, 3):
+        cfg = readme_config(particleNum=6, maxIteration=8, expansionStrategy=strategy)
+        S = common.oracle_scene(cfg, pawn_small)
+        m = MVS(cfg, pawn_small.cameras, device=-1, seed=42)
+        for X, vis in pawn_small.seeds:
+            m.add_seed(X, vis)
+        cands, n = m.seed_begin()
+        S.ptr.contents.cfg.neighborRadius = m.neighbor_radius()
+        m.seed_commit(_oracle_records(S, cands, n, True), n)
+        m.expansion_begin()
+        while True:
+            done, cands, n = m.round_begin(1)
+            if done:
+                break
+            recs = (_lib.PatchResult * max(n, 1))()
+            for k in range(n):
+                recs[k].dropped = 1
+            m.round_commit(recs, n)
+        alive, unexpanded = [], []
+        for i in range(m.num_slots()):
+            r = _lib.PatchResult(); e = C.c_int(0)
+            if m.L.pais_mvs_get_patch(m.h, i, C.byref(r), C.byref(e)) == 0:
+                alive.append((i, r.priority))
+                if not e.value:
+                    unexpanded.append(i)
+        assert len(alive) >= 10
+        # parents whose runtimeFiltering failed at pop time were deleted; of the rest exactly one stays unexpanded
+        assert len(unexpanded) == 1, (strategy, unexpanded)
+        ids = [i for i, _ in alive]
+        if strategy == 0:      # best-first: the worst priority is popped last
+            assert unexpanded[0] == max(alive, key=lambda t: (t[1], t[0]))[0]
+        elif strategy == 1:    # worst-first: the best priority is popped last
+            assert unexpanded[0] == min(alive, key=lambda t: (t[1], -t[0]))[0]
+        elif strategy == 2:    # breadth-first: the last queued
+            assert unexpanded[0] == ids[-1]
+        else:                  # depth-first: queue[0], never examined
+            assert unexpanded[0] == ids[0]
+        m.close()
+
+
 def test_one_parent_per_round_is_the_reference_order_for_any_thin_front(pawn_small):
     """B = 1: taking a parent's camera slots one round at a time or all in one round is the same sequential
     loop (mvs.cpp:529-563), so the cloud must not depend on the thin-front threshold."""
