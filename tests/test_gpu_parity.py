@@ -149,6 +149,34 @@ def test_refine_seeds_matches_oracle(pawn_small):
     ctx.close()
 
 
+def test_refine_against_literal_arithmetic_at_north_star_tolerance(pawn_small):
+    """The independent anchor: whole refine() runs of the HIP path -- seeds and first-ring children of the
+    320x240 pawn scene -- against the oracle's LITERAL arithmetic (platform libm, the reference's sequential sums, its
+    own per-particle window), at north_star's gate: identical dropped / camera set / reference camera / LOD for every
+    candidate, centres within 1e-4 relative L2, normals within 1e-4 except where the PSO trajectory branched (counted
+    and bounded; tests/test_oracle_modes.py states the numbers)."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import make_candidate
+    from tests.test_oracle_modes import refine_pairs, mode_statistics, assert_north_star_parity
+    cfg = readme_config()
+    S = common.oracle_scene(cfg, pawn_small)
+    S.set_omp(True)
+    ctx = _ctx(cfg, pawn_small)
+
+    def gpu(seeds_in, child_in):
+        cands = [make_candidate(cen, nrm, cams, key, 0, normalS=ns) for cen, nrm, ns, cams, key in seeds_in]
+        for cen, nrm, cams, key in child_in:
+            child = S.expand_patch(cen, nrm, cams, key)          # the expansion constructor incl. expandVisibleCamera
+            cands.append(make_candidate(child.center[:], child.normal[:], child.cams(), key, 1, normalS=child.normalS[:]))
+        return list(ctx.refine_batch(cands))
+
+    lit, got = refine_pairs(S, pawn_small, cfg, run_b=gpu)
+    st = mode_statistics(lit, got, lambda r: (r.dropped, r.cams(), r.ref_cam, r.lod, list(r.center[:]), list(r.normal[:])))
+    print("\nHIP path vs literal arithmetic:", st)
+    assert_north_star_parity(st)
+    ctx.close()
+
+
 def test_expand_candidates_match_oracle(pawn_small):
     """Children of refined seeds: MVS::expandCell (mvs.cpp:566-577) per candidate."""
     from oracle import po
