@@ -95,8 +95,11 @@ typedef struct pais_camera_desc {
     int32_t level_height[PAIS_MAX_LEVELS];   /* getPyramidImage(l).rows     */
     int64_t level_stride[PAIS_MAX_LEVELS];   /* Mat::step in bytes (0 = width) */
     const uint8_t *level_image[PAIS_MAX_LEVELS]; /* getPyramidImage(l).data, host memory */
-    const double  *level_edge[PAIS_MAX_LEVELS];  /* getPyramidEdge(l).data (dense rows), host memory;
-                                                    may be NULL when adaptiveGradientEnable == 0 */
+    const double  *level_edge[PAIS_MAX_LEVELS];  /* getPyramidEdge(l).data (dense rows), host memory.  May be NULL
+                                                    (all levels of all cameras): with adaptiveGradientEnable set the
+                                                    library then evaluates the edge maps on the fly from the gray
+                                                    levels with the statements of camera.cpp:72-77,87-91 (Sobel ksize 1,
+                                                    magnitude, per-level min-max) -- no 8-byte-per-pixel copy in HBM */
 } pais_camera_desc;
 
 /* The part of a Patch that PAIS::getFitness reads (patch.cpp:922-944). */

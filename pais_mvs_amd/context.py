@@ -30,7 +30,7 @@ def camera_desc(cam: Camera, with_edges: bool, keep: list) -> "_lib.CameraDesc":
         d.level_height[l] = img.shape[0]
         d.level_stride[l] = img.strides[0]
         d.level_image[l] = img.ctypes.data
-        if with_edges:
+        if with_edges and cam.edge_pyramid:     # no host edge pyramid: the library evaluates the maps on the fly
             e = np.ascontiguousarray(cam.edge_pyramid[l], dtype=np.float64)
             keep.append(e)
             d.level_edge[l] = e.ctypes.data

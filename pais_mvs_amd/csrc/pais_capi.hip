@@ -48,6 +48,7 @@ struct pais_ctx {
     uint8_t *d_img = nullptr;
     PaisImgT *d_imgF = nullptr;         // tap copy of d_img (element offsets identical; pais_internal.h PAIS_IMG_MODE)
     double *d_edge = nullptr;
+    bool edgesOnTheFly = false;
     double *d_gauss = nullptr;
     size_t imgBytes = 0, edgeBytes = 0;
     // work buffers (grown on demand, never shrunk)
@@ -169,6 +170,9 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     int rc = apply_config(ctx, cfg);
     if (rc) { pais_ctx_destroy(ctx); return rc; }
     const bool wantEdge = cfg->adaptiveGradientEnable != 0;
+    // edge pyramids: as the caller built them (Camera::pyramidEdge, camera.cpp:72-77,87-91), or -- level_edge == NULL --
+    // evaluated on the fly from the gray levels with the same statements (no double-precision copy of every pyramid)
+    const bool edgesGiven = wantEdge && cams[0].level_edge[0] != nullptr;
 
     // layout the blobs
     std::vector<DevCamera> hc((size_t)num_cams);
@@ -182,54 +186,60 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
             size_t px = (size_t)d.level_width[l] * d.level_height[l];
             imgOff[(size_t)c * PAIS_MAX_LEVELS + l] = imgBytes;
             imgBytes = (imgBytes + px + 16 + 255) & ~(size_t)255; // +16: taps read (px+1, py+1)
-            if (wantEdge) {
-                if (!d.level_edge[l]) { pais_ctx_destroy(ctx); return fail_msg("adaptiveGradientEnable set but level_edge missing"); }
+            if (wantEdge && edgesGiven) {
+                if (!d.level_edge[l]) { pais_ctx_destroy(ctx); return fail_msg("level_edge given for some levels only"); }
                 edgeOff[(size_t)c * PAIS_MAX_LEVELS + l] = edgeBytes;
                 edgeBytes = (edgeBytes + px * sizeof(double) + 255) & ~(size_t)255;
             }
         }
     }
-    std::vector<uint8_t> himg(imgBytes, 0);
+    // pyramid levels straight from the caller's buffers into HBM (rows repacked to stride == width); the padding between
+    // levels is zero
+    HIPCHK(hipMalloc(&ctx->d_img, imgBytes));
+    HIPCHK(hipMemsetAsync(ctx->d_img, 0, imgBytes, ctx->stream));
     for (int c = 0; c < num_cams; ++c) {
         const pais_camera_desc &d = cams[c];
         for (int l = 0; l <= d.max_lod; ++l) {
             const int w = d.level_width[l], h = d.level_height[l];
             const size_t stride = d.level_stride[l] > 0 ? (size_t)d.level_stride[l] : (size_t)w;
-            uint8_t *dst = himg.data() + imgOff[(size_t)c * PAIS_MAX_LEVELS + l];
-            for (int y = 0; y < h; ++y) memcpy(dst + (size_t)y * w, d.level_image[l] + (size_t)y * stride, (size_t)w);
+            HIPCHK(hipMemcpy2DAsync(ctx->d_img + imgOff[(size_t)c * PAIS_MAX_LEVELS + l], (size_t)w, d.level_image[l], stride, (size_t)w,
+                                    (size_t)h, hipMemcpyHostToDevice, ctx->stream));
         }
     }
-    HIPCHK(hipMalloc(&ctx->d_img, imgBytes));
-    HIPCHK(hipMemcpy(ctx->d_img, himg.data(), imgBytes, hipMemcpyHostToDevice));
     ctx->imgBytes = imgBytes;
-    {
-        std::vector<PaisImgT> hf(imgBytes);
-        for (size_t i = 0; i < imgBytes; ++i) {
-#if PAIS_IMG_MODE == 0
-            hf[i] = (float)himg[i];
-#elif PAIS_IMG_MODE == 3
-            hf[i] = himg[i];
-#else
-            const int a = himg[i], b = (i + 1 < imgBytes) ? himg[i + 1] : 0; // the last column's difference is never tapped
-            hf[i].x = a;
-            hf[i].y = b - a;
-#endif
-        }
-        HIPCHK(hipMalloc(&ctx->d_imgF, imgBytes * sizeof(PaisImgT)));
-        HIPCHK(hipMemcpy(ctx->d_imgF, hf.data(), imgBytes * sizeof(PaisImgT), hipMemcpyHostToDevice));
-    }
-    if (wantEdge && edgeBytes) {
+    // the tap copy is expanded on the device (pais_internal.h PAIS_IMG_MODE)
+    HIPCHK(hipMalloc(&ctx->d_imgF, imgBytes * sizeof(PaisImgT)));
+    HIPCHK(pais_launch::expand_image(ctx->d_img, ctx->d_imgF, imgBytes, ctx->stream));
+    if (wantEdge && edgesGiven && edgeBytes) {
         HIPCHK(hipMalloc(&ctx->d_edge, edgeBytes));
         for (int c = 0; c < num_cams; ++c) {
             const pais_camera_desc &d = cams[c];
             for (int l = 0; l <= d.max_lod; ++l) {
                 size_t px = (size_t)d.level_width[l] * d.level_height[l];
-                HIPCHK(hipMemcpy((uint8_t *)ctx->d_edge + edgeOff[(size_t)c * PAIS_MAX_LEVELS + l], d.level_edge[l],
-                                 px * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpyAsync((uint8_t *)ctx->d_edge + edgeOff[(size_t)c * PAIS_MAX_LEVELS + l], d.level_edge[l],
+                                      px * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
             }
         }
         ctx->edgeBytes = edgeBytes;
     }
+    // edge maps on the fly (level_edge == NULL): only the per-level minimum / maximum magnitude is precomputed
+    std::vector<unsigned long long> mm;
+    if (wantEdge && !edgesGiven) {
+        mm.assign((size_t)num_cams * PAIS_MAX_LEVELS * 2, 0ULL);
+        for (size_t i = 0; i < mm.size(); i += 2) mm[i] = ~0ULL;
+        unsigned long long *d_mm = nullptr;
+        HIPCHK(hipMalloc(&d_mm, mm.size() * sizeof(unsigned long long)));
+        HIPCHK(hipMemcpyAsync(d_mm, mm.data(), mm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+        for (int c = 0; c < num_cams; ++c)
+            for (int l = 0; l <= cams[c].max_lod; ++l)
+                HIPCHK(pais_launch::level_edge_minmax(ctx->d_img + imgOff[(size_t)c * PAIS_MAX_LEVELS + l], cams[c].level_width[l],
+                                                      cams[c].level_height[l], d_mm + ((size_t)c * PAIS_MAX_LEVELS + l) * 2, ctx->stream));
+        HIPCHK(hipMemcpyAsync(mm.data(), d_mm, mm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_mm);
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->edgesOnTheFly = wantEdge && !edgesGiven;
     for (int c = 0; c < num_cams; ++c) {
         const pais_camera_desc &d = cams[c];
         DevCamera &h = hc[c];
@@ -248,6 +258,11 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
             h.h[l] = d.level_height[l];
             h.imgOff[l] = (uint64_t)imgOff[(size_t)c * PAIS_MAX_LEVELS + l];
             h.edgeOff[l] = (uint64_t)(edgeOff[(size_t)c * PAIS_MAX_LEVELS + l] / sizeof(double));
+            if (!mm.empty()) {
+                const unsigned long long lo = mm[((size_t)c * PAIS_MAX_LEVELS + l) * 2], hi = mm[((size_t)c * PAIS_MAX_LEVELS + l) * 2 + 1];
+                memcpy(&h.edgeMin[l], &lo, 8);
+                memcpy(&h.edgeMax[l], &hi, 8);
+            }
         }
     }
     HIPCHK(hipMalloc(&ctx->d_cams, sizeof(DevCamera) * (size_t)num_cams));
@@ -310,7 +325,8 @@ extern "C" int pais_ctx_set_config(pais_ctx *ctx, const pais_config *cfg)
 {
     if (!ctx || !cfg) return fail_msg("pais_ctx_set_config: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    if (cfg->adaptiveGradientEnable && !ctx->d_edge) return fail_msg("adaptiveGradientEnable needs edge pyramids at create time");
+    if (cfg->adaptiveGradientEnable && !ctx->d_edge && !ctx->edgesOnTheFly)
+        return fail_msg("adaptiveGradientEnable needs the gradient weighting enabled at create time (edge pyramids or their on-the-fly statistics)");
     double nr = ctx->sc.cfg.neighborRadius;
     int rc = apply_config(ctx, cfg);
     (void)nr;

@@ -123,6 +123,20 @@ __device__ __forceinline__ double rcp_cr(double w)
 #endif
 }
 
+// Camera::pyramidEdge(LOD) at one pixel without a stored map (camera.cpp:72-77, 87-91): Sobel(ksize = 1) = central
+// differences with reflect-101 borders, magnitude sqrt(gx^2 + gy^2) (exact: small integers), normalised with the level's
+// minimum / maximum -- the statements of k_sobel_mag / k_edge_normalise (pais_pyramid.hip), which reproduce the host
+// construction bit for bit.  Saves a double-precision copy of every pyramid (36 GB at 128 x 12.6 MP).
+__device__ __forceinline__ double edge_on_the_fly(const uint8_t *img, int w, int h, int x, int y, double mn, double mx)
+{
+    const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+    const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+    const double gx = (double)img[(size_t)y * w + xr] - (double)img[(size_t)y * w + xl];
+    const double gy = (double)img[(size_t)yd * w + x] - (double)img[(size_t)yu * w + x];
+    const double m = sqrt(gx * gx + gy * gy);
+    return (mx > mn) ? (m - mn) / (mx - mn) : 0.0;
+}
+
 // Builds the evaluation block of one PSO run; called by all 64 lanes of one wave.
 //   ep, cams : K <= PAIS_MAX_VIS = 64 cameras, one per lane
 //   win      : S*S WinPix
@@ -189,7 +203,8 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
     }
     const uint8_t *refImg = sc.imgBlob + rc.imgOff[LOD];
     const PaisImgT *refF = sc.imgF + rc.imgOff[LOD];
-    const double *refEdge = sc.edgeBlob + rc.edgeOff[LOD];
+    const double *refEdge = sc.edgeBlob ? sc.edgeBlob + rc.edgeOff[LOD] : nullptr;
+    const double eMin = rc.edgeMin[LOD], eMax = rc.edgeMax[LOD];
     const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useGrad = sc.cfg.adaptiveGradientEnable != 0;
     const double gradW = sc.cfg.gradientWeighting;
     for (int k = lane; k < S2; k += 64) {
@@ -202,7 +217,10 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
         WinPix wp;
         wp.refCol = lerp3(load_row(refF + off), load_row(refF + off + (uint32_t)refW), bx, by);
         double ws = useDist ? sc.gauss[xi * S + yi] : 1.0;
-        if (useGrad) ws *= det_exp_poly(-1.0 / (refEdge[ry * refW + rx] * gradW));
+        if (useGrad) {
+            const double e = refEdge ? refEdge[ry * refW + rx] : edge_on_the_fly(refImg, refW, refH, rx, ry, eMin, eMax);
+            ws *= det_exp_poly(-1.0 / (e * gradW));
+        }
         wp.wStat = (refImg[ry * refW + rx] != 0) ? ws : -1.0; // :986
         win[k] = wp;
     }

@@ -24,6 +24,9 @@ struct DevCamera {
     // kernel argument lets the compiler emit global_load (saddr) instead of flat_load for every tap
     uint64_t imgOff[PAIS_MAX_LEVELS];
     uint64_t edgeOff[PAIS_MAX_LEVELS];
+    // edge maps evaluated on the fly (DevScene::edgeBlob == nullptr while adaptiveGradientEnable is set): the minimum and
+    // maximum Sobel magnitude of every level, what the per-level normalisation of camera.cpp:72-77,87-91 needs
+    double edgeMin[PAIS_MAX_LEVELS], edgeMax[PAIS_MAX_LEVELS];
 };
 
 // What the cost taps read: a copy of the byte blob with identical element offsets (imgOff), in a layout that needs no
@@ -51,7 +54,7 @@ struct DevScene {
     const DevCamera *cams;
     const uint8_t *imgBlob;
     const PaisImgT *imgF;   // tap copy of imgBlob, same element offsets (imgOff)
-    const double *edgeBlob;
+    const double *edgeBlob; // normalised Sobel magnitude per level as the caller built it; nullptr: evaluated on the fly
     const double *gauss; // patchDistWeight, S*S, indexed [x*S + y] (mvs.cpp:104-109)
     double lodScale[PAIS_MAX_LEVELS]; // pow(lodRatio, LOD) (camera.cpp:157, patch.cpp:309)
     uint64_t seed;
@@ -67,6 +70,8 @@ hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStat
                    double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream);
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream);
 hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream);
+hipError_t expand_image(const uint8_t *img, PaisImgT *out, size_t n, hipStream_t stream);
+hipError_t level_edge_minmax(const uint8_t *img, int w, int h, unsigned long long *minmax, hipStream_t stream);
 size_t pso_state_bytes_host(int Nmax);
 hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
                     int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);

@@ -1274,6 +1274,65 @@ __global__ __launch_bounds__(128) void k_after(DevScene sc, pais_patch_result *r
     }
 }
 
+// ------------------------------------------------------- scene preparation ---
+// tap copy of the byte blob (pais_internal.h PAIS_IMG_MODE): one thread per pixel, coalesced
+__global__ __launch_bounds__(256) void k_expand_image(const uint8_t *img, PaisImgT *out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#if PAIS_IMG_MODE == 0
+    out[i] = (float)img[i];
+#elif PAIS_IMG_MODE == 3
+    out[i] = img[i];
+#else
+    const int a = img[i], b = (i + 1 < n) ? img[i + 1] : 0; // the last column's difference is never tapped
+    PaisImgT v;
+    v.x = a;
+    v.y = b - a;
+    out[i] = v;
+#endif
+}
+// minimum / maximum Sobel magnitude of one level (the statements of k_sobel_mag in pais_pyramid.hip without the map):
+// magnitudes are >= 0, so their bit patterns order like the values; one atomic pair per workgroup
+__global__ __launch_bounds__(256) void k_level_edge_minmax(const uint8_t *img, int w, int h, unsigned long long *minmax)
+{
+    __shared__ unsigned long long red[8];
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long lo = ~0ULL, hi = 0ULL;
+    if (x < w) {
+        const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+        for (int r = 0; r < 16; ++r) {
+            const int y = blockIdx.y * 16 + r;
+            if (y >= h) break;
+            const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+            const double gx = (double)img[(size_t)y * w + xr] - (double)img[(size_t)y * w + xl];
+            const double gy = (double)img[(size_t)yd * w + x] - (double)img[(size_t)yu * w + x];
+            const unsigned long long u = (unsigned long long)__double_as_longlong(sqrt(gx * gx + gy * gy));
+            lo = u < lo ? u : lo;
+            hi = u > hi ? u : hi;
+        }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long ol = __shfl_xor(lo, s, 64), oh = __shfl_xor(hi, s, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave] = lo;
+        red[4 + wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q) {
+            lo = red[q] < lo ? red[q] : lo;
+            hi = red[4 + q] > hi ? red[4 + q] : hi;
+        }
+        if (lo != ~0ULL) atomicMin(&minmax[0], lo);
+        atomicMax(&minmax[1], hi);
+    }
+}
+
 // -------------------------------------------------------- k_neighbor_count ---
 // MVS::neighborPatchFiltering (mvs.cpp:448-524), the O(n^2) part: for every patch the number of OTHER patches
 // whose centre lies within neighborRadius (the reference sorts all distances and counts up to the first one
@@ -1383,6 +1442,18 @@ hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_res
     return hipGetLastError();
 }
 
+hipError_t expand_image(const uint8_t *img, PaisImgT *out, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_expand_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, img, out, n);
+    return hipGetLastError();
+}
+// minmax[0] = ~0, minmax[1] = 0 on entry (ordered bit patterns of the minimum / maximum magnitude on exit)
+hipError_t level_edge_minmax(const uint8_t *img, int w, int h, unsigned long long *minmax, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_level_edge_minmax, dim3((w + 255) / 256, (h + 15) / 16), dim3(256), 0, stream, img, w, h, minmax);
+    return hipGetLastError();
+}
 hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;

@@ -114,6 +114,51 @@ def render(obj: SolidOfRevolution, R: np.ndarray, C: np.ndarray, focal, pp, widt
     return img
 
 
+def render_gpu(obj: SolidOfRevolution, R: np.ndarray, C: np.ndarray, focal, pp, width: int, height: int, device: int = 0,
+               chunk_rows: int = 1024) -> np.ndarray:
+    """The statements of render() evaluated with torch on an MI355X (float64): the 128 x 12.6 MP renders of the dome
+    rig take hours in numpy on the host.  Test / bench infrastructure for producing synthetic inputs -- not the product."""
+    import torch
+    dev = torch.device("cuda", device)
+    f64 = torch.float64
+    T = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=f64, device=dev)
+    Q = T(obj.frame())
+    Rt, Ct = T(R), T(C)
+    o = Q @ (Ct - T(obj.center))
+    wk, wphi, wamp = T(obj.waves_k), T(obj.waves_phi), T(obj.waves_amp)
+    img = torch.zeros((height, width), dtype=torch.uint8, device=dev)
+    us = torch.arange(width, dtype=f64, device=dev)
+    for y0 in range(0, height, chunk_rows):
+        y1 = min(height, y0 + chunk_rows)
+        vs = torch.arange(y0, y1, dtype=f64, device=dev)
+        vv, uu = torch.meshgrid(vs, us, indexing="ij")
+        dc = torch.stack([(uu.reshape(-1) - pp[0]) / focal[0], (vv.reshape(-1) - pp[1]) / focal[1], torch.ones(uu.numel(), dtype=f64, device=dev)], dim=1)
+        dw = dc @ Rt
+        d = dw @ Q.T
+        best = torch.full((dw.shape[0],), float("inf"), dtype=f64, device=dev)
+        for e in obj.parts:
+            s = T([1.0 / e.rxy, 1.0 / e.rxy, 1.0 / e.rz])
+            oo = (o - T([0.0, 0.0, e.z])) * s
+            dd = d * s
+            A = (dd * dd).sum(dim=1)
+            B = 2.0 * (dd @ oo)
+            Cc = float(oo @ oo) - 1.0
+            disc = B * B - 4 * A * Cc
+            ok = disc > 0
+            sq = torch.sqrt(torch.where(ok, disc, torch.zeros_like(disc)))
+            t = (-B - sq) / (2 * A)
+            t = torch.where(ok & (t > 1e-9), t, torch.full_like(t, float("inf")))
+            best = torch.minimum(best, t)
+        hit = torch.isfinite(best)
+        vals = torch.zeros(uu.numel(), dtype=f64, device=dev)
+        if bool(hit.any()):
+            X = Ct[None, :] + best[hit, None] * dw[hit]
+            alb = 128.0 + torch.sin(X @ wk.T + wphi) @ wamp
+            vals[hit] = torch.clamp(torch.round(alb), 16, 240)
+        img[y0:y1] = vals.reshape(y1 - y0, width).to(torch.uint8)
+    return img.cpu().numpy()
+
+
 @dataclass
 class Scene:
     name: str
@@ -228,8 +273,8 @@ def pawn_scene(width: int = 640, height: int = 480, n_seeds: int = 200, lod_rati
 def ring_scene(n_cams: int = 32, width: int = 1920, height: int = 1080, focal: float = 2000.0,
                radius: float = 3.0, elevation_deg: float = 20.0, n_seeds: int = 400, lod_ratio: float = 0.8,
                cfg_max_lod: int = 15, tex_seed: int = 2345, seed_seed: int = 6789,
-               build_edges: bool = True) -> Scene:
-    """Configs 2/3: cameras on a circle looking at a textured solid at the origin."""
+               build_edges: bool = True, device=None) -> Scene:
+    """Configs 2/3: cameras on a circle looking at a textured solid at the origin.  device: render / build pyramids on that GPU."""
     X0 = np.zeros(3)
     up = np.array([0.0, 0.0, 1.0])
     parts = [Ellipsoid(-0.35, 0.55, 0.22), Ellipsoid(0.0, 0.38, 0.55), Ellipsoid(0.45, 0.30, 0.30)]
@@ -249,17 +294,21 @@ def ring_scene(n_cams: int = 32, width: int = 1920, height: int = 1080, focal: f
         q = rotation_to_quaternion(R)
         f2 = np.array([focal, focal])
         pp = np.array([float(width >> 1), float(height >> 1)])
-        img = render(obj, quaternion_to_rotation(q), C, f2, pp, width, height)
+        if device is None:
+            img = render(obj, quaternion_to_rotation(q), C, f2, pp, width, height)
+        else:
+            img = render_gpu(obj, quaternion_to_rotation(q), C, f2, pp, width, height, device)
         cams.append(Camera(focal=f2, principle_point=np.array([-1.0, -1.0]), quaternion=q, center=C, image=img,
-                           name="ring%04d" % i).finalize(lod_ratio, cfg_max_lod, build_edges))
+                           name="ring%04d" % i).finalize(lod_ratio, cfg_max_lod, build_edges, device=device))
     seeds = _make_seeds(obj, cams, n_seeds, np.random.default_rng(seed_seed))
     return Scene("ring", cams, obj, seeds)
 
 
 def dome_scene(n_cams: int = 128, width: int = 4096, height: int = 3072, focal: float = 4500.0,
                radius: float = 4.0, n_seeds: int = 2000, lod_ratio: float = 0.8, cfg_max_lod: int = 15,
-               tex_seed: int = 3456, seed_seed: int = 7890, build_edges: bool = True) -> Scene:
-    """Config 4: Fibonacci hemisphere of cameras."""
+               tex_seed: int = 3456, seed_seed: int = 7890, build_edges: bool = True, device=None) -> Scene:
+    """Config 4: Fibonacci hemisphere of cameras.  device: render and build the pyramids on that GPU (full size:
+    128 x 4096 x 3072 takes hours in numpy); build_edges = False leaves the edge maps to the library (on the fly)."""
     X0 = np.zeros(3)
     up = np.array([0.0, 0.0, 1.0])
     parts = [Ellipsoid(-0.35, 0.75, 0.3), Ellipsoid(0.0, 0.5, 0.7), Ellipsoid(0.55, 0.4, 0.4)]
@@ -280,8 +329,11 @@ def dome_scene(n_cams: int = 128, width: int = 4096, height: int = 3072, focal: 
         q = rotation_to_quaternion(R)
         f2 = np.array([focal, focal])
         pp = np.array([float(width >> 1), float(height >> 1)])
-        img = render(obj, quaternion_to_rotation(q), C, f2, pp, width, height)
+        if device is None:
+            img = render(obj, quaternion_to_rotation(q), C, f2, pp, width, height)
+        else:
+            img = render_gpu(obj, quaternion_to_rotation(q), C, f2, pp, width, height, device)
         cams.append(Camera(focal=f2, principle_point=np.array([-1.0, -1.0]), quaternion=q, center=C, image=img,
-                           name="dome%04d" % i).finalize(lod_ratio, cfg_max_lod, build_edges))
+                           name="dome%04d" % i).finalize(lod_ratio, cfg_max_lod, build_edges, device=device))
     seeds = _make_seeds(obj, cams, n_seeds, np.random.default_rng(seed_seed))
     return Scene("dome", cams, obj, seeds)

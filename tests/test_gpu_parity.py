@@ -667,3 +667,123 @@ def test_large_swarms_and_the_split_pipeline_match_oracle(pawn_small, monkeypatc
             alive += 0 if p.drop else 1
         assert alive >= 3
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_edges_on_the_fly_equal_the_given_edge_maps(ring_small):
+    """level_edge == NULL with adaptiveGradientEnable: the library evaluates Camera::pyramidEdge from the gray levels
+    itself (Sobel ksize 1, magnitude, per-level min-max; camera.cpp:72-77,87-91) instead of keeping an 8-byte-per-pixel
+    copy in HBM.  Cost values and whole refine() records must equal those computed from the caller's edge
+    pyramids bit for bit -- and so, transitively, the oracle, which reads those pyramids."""
+    import copy
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import Context
+    cfg = readme_config(adaptiveGradientEnable=True, particleNum=8, maxIteration=12)
+    S = common.oracle_scene(cfg, ring_small)
+    rng = np.random.default_rng(3)
+    states, pats, idx, parts = _states_and_particles(S, ring_small, rng, n_per=12)
+    _, cands = common.seed_candidates(S, ring_small)
+    bare = []
+    for cam in ring_small.cameras:
+        c2 = copy.copy(cam)
+        c2.edge_pyramid = []
+        bare.append(c2)
+    out = []
+    for cams in (ring_small.cameras, bare):
+        ctx = Context(cfg, cams, device=0, seed=42)
+        fit = ctx.fitness_batch(states, idx, parts)
+        res = ctx.refine_batch(cands[:16])
+        out.append((fit.tobytes(), [bytes(r) for r in res]))
+        ctx.close()
+    assert np.isfinite(np.frombuffer(out[0][0])).sum() > 30
+    assert out[0][0] == out[1][0]
+    assert out[0][1] == out[1][1]
+
+
+def _surface_error(scene, patches, every):
+    obj = scene.obj
+    errs = []
+    for p in patches[::every]:
+        cam = scene.cameras[p.ref_cam]
+        d = np.array(p.center[:]) - cam.center
+        dist = np.linalg.norm(d)
+        t = obj.intersect(cam.center, (d / dist)[None, :])[0]
+        errs.append(abs(t - dist) / dist)
+    return float(np.median(errs))
+
+
+@pytest.mark.gpu
+def test_ring_full_size_properties_and_determinism():
+    """BASELINE.json configs[2] at FULL size: 32 cameras 1920x1080 on a ring, patchRadius 15, all three adaptive weights
+    on (edge maps on the fly), rounds of 4096 parents, a bounded number of rounds.  Size-independent properties: every
+    accepted patch satisfies the acceptance rules of runtimeFiltering, lies on the synthetic surface, the surface is
+    actually grown, and the cloud is bit-reproducible run to run."""
+    import torch
+    from pais_mvs_amd import synth
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    scene = synth.ring_scene(n_seeds=300, build_edges=False, device=0)
+    assert len(scene.cameras) == 32 and scene.cameras[0].image.shape == (1080, 1920)
+    cfg = readme_config(adaptiveGradientEnable=True)
+    clouds = []
+    for rep in range(2):
+        m = MVS(cfg, scene.cameras, device=0, seed=42)
+        for X, vis in scene.seeds:
+            m.add_seed(X, vis)
+        m.refineSeedPatches()
+        n_seed = m.num_patches()
+        m.expansionPatches(4096, 5)
+        ps = m.patches()
+        st = m.stats()
+        clouds.append(m.cloud())
+        assert n_seed > len(scene.seeds) // 2 and len(ps) > 8 * n_seed, (n_seed, len(ps))
+        ks = [p.num_cam for p in ps]
+        assert max(ks) >= 7 and min(ks) >= cfg.minCamNum
+        for p in ps[:: max(1, len(ps) // 500)]:
+            assert not p.dropped and 0 < p.fitness <= cfg.maxFitness and p.correlation >= cfg.minCorrelation
+            assert len(set(p.cams())) == p.num_cam and p.ref_cam in p.cams()
+            assert abs(np.linalg.norm(np.array(p.normal[:])) - 1) < 1e-12
+        assert _surface_error(scene, ps, max(1, len(ps) // 300)) < 2e-3
+        assert st.candidates_refined >= st.candidates_effective > 0
+        m.close()
+    assert clouds[0].shape == clouds[1].shape and np.array_equal(clouds[0], clouds[1])
+
+
+@pytest.mark.gpu
+def test_dome_full_size_bounded_rounds():
+    """BASELINE.json configs[4] on ONE GPU at FULL size: 128 cameras 4096x3072 on a Fibonacci dome, patchRadius 25
+    (S^2 = 2601), reduceNormalRange 4, all adaptive weights on.  The renders and pyramids are produced on the GPU (hours in
+    numpy), the edge maps are never materialised; seeds + a bounded number of expansion rounds; properties as above and the
+    HBM footprint is reported (~4.5 GB of gray pyramids + their tap copy)."""
+    import torch
+    from pais_mvs_amd import synth
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    free0, total = torch.cuda.mem_get_info(0)
+    scene = synth.dome_scene(n_seeds=160, build_edges=False, device=0)
+    assert len(scene.cameras) == 128 and scene.cameras[0].image.shape == (3072, 4096)
+    cfg = readme_config(patchRadius=25, distWeighting=25 / 3.0, reduceNormalRange=4.0, adaptiveGradientEnable=True)
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info(0)
+    m = MVS(cfg, scene.cameras, device=0, seed=42)
+    free2, _ = torch.cuda.mem_get_info(0)
+    scene_gb = (free1 - free2) / 2 ** 30
+    for X, vis in scene.seeds:
+        m.add_seed(X, vis)
+    m.refineSeedPatches()
+    n_seed = m.num_patches()
+    m.expansionPatches(1024, 2)
+    free3, _ = torch.cuda.mem_get_info(0)
+    ps = m.patches()
+    st = m.stats()
+    print("\ndome 128 x 4096 x 3072: scene in HBM %.1f GB, peak working set %.1f GB of %.0f GB; %d seeds kept, %d patches after 2 rounds, "
+          "K max %d, %d candidates refined" % (scene_gb, (free1 - free3) / 2 ** 30, total / 2 ** 30, n_seed, len(ps), max(p.num_cam for p in ps),
+                                              st.candidates_refined))
+    assert 10.0 < scene_gb < 80.0
+    assert n_seed >= len(scene.seeds) // 3 and len(ps) > 2 * n_seed
+    assert max(p.num_cam for p in ps) >= 12
+    for p in ps[:: max(1, len(ps) // 300)]:
+        assert not p.dropped and 0 < p.fitness <= cfg.maxFitness and p.correlation >= cfg.minCorrelation
+        assert len(set(p.cams())) == p.num_cam and p.ref_cam in p.cams()
+    assert _surface_error(scene, ps, max(1, len(ps) // 200)) < 2e-3
+    m.close()
