@@ -1278,19 +1278,20 @@ __global__ __launch_bounds__(128) void k_after(DevScene sc, pais_patch_result *r
 // tap copy of the byte blob (pais_internal.h PAIS_IMG_MODE): one thread per pixel, coalesced
 __global__ __launch_bounds__(256) void k_expand_image(const uint8_t *img, PaisImgT *out, size_t n)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    // grid-stride: a blob of several GB has more pixels than one launch may have threads (2^32)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 #if PAIS_IMG_MODE == 0
-    out[i] = (float)img[i];
+        out[i] = (float)img[i];
 #elif PAIS_IMG_MODE == 3
-    out[i] = img[i];
+        out[i] = img[i];
 #else
-    const int a = img[i], b = (i + 1 < n) ? img[i + 1] : 0; // the last column's difference is never tapped
-    PaisImgT v;
-    v.x = a;
-    v.y = b - a;
-    out[i] = v;
+        const int a = img[i], b = (i + 1 < n) ? img[i + 1] : 0; // the last column's difference is never tapped
+        PaisImgT v;
+        v.x = a;
+        v.y = b - a;
+        out[i] = v;
 #endif
+    }
 }
 // minimum / maximum Sobel magnitude of one level (the statements of k_sobel_mag in pais_pyramid.hip without the map):
 // magnitudes are >= 0, so their bit patterns order like the values; one atomic pair per workgroup
@@ -1445,7 +1446,8 @@ hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_res
 hipError_t expand_image(const uint8_t *img, PaisImgT *out, size_t n, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_expand_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, img, out, n);
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_expand_image, dim3((unsigned)(blocks < (1u << 20) ? blocks : (1u << 20))), dim3(256), 0, stream, img, out, n);
     return hipGetLastError();
 }
 // minmax[0] = ~0, minmax[1] = 0 on entry (ordered bit patterns of the minimum / maximum magnitude on exit)

@@ -211,7 +211,9 @@ def _surface_normal(obj: SolidOfRevolution, X: np.ndarray) -> np.ndarray:
 
 
 def _make_seeds(obj: SolidOfRevolution, cams: List[Camera], n_seeds: int, rng: np.random.Generator,
-                min_vis: int = 3) -> List[Tuple[np.ndarray, List[int]]]:
+                min_vis: int = 3, max_vis: int = 0) -> List[Tuple[np.ndarray, List[int]]]:
+    """max_vis > 0: a seed keeps at most that many cameras, the most frontal ones (an SfM track is short; the path
+    tracks at most PAIS_MAX_VIS = 64 cameras per patch)."""
     seeds: List[Tuple[np.ndarray, List[int]]] = []
     tries = 0
     while len(seeds) < n_seeds and tries < n_seeds * 200:
@@ -228,6 +230,13 @@ def _make_seeds(obj: SolidOfRevolution, cams: List[Camera], n_seeds: int, rng: n
         X = c.center + t * dw
         n = _surface_normal(obj, X)
         vis = _visible_cams(obj, X, n, cams)
+        if max_vis and len(vis) > max_vis:
+            cosv = []
+            for i in vis:
+                v = cams[i].center - X
+                cosv.append(float(v @ n) / float(np.linalg.norm(v)))
+            keep = sorted(sorted(range(len(vis)), key=lambda k: -cosv[k])[:max_vis])
+            vis = [vis[k] for k in keep]
         if len(vis) >= min_vis:
             seeds.append((X, vis))
     return seeds
@@ -335,5 +344,5 @@ def dome_scene(n_cams: int = 128, width: int = 4096, height: int = 3072, focal: 
             img = render_gpu(obj, quaternion_to_rotation(q), C, f2, pp, width, height, device)
         cams.append(Camera(focal=f2, principle_point=np.array([-1.0, -1.0]), quaternion=q, center=C, image=img,
                            name="dome%04d" % i).finalize(lod_ratio, cfg_max_lod, build_edges, device=device))
-    seeds = _make_seeds(obj, cams, n_seeds, np.random.default_rng(seed_seed))
+    seeds = _make_seeds(obj, cams, n_seeds, np.random.default_rng(seed_seed), max_vis=32)
     return Scene("dome", cams, obj, seeds)

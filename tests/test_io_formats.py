@@ -108,3 +108,156 @@ def test_ply_and_psr_writers(tmp_path):
     io.write_psr(str(psr), cen, nor)
     vals = np.frombuffer(psr.read_bytes(), dtype="<f4").reshape(2, 6)
     assert np.array_equal(vals, np.hstack([cen, nor]).astype(np.float32))
+
+
+# ---- cross-checks against the oracle's independent C restatement (oracle/po_io.c) --------------------------------------
+def _po_io():
+    import ctypes as C
+    from oracle import po
+    L = po.lib()
+
+    class OCam(C.Structure):
+        _fields_ = [("name", C.c_char * 256), ("center", C.c_double * 3), ("focal", C.c_double * 2), ("pp", C.c_double * 2),
+                    ("quaternion", C.c_double * 4), ("radial", C.c_double)]
+
+    class OPatch(C.Structure):
+        _fields_ = [("center", C.c_double * 3), ("normalS", C.c_double * 2), ("numCam", C.c_int), ("camIdx", C.c_int * 64),
+                    ("fitness", C.c_double), ("correlation", C.c_double)]
+    L.po_io_sizeof_mvsconfig.restype = C.c_size_t
+    L.po_io_write_mvs_v3.argtypes = [C.c_char_p, C.POINTER(po.Config), C.c_int, C.POINTER(OCam), C.c_int, C.POINTER(OPatch)]
+    L.po_io_read_mvs_v3.argtypes = [C.c_char_p, C.POINTER(po.Config), C.POINTER(C.c_int), C.c_int, C.POINTER(OCam), C.POINTER(C.c_int),
+                                    C.c_int, C.POINTER(OPatch), C.POINTER(C.c_int)]
+    L.po_io_parse_nvm_point.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    return L, OCam, OPatch
+
+
+def _sample_cloud(rng, n_cam=4, n_pat=57):
+    cams = [dict(name="view_%02d.jpg" % i, center=rng.normal(size=3), focal=rng.uniform(500, 900, 2), pp=rng.uniform(200, 400, 2),
+                 q=rng.normal(size=4), radial=float(rng.normal())) for i in range(n_cam)]
+    pats = []
+    for _ in range(n_pat):
+        k = int(rng.integers(0, n_cam + 1))
+        pats.append(dict(center=rng.normal(size=3), normalS=rng.uniform(-3, 3, 2), cams=sorted(rng.choice(n_cam, k, replace=False).tolist()),
+                         fitness=float(rng.uniform(0, 10)), correlation=float(rng.uniform(0, 1))))
+    return cams, pats
+
+
+def test_mvs_v3_cross_read_with_the_oracle_restatement(tmp_path):
+    """N1: the product's writer/reader (pais_io.hip) against an independent C statement of io/filewriter.cpp:3-103 and
+    io/fileloader.cpp:167-231,403-472 -- each side reads what the other wrote, and the two files are byte-identical."""
+    import ctypes as C
+    from oracle import po
+    from pais_mvs_amd import io
+    from pais_mvs_amd.config import readme_config
+    from tests.common import oracle_cfg
+    L, OCam, OPatch = _po_io()
+    assert L.po_io_sizeof_mvsconfig() == 160 == io._L().pais_io_sizeof_mvsconfig_disk()
+    rng = np.random.default_rng(17)
+    cams, pats = _sample_cloud(rng)
+    cfg = readme_config(adaptiveGradientEnable=True, neighborRadius=0.0123, expansionStrategy=2)
+    # product writes
+    a = str(tmp_path / "product.mvs")
+    io.write_mvs(a, cfg, [io.io_camera(c["name"], c["focal"], c["pp"], c["q"], c["center"], c["radial"]) for c in cams],
+                 [io.io_patch(p["center"], p["normalS"], p["cams"], p["fitness"], p["correlation"]) for p in pats])
+    # oracle writes
+    b = str(tmp_path / "oracle.mvs")
+    oc = (OCam * len(cams))()
+    for o, c in zip(oc, cams):
+        o.name = c["name"].encode(); o.center[:] = c["center"]; o.focal[:] = c["focal"]; o.pp[:] = c["pp"]; o.quaternion[:] = c["q"]; o.radial = c["radial"]
+    op = (OPatch * len(pats))()
+    for o, p in zip(op, pats):
+        o.center[:] = p["center"]; o.normalS[:] = p["normalS"]; o.numCam = len(p["cams"]); o.fitness = p["fitness"]; o.correlation = p["correlation"]
+        for i, v in enumerate(p["cams"]):
+            o.camIdx[i] = v
+    ocfg = oracle_cfg(cfg)
+    assert L.po_io_write_mvs_v3(b.encode(), C.byref(ocfg), len(cams), oc, len(pats), op) == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+    # product reads the oracle's file
+    cfg2, cams2, pats2 = io.load_mvs(b)
+    assert cfg2 == cfg and len(cams2) == len(cams) and len(pats2) == len(pats)
+    for g, c in zip(cams2, cams):
+        assert g.file_name.decode() == c["name"] and list(g.center) == list(c["center"]) and list(g.quaternion) == list(c["q"])
+        assert list(g.focal) == list(c["focal"]) and list(g.principle_point) == list(c["pp"]) and g.radial_distortion == c["radial"]
+    for g, p in zip(pats2, pats):
+        assert list(g.center) == list(p["center"]) and list(g.normalS) == list(p["normalS"]) and list(g.cam_idx[:g.num_cam]) == p["cams"]
+        assert g.fitness == p["fitness"] and g.correlation == p["correlation"]
+    # the oracle reads the product's file
+    rc_cfg = po.Config(); has = C.c_int(0); nc = C.c_int(0); npp = C.c_int(0)
+    rc_c = (OCam * 16)(); rc_p = (OPatch * 128)()
+    assert L.po_io_read_mvs_v3(a.encode(), C.byref(rc_cfg), C.byref(has), 16, rc_c, C.byref(nc), 128, rc_p, C.byref(npp)) == 0
+    assert has.value == 1 and nc.value == len(cams) and npp.value == len(pats)
+    for name, _t in po.Config._fields_:
+        assert getattr(rc_cfg, name) == getattr(ocfg, name), name
+    for g, c in zip(rc_c, cams):
+        assert g.name.decode() == c["name"] and list(g.center) == list(c["center"]) and list(g.quaternion) == list(c["q"]) and g.radial == c["radial"]
+    for g, p in zip(rc_p, pats):
+        assert list(g.center) == list(p["center"]) and list(g.camIdx[:g.numCam]) == p["cams"] and g.fitness == p["fitness"]
+
+
+def test_nvm_point_lines_cross_parse(tmp_path):
+    """N1: NVM measurement lines -- the product's loader and the oracle's statement of fileloader.cpp:112-165 agree, incl.
+    the image-centre offset (cols / 2, rows / 2 with integer division) the driver adds for reCentering."""
+    import ctypes as C
+    from pais_mvs_amd import io
+    L, _, _ = _po_io()
+    rng = np.random.default_rng(5)
+    widths, heights = [640, 641, 1920, 333], [480, 479, 1080, 777]
+    lines = []
+    for _ in range(40):
+        n = int(rng.integers(1, 5))
+        idx = rng.choice(4, n, replace=False)
+        meas = " ".join("%d %d %r %r" % (int(c), int(rng.integers(0, 5000)), float(rng.normal(0, 200)), float(rng.normal(0, 150))) for c in idx)
+        lines.append("%r %r %r %d %d %d %d %s " % (float(rng.normal()), float(rng.normal()), float(rng.normal()), *rng.integers(0, 256, 3), n, meas))
+    p = tmp_path / "pts.nvm"
+    cam_lines = ["c%d.jpg 600 1 0 0 0 0 0 0 0 0" % i for i in range(4)]
+    p.write_text("NVM_V3\n\n4\n" + "\n".join(cam_lines) + "\n\n%d\n" % len(lines) + "\n".join(lines) + "\n\n0\n")
+    _, pts = io.load_nvm(str(p))
+    assert len(pts) == len(lines)
+    W = (C.c_int * 4)(*widths); H = (C.c_int * 4)(*heights)
+    for line, g in zip(lines, pts):
+        cen = (C.c_double * 3)(); rgb = (C.c_int * 3)(); ci = (C.c_int * 8)(); xy = (C.c_double * 16)()
+        n = L.po_io_parse_nvm_point(line.encode(), 4, W, H, cen, rgb, 8, ci, xy)
+        assert n == g.num_meas and list(cen) == list(g.center) and list(rgb) == list(g.rgb)
+        for i in range(n):
+            assert ci[i] == g.cam_idx[i]
+            # the product keeps the file's offsets; the driver adds the image centre (pais_mvs_add_seed_measured's caller)
+            assert xy[2 * i] == g.xy[i][0] + widths[ci[i]] // 2 and xy[2 * i + 1] == g.xy[i][1] + heights[ci[i]] // 2
+
+
+def test_host_pyramid_equals_the_oracle_restatement():
+    """N2 on the CPU: camera.py (the product's host construction of Camera::Camera's pyramid and edge maps) against the
+    oracle's C statement of camera.cpp:63-91 + the published area-resize / Sobel algorithms -- identical arrays.  The float
+    accumulator order of OpenCV 2.4 (po_resize_area_f32) is the documented alternative: it moves a small fraction of
+    pixels by one grey level, never more."""
+    import ctypes as C
+    from oracle import po
+    from pais_mvs_amd.camera import resize_area, sobel_magnitude_normalised
+    L = po.lib()
+    u8 = C.POINTER(C.c_uint8)
+    L.po_resize_area.argtypes = [u8, C.c_int, C.c_int, C.c_double, u8]
+    L.po_resize_area_f32.argtypes = [u8, C.c_int, C.c_int, C.c_double, u8]
+    L.po_resize_dims.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.po_sobel_magnitude_normalised.argtypes = [u8, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(3)
+    moved = total = 0
+    for (h, w) in ((240, 320), (271, 353), (97, 64)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (127 + 80 * np.sin(xx / 7.3) * np.cos(yy / 5.1) + rng.normal(0, 20, (h, w))).clip(0, 255).astype(np.uint8)
+        for lvl in (1, 2, 5, 9):
+            fx = 0.8 ** lvl
+            dw, dh = C.c_int(), C.c_int()
+            L.po_resize_dims(w, h, fx, C.byref(dw), C.byref(dh))
+            want = np.zeros((dh.value, dw.value), np.uint8)
+            L.po_resize_area(img.ctypes.data_as(u8), w, h, fx, want.ctypes.data_as(u8))
+            got = resize_area(img, fx)
+            assert got.shape == want.shape and np.array_equal(got, want), (h, w, lvl)
+            f32 = np.zeros_like(want)
+            L.po_resize_area_f32(img.ctypes.data_as(u8), w, h, fx, f32.ctypes.data_as(u8))
+            d = np.abs(f32.astype(int) - want.astype(int))
+            assert d.max() <= 1
+            moved += int((d > 0).sum()); total += d.size
+            e = np.zeros(want.shape, np.float64)
+            L.po_sobel_magnitude_normalised(want.ctypes.data_as(u8), want.shape[1], want.shape[0], e.ctypes.data_as(C.POINTER(C.c_double)))
+            assert np.array_equal(sobel_magnitude_normalised(want), e)
+    assert moved <= 0.02 * total, (moved, total)
