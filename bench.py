@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="pawn", choices=["pawn", "ring"])
+    ap.add_argument("--scene", default="pawn", choices=["pawn", "ring", "dome"])
     ap.add_argument("--parents-per-round", type=int, default=int(os.environ.get("PAIS_B", "4096")))
     ap.add_argument("--max-rounds", type=int, default=0)
     ap.add_argument("--seeds", type=int, default=200)
@@ -43,17 +43,25 @@ def parse():
     return ap.parse_args()
 
 
-def build_scene(args):
+def build_scene(args, device):
+    """pawn = BASELINE.json configs[1] (the configuration the metric is quoted on, the default); ring = configs[2] and
+    dome = configs[4] at full size are extra lines for profiles/ (rendered and pyramided on the GPU, edge maps on the fly)."""
     from pais_mvs_amd import synth
     from pais_mvs_amd.config import readme_config
     if args.scene == "pawn":
         cfg = readme_config()
         scene = synth.pawn_scene(n_seeds=args.seeds, build_edges=False)
         name = "5-camera pawn scene (README.md:68-72 cameras, synthetic 640x480 renders), patchRadius 15, README config, full expansion to convergence"
-    else:
+    elif args.scene == "ring":
         cfg = readme_config(adaptiveGradientEnable=True)
-        scene = synth.ring_scene(n_seeds=max(args.seeds, 400), build_edges=True)
-        name = "32-camera synthetic ring 1920x1080, patchRadius 15, adaptive weighting on"
+        scene = synth.ring_scene(n_seeds=max(args.seeds, 400), build_edges=False, device=device)
+        name = "32-camera synthetic ring 1920x1080, patchRadius 15, all adaptive weights on"
+    else:
+        cfg = readme_config(patchRadius=25, distWeighting=25 / 3.0, reduceNormalRange=4.0, adaptiveGradientEnable=True)
+        scene = synth.dome_scene(n_seeds=max(args.seeds, 400), build_edges=False, device=device)
+        name = "128-camera synthetic dome 4096x3072, patchRadius 25, reduceNormalRange 4, all adaptive weights on"
+    if args.max_rounds:
+        name += " (first %d expansion rounds)" % args.max_rounds
     return cfg, scene, name
 
 
@@ -202,7 +210,7 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
 
-    cfg, scene, wname = build_scene(args)
+    cfg, scene, wname = build_scene(args, local)
     m = MVS(cfg, scene.cameras, device=local, seed=42)
     if world > 1 or force_dist:
         D.attach(m, job, transport=os.environ.get("PAIS_DIST_TRANSPORT", "rccl"))
@@ -300,7 +308,7 @@ def main():
                                    "host_enumerate": last.host_enumerate_ms if last else 0,
                                    "host_commit": last.host_commit_ms if last else 0},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.scene == "pawn":   # the extra scenes carry no host edge maps for the oracle
             out["cpu_baseline"] = cpu_baseline(cfg, scene, args.cpu_seconds, int(last.seeds_refined), int(last.candidates_effective))
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     m.close()

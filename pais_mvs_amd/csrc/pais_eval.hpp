@@ -319,11 +319,11 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 //   Hbuf : M*9 doubles            (homographies, patch.cpp:290-330)
 //   cbuf : (NS*M + 8)*64 doubles  (per-camera colour of the lane's NS pixels; last 8 rows: the lane's 4 x (fitness,
 //          weight) sub-accumulators)
-#if PAIS_ACC_REG
-#define PAIS_CBUF_ROWS(NS, M) ((NS) * (M))
-#else
-#define PAIS_CBUF_ROWS(NS, M) ((NS) * (M) + 8)
-#endif
+// The lane's four (fitness, weight) sub-accumulators: LDS rows for the two-pixel kernels (few cameras: registers are the
+// scarce resource there), registers for the one-pixel kernels (many cameras: the LDS scratch caps the occupancy;
+// measured +17 % on the 32-camera ring, -1 % on the 5-camera pawn scene if used there too)
+#define PAIS_ACC_IN_REGS(NS) (PAIS_ACC_REG || (NS) == 1)
+#define PAIS_CBUF_ROWS(NS, M) ((NS) * (M) + (PAIS_ACC_IN_REGS(NS) ? 0 : 8))
 __host__ __device__ inline size_t eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
 __host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax)
 {
@@ -385,13 +385,13 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     const bool hasRef = ep->hasRef != 0;
     const double invK = 1.0 / (double)K;
     double *myc = cbuf + lane;
-#if PAIS_ACC_REG
-    double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0}; // the lane's sub-accumulators
-#else
-    double *myacc = cbuf + (size_t)M * NS * 64 + lane; // [2a] fitness, [2a+1] weight of sub-accumulator a
+    constexpr bool ACCREG = PAIS_ACC_IN_REGS(NS);
+    double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0}; // the lane's sub-accumulators (ACCREG)
+    double *myacc = cbuf + (size_t)M * NS * 64 + lane;     // [2a] fitness, [2a+1] weight of sub-accumulator a (!ACCREG)
+    if (!ACCREG) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) myacc[a * 64] = 0;
-#endif
+        for (int a = 0; a < 8; ++a) myacc[a * 64] = 0;
+    }
 
     // Branch-free over lanes: every lane runs the same straight-line tap code (clamped pixel index / clamped
     // addresses for lanes that have no pixel, a masked pixel or an overflowing tap); only wave-uniform
@@ -447,38 +447,38 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
             const double sadq = sad[q] * invK;
             double weight = wp[q].wStat;
             if (useDiff) weight *= det_exp_poly(-(sadq * sadq) * invDiffW);
-#if PAIS_ACC_REG
-            // the sub-accumulator index is wave-uniform: a scalar branch selects the registers
-#define PAIS_ACC(a)                                          \
-    {                                                        \
-        accW[a] = act ? (accW[a] + weight) : accW[a];        \
+            if (ACCREG) {
+                // the sub-accumulator index is wave-uniform: a scalar branch selects the registers
+#define PAIS_ACC(a)                                           \
+    {                                                         \
+        accW[a] = act ? (accW[a] + weight) : accW[a];         \
         accF[a] = act ? fma(weight, sadq, accF[a]) : accF[a]; \
     }
-            const int ga = __builtin_amdgcn_readfirstlane(gi[q]);
-            if (ga == 0) PAIS_ACC(0) else if (ga == 1) PAIS_ACC(1) else if (ga == 2) PAIS_ACC(2) else PAIS_ACC(3)
+                const int ga = __builtin_amdgcn_readfirstlane(gi[q]);
+                if (ga == 0) PAIS_ACC(0) else if (ga == 1) PAIS_ACC(1) else if (ga == 2) PAIS_ACC(2) else PAIS_ACC(3)
 #undef PAIS_ACC
-#else
-            double *pa = myacc + gi[q] * 128;
-            const double w0 = pa[64], f0 = pa[0];
-            pa[64] = act ? (w0 + weight) : w0;
-            pa[0] = act ? fma(weight, sadq, f0) : f0;
-#endif
+            } else {
+                double *pa = myacc + gi[q] * 128;
+                const double w0 = pa[64], f0 = pa[0];
+                pa[64] = act ? (w0 + weight) : w0;
+                pa[0] = act ? fma(weight, sadq, f0) : f0;
+            }
         }
     }
     // butterflies only for this wave's sub-accumulators (uniform conditions)
-#if PAIS_ACC_REG
+    if (ACCREG) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        if ((a - part) % nparts != 0 || a < part) continue;
-        f4[a] = wave_sum(accF[a]);
-        w4[a] = wave_sum(accW[a]);
+        for (int a = 0; a < 4; ++a) {
+            if ((a - part) % nparts != 0 || a < part) continue;
+            f4[a] = wave_sum(accF[a]);
+            w4[a] = wave_sum(accW[a]);
+        }
+    } else {
+        for (int a = part; a < 4; a += nparts) {
+            f4[a] = wave_sum(myacc[a * 128]);
+            w4[a] = wave_sum(myacc[a * 128 + 64]);
+        }
     }
-#else
-    for (int a = part; a < 4; a += nparts) {
-        f4[a] = wave_sum(myacc[a * 128]);
-        w4[a] = wave_sum(myacc[a * 128 + 64]);
-    }
-#endif
     return 0;
 }
 __device__ __forceinline__ double combine_parts(const double *f4, const double *w4)

@@ -44,7 +44,11 @@ using namespace pais;
 #ifndef PAIS_XCD_SWIZZLE
 #define PAIS_XCD_SWIZZLE 0
 #endif
-#define PAIS_EVAL_BOUNDS(NS) __launch_bounds__(64 * PAIS_WG_WAVES, (NS) == 1 ? 4 : 3)
+//   PAIS_NS1_WAVES   waves per SIMD the register allocator is asked for in the one-pixel-per-lane kernels (many cameras)
+#ifndef PAIS_NS1_WAVES
+#define PAIS_NS1_WAVES 3
+#endif
+#define PAIS_EVAL_BOUNDS(NS) __launch_bounds__(64 * PAIS_WG_WAVES, (NS) == 1 ? PAIS_NS1_WAVES : 3)
 //   PAIS_TWO_PIXELS_MAXK  largest camera count of a batch that still runs two window pixels per lane (NS = 2)
 #ifndef PAIS_TWO_PIXELS_MAXK
 #define PAIS_TWO_PIXELS_MAXK 6

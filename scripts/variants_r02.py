@@ -8,13 +8,8 @@ SRC = os.path.join(ROOT, "pais_mvs_amd", "csrc")
 OUT = os.path.join(SRC, "variants")
 VARS = {
     "base": [],
-    "img1": ["-DPAIS_IMG_MODE=1"],
-    "img2": ["-DPAIS_IMG_MODE=2"],
-    "accreg": ["-DPAIS_ACC_REG=1"],
-    "img1_accreg": ["-DPAIS_IMG_MODE=1", "-DPAIS_ACC_REG=1"],
-    "ns1": ["-DPAIS_TWO_PIXELS_MAXK=0"],
-    "wg4": ["-DPAIS_WG_WAVES=4"],
-    "img1_wg4": ["-DPAIS_IMG_MODE=1", "-DPAIS_WG_WAVES=4"],
+    "ns1w3": ["-DPAIS_NS1_WAVES=3"],
+    "ns1w2": ["-DPAIS_NS1_WAVES=2"],
 }
 FILES = ["pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip"]
 
@@ -38,16 +33,18 @@ def run(names):
     for name in names:
         so = os.path.join(OUT, "libpais_%s.so" % name.replace(",", "_").replace("=", ""))
         env = dict(os.environ, PAIS_LIB_PATH=so)
-        mb = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "microbench_eval.py")], env=env, capture_output=True, text=True)
-        rates = [float(l.split("M evals/s")[0].split()[-1]) for l in mb.stdout.splitlines() if "M evals/s" in l]
-        b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], env=env,
-                           capture_output=True, text=True)
+        rates = []
+        if not os.environ.get("NO_MICROBENCH"):
+            mb = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "microbench_eval.py")], env=env, capture_output=True, text=True)
+            rates = [float(l.split("M evals/s")[0].split()[-1]) for l in mb.stdout.splitlines() if "M evals/s" in l]
+        b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] +
+                           os.environ.get("BENCH_ARGS", "--steps 4 --warmup 2").split(), env=env, capture_output=True, text=True)
         try:
             j = json.loads(b.stdout.strip().splitlines()[-1])
             res[name] = {"Mevals": max(rates) if rates else None, "patches_s": j["value"], "ms_step": j["ms_per_step"],
                          "units": j["config"]["patches_per_step"], "accepted": j["config"]["accepted_patches"]}
         except Exception as e:
-            res[name] = {"Mevals": max(rates) if rates else None, "err": (b.stderr or "")[-400:] + mb.stderr[-300:]}
+            res[name] = {"Mevals": max(rates) if rates else None, "err": (b.stderr or "")[-400:]}
         print(name, res[name], flush=True)
     return res
 
