@@ -57,6 +57,8 @@ struct pais_ctx {
     size_t recCap = 0;
     double *d_hp = nullptr;
     size_t hpBytes = 0;
+    double *d_ratios = nullptr;         // region ratio per (candidate, visible camera) (k_region_ratio)
+    size_t ratioBytes = 0;
     int *d_counters = nullptr;          // [1] "needs another pass" count, [2] active-list length
     pais_candidate *h_cands = nullptr;  // pinned staging of pais_refine_batch
     pais_patch_result *h_recs = nullptr;
@@ -308,6 +310,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evEval); freeEv(ctx->evFree);
     (void)hipFree(ctx->d_psoStates);
     (void)hipFree(ctx->d_win);
+    (void)hipFree(ctx->d_ratios);
     (void)hipFree(ctx->d_nbC); (void)hipFree(ctx->d_nbN);
     for (auto st : ctx->sub) (void)hipStreamDestroy(st);
     for (auto ev : ctx->subDone) (void)hipEventDestroy(ev);
@@ -532,6 +535,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     if (grow(ctx, ctx->d_win, ctx->winCap, pais_launch::win_bytes_per_candidate(sc) * (size_t)n)) return -2;
     const size_t SB = pais_launch::pso_state_bytes_host(Nmax);
     if (grow(ctx, ctx->d_psoStates, ctx->psoStateBytes, SB * (size_t)n)) return -2;
+    if (grow(ctx, ctx->d_ratios, ctx->ratioBytes, sizeof(double) * PAIS_MAX_VIS * (size_t)n)) return -2;
     const size_t EB = pais_launch::eval_block_bytes_host(Kmax), WB = pais_launch::win_bytes_per_candidate(sc);
 
     Timed tb;
@@ -601,7 +605,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         ctx->psoLaunches++;
         Timed ta;
         if (ta.begin(ctx, ctx->stream, &ctx->evAfter)) return -2;
-        HIPCHK(pais_launch::after(sc, d_out, n, ctx->d_hp, afterGrid, ctx->d_counters, ctx->d_stat, Kmax, ctx->stream));
+        HIPCHK(pais_launch::after(sc, d_out, n, ctx->d_hp, afterGrid, ctx->d_counters, ctx->d_stat, Kmax, ctx->d_ratios, ctx->stream));
         if (ta.end()) return -2;
         if (!has_seeds) break;
         HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));

@@ -9,6 +9,8 @@
 #define PAIS_STAGE_DONE  0
 #define PAIS_STAGE_PSO   1  /* psoOptimization() pending (patch.cpp:153)           */
 #define PAIS_STAGE_AFTER 2  /* PSO finished, removeInvisibleCamera etc. pending     */
+#define PAIS_STAGE_AFTER2 3 /* refine() has ended: the caller's removeInvisibleCamera (mvs.cpp:215 / :574) pending */
+#define PAIS_STAGE_AFTER2_KEEP 4 /* ... and the region ratios of the first call are still valid                     */
 
 // HBM layout: one DevCamera per camera in a dense array;
 // every pyramid level of every camera repacked row-major with stride == width
@@ -83,5 +85,5 @@ hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *active
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                     unsigned long long *stat, hipStream_t stream);
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
-                 unsigned long long *stat, int Kmax, hipStream_t stream);
+                 unsigned long long *stat, int Kmax, double *ratios, hipStream_t stream);
 } // namespace pais_launch

@@ -322,14 +322,17 @@ __device__ void set_priority_and_image_point(const DevScene &sc, pais_patch_resu
 }
 
 // Patch::removeInvisibleCamera, patch.cpp:655-721 (with setCorrelationTable :221-267,
-// getHomographyPatch :332-386, getHomographyRegionRatio :269-288).
-//   hp    : global scratch of this workgroup, Kmax*S2 doubles (warped patches)
-//   table : LDS, Kmax*Kmax doubles ; Hn: LDS, Kmax*9 doubles ; tmp: LDS, Kmax + 1 doubles (region ratios + drop flag)
-// Called by a workgroup of TWO waves: wave 0 warps the patches and builds the correlation table while wave 1 fits the
-// ellipses (three serial Jacobi SVDs per camera lane, a third of the function's latency); everything else is done
-// redundantly by both waves with single-writer stores (tid 0).
+// getHomographyPatch :332-386; the region ratios of getHomographyRegionRatio :269-288 come from k_region_ratio).
+//   hp     : global scratch of this workgroup, Kmax*S2 doubles (warped patches)
+//   table  : LDS, Kmax*Kmax doubles ; Hn: LDS, Kmax*9 doubles ; flag: LDS, 1 int (drop)
+//   ratios : global, this candidate's region ratio per visible camera
+// Called by a workgroup of AFTER_WAVES waves: the cameras' warped patches are built by the waves in parallel (one camera
+// per wave at a time), then the camera pairs of the correlation table are dealt to the waves; every value is produced
+// by one wave with the operation sequence of the single-wave statement.  The rest runs redundantly in every wave with
+// single-writer stores (thread 0).
+#define AFTER_WAVES 4
 __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *st, double *hp, double *table,
-                                        double *Hn, double *tmp, int lane, int wave)
+                                        double *Hn, int *flag, double *ratios, int lane, int wave)
 {
     if (st->dropped) return;
     const bool lead = (lane == 0) && (wave == 0);
@@ -342,7 +345,7 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
     double n[3] = {st->normal[0], st->normal[1], st->normal[2]};
 
     // getHomographies(center, normal, H)
-    {
+    if (wave == 0) {
         const double d = -dot3(center, n);
         double Mref[9], invH[9];
         plane_matrix(d, s, rc.KR, rc.KT, n, Mref);
@@ -360,17 +363,16 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
             for (int i = 0; i < 9; ++i) Hn[c * 9 + i] = H[i];
         }
     }
-    for (int i = lane; i < K * K; i += 64) table[i] = 0;
+    for (int i = threadIdx.x; i < K * K; i += 64 * AFTER_WAVES) table[i] = 0;
+    if (threadIdx.x == 0) *flag = 0;
     __syncthreads();
 
     double pt[2];
     cam_project(sc, refCam, center, pt, LOD);
     const double a0 = pt[0] - r, b0 = pt[1] - r;
 
-    // setCorrelationTable: warped, L2-normalised patches (wave 0)
-    bool dropNow = false;
-    if (wave == 0) {
-    for (int c = 0; c < K && !dropNow; ++c) {
+    // setCorrelationTable: warped, L2-normalised patches, camera c by wave c mod AFTER_WAVES
+    for (int c = wave; c < K; c += AFTER_WAVES) {
         const DevCamera &cam = sc.cams[st->cam_idx[c]];
         const uint8_t *img = sc.imgBlob + cam.imgOff[LOD];
         const int cw = cam.w[LOD], ch = cam.h[LOD];
@@ -379,7 +381,7 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
         double sq = 0;
         bool bad = false;
         // no lane-dependent exit inside the walk (an out-of-image sample is flagged and sampled at a clamped position,
-        // its value is never used: the whole patch is dropped), so the loads of the 16 steps overlap
+        // its value is never used: the whole patch is dropped), so the loads of the steps overlap
         for (int k = lane; k < S2; k += 64) {
             const int yi = k / S, xi = k - yi * S;
             const double x = a0 + (double)xi, y = b0 + (double)yi;
@@ -392,44 +394,18 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
             hpc[k] = v;
             sq += v * v;
         }
-        if (__any(bad)) {
-            dropNow = true;
-            break;
+        if (__any(bad)) { // patch.cpp:243-247: any camera that leaves the image drops the patch
+            if (lane == 0) atomicOr(flag, 1);
+            continue;
         }
         sq = wave_sum(sq);
         const double inv = 1.0 / sqrt(sq);
         for (int k = lane; k < S2; k += 64) hpc[k] = hpc[k] * inv; // hp /= sqrt(sum)
     }
-    wave_sync();
-    if (lane == 0) {
-        st->ncc_tables += 1;
-        tmp[K] = dropNow ? 1.0 : 0.0; // the other wave has to take the same exit
-    }
-    if (!dropNow) {
-    for (int i = 0; i < K; ++i) {
-        for (int j = i + 1; j < K; ++j) {
-            const double *a = hp + (size_t)i * S2, *b = hp + (size_t)j * S2;
-            double acc = 0;
-            for (int k = lane; k < S2; k += 64) acc += a[k] * b[k];
-            acc = wave_sum(acc);
-            if (lane == 0) {
-                table[i * K + j] = acc;
-                table[j * K + i] = acc;
-            }
-        }
-    }
-        } // !dropNow
-    } else {
-        // region ratios, one camera per lane (wave 1)
-        for (int c = lane; c < K; c += 64) {
-            double H[9];
-            for (int i = 0; i < 9; ++i) H[i] = Hn[c * 9 + i];
-            tmp[c] = region_ratio(pt[0], pt[1], r, H);
-        }
-    }
-    __syncthreads();
-    if (tmp[K] != 0.0) {
-        // patch.cpp:243-247: drop, correlation = 0 (and every later step is a no-op)
+    __syncthreads(); // the warped patches of all waves are visible (same CU: global stores through the same L1 / L2)
+    if (lead) st->ncc_tables += 1;
+    if (*flag != 0) {
+        // drop, correlation = 0 (and every later step is a no-op)
         __syncthreads();
         if (lead) {
             st->dropped = 1;
@@ -438,6 +414,23 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
         __syncthreads();
         return;
     }
+    {
+        int p = 0;
+        for (int i = 0; i < K; ++i) {
+            for (int j = i + 1; j < K; ++j, ++p) {
+                if (p % AFTER_WAVES != wave) continue; // uniform per wave
+                const double *a = hp + (size_t)i * S2, *b = hp + (size_t)j * S2;
+                double acc = 0;
+                for (int k = lane; k < S2; k += 64) acc += a[k] * b[k];
+                acc = wave_sum(acc);
+                if (lane == 0) {
+                    table[i * K + j] = acc;
+                    table[j * K + i] = acc;
+                }
+            }
+        }
+    }
+    __syncthreads();
 
     double correlation = 0;
     for (int i = 0; i < K; ++i)
@@ -455,29 +448,30 @@ __device__ void remove_invisible_camera(const DevScene &sc, pais_patch_result *s
         }
     }
 
-    // mark + erase, keeping order (removeIdx holds distinct camera indices)
-    int newIdx[PAIS_MAX_VIS];
-    int nn = 0;
-    for (int i = 0; i < K; ++i) {
-        bool rem = false;
-        const int ci = st->cam_idx[i];
-        if (tmp[i] < sc.cfg.minRegionRatio) {
-            rem = true;
-        } else {
-            const DevCamera &cam = sc.cams[ci];
-            double dd = n[0] * (-cam.optN[0]) + n[1] * (-cam.optN[1]) + n[2] * (-cam.optN[2]);
-            if (dd < 0) {
-                rem = true;
-            } else if (i != maxIdx && table[maxIdx * K + i] < sc.cfg.minCorrelation) {
-                rem = true;
-            }
-        }
-        if (!rem) newIdx[nn++] = ci;
-    }
+    // mark + erase, keeping order (removeIdx holds distinct camera indices): compacted in place by one thread
     __syncthreads();
     if (lead) {
+        int nn = 0;
+        for (int i = 0; i < K; ++i) {
+            bool rem = false;
+            const int ci = st->cam_idx[i];
+            if (ratios[i] < sc.cfg.minRegionRatio) {
+                rem = true;
+            } else {
+                const DevCamera &cam = sc.cams[ci];
+                double dd = n[0] * (-cam.optN[0]) + n[1] * (-cam.optN[1]) + n[2] * (-cam.optN[2]);
+                if (dd < 0) {
+                    rem = true;
+                } else if (i != maxIdx && table[maxIdx * K + i] < sc.cfg.minCorrelation) {
+                    rem = true;
+                }
+            }
+            if (!rem) {
+                ratios[nn] = ratios[i]; // stays valid for the trailing removeInvisibleCamera if the homographies do
+                st->cam_idx[nn++] = ci;
+            }
+        }
         st->correlation = correlation;
-        for (int i = 0; i < nn; ++i) st->cam_idx[i] = newIdx[i];
         st->num_cam = nn;
         if (nn < sc.cfg.minCamNum) st->dropped = 1;
     }
@@ -1197,84 +1191,133 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
 }
 
 // ---------------------------------------------------------------- k_after ---
-// After one PSO run: patch.cpp:161-175 (+ the caller's removeInvisibleCamera,
-// mvs.cpp:215 / :574, once the refine loop has ended).
-// Two waves per candidate (see remove_invisible_camera); the setters run redundantly in both, stores by thread 0.
-__global__ __launch_bounds__(128) void k_after(DevScene sc, pais_patch_result *recs, int n, double *hpScratch,
-                                              int *counters, unsigned long long *stat, int Kmax)
+// After one PSO run: patch.cpp:161-175 (+ the caller's removeInvisibleCamera, mvs.cpp:215 / :574, once the refine loop
+// has ended).  Four launches:
+//   k_region_ratio(AFTER)   region ratio of every (candidate, visible camera): ONE LANE each -- three small Jacobi SVDs
+//                           (cv::fitEllipse) are a long serial chain, so they are packed 64 to a wave across candidates
+//                           instead of occupying K lanes of a candidate's wave
+//   k_after<1>              first removeInvisibleCamera, setters, seed-loop control, priority + image points
+//   k_region_ratio(AFTER2)  the same for the state after the setters (other reference camera / LOD / camera set)
+//   k_after<2>              the trailing removeInvisibleCamera
+__global__ __launch_bounds__(64) void k_region_ratio(DevScene sc, const pais_patch_result *recs, int n, int stage, double *ratios, int Kmax)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int c = t / Kmax, k = t - c * Kmax; // Kmax = the batch's largest camera count: (nearly) every lane has a camera
+    if (c >= n) return;
+    const pais_patch_result *P = &recs[c];
+    if (P->stage != stage || P->dropped || k >= P->num_cam) return;
+    const int LOD = P->lod, refCam = P->ref_cam;
+    const DevCamera &rc = sc.cams[refCam];
+    const double s = sc.lodScale[LOD];
+    const double center[3] = {P->center[0], P->center[1], P->center[2]};
+    const double nrm[3] = {P->normal[0], P->normal[1], P->normal[2]};
+    double H[9];
+    const int ci = P->cam_idx[k];
+    if (ci == refCam) {
+        H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0; H[6] = 0; H[7] = 0; H[8] = 1;
+    } else {
+        const double d = -dot3(center, nrm);
+        double Mref[9], invH[9], M[9];
+        plane_matrix(d, s, rc.KR, rc.KT, nrm, Mref);
+        inv3(Mref, invH);
+        plane_matrix(d, s, sc.cams[ci].KR, sc.cams[ci].KT, nrm, M);
+        mul33(M, invH, H);
+    }
+    double pt[2];
+    cam_project(sc, refCam, center, pt, LOD);
+    ratios[(size_t)c * PAIS_MAX_VIS + k] = region_ratio(pt[0], pt[1], sc.cfg.patchRadius, H);
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(64 * AFTER_WAVES) void k_after(DevScene sc, pais_patch_result *recs, int n, double *hpScratch,
+                                                              int *counters, unsigned long long *stat, int Kmax, double *ratios,
+                                                              int hpInLds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     pais_patch_result *st = (pais_patch_result *)smem;
     size_t off = (sizeof(pais_patch_result) + 15) & ~(size_t)15;
     double *table = (double *)(smem + off); off += sizeof(double) * Kmax * Kmax;
     double *Hn = (double *)(smem + off); off += sizeof(double) * 9 * Kmax;
-    double *tmp = (double *)(smem + off);
+    int *flag = (int *)(smem + off); off += 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool lead = threadIdx.x == 0;
     const int S2 = sc.cfg.patchSize * sc.cfg.patchSize;
-    double *hp = hpScratch + (size_t)blockIdx.x * Kmax * S2;
-
+    // the warped patches (Kmax x S2 doubles, written once, read K times): LDS while they fit, else a global scratch slab
+    double *hp = hpInLds ? (double *)(smem + off) : hpScratch + (size_t)blockIdx.x * Kmax * S2;
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
-        if (recs[c].stage != PAIS_STAGE_AFTER) continue;
+        const int stg = recs[c].stage;
+        if (PHASE == 1 ? (stg != PAIS_STAGE_AFTER) : (stg != PAIS_STAGE_AFTER2 && stg != PAIS_STAGE_AFTER2_KEEP)) continue;
         __syncthreads();
-        copy_record(st, &recs[c], threadIdx.x, 128);
+        copy_record(st, &recs[c], threadIdx.x, 64 * AFTER_WAVES);
         __syncthreads();
 
         const int nccBefore = st->ncc_tables;
-        remove_invisible_camera(sc, st, hp, table, Hn, tmp, lane, wave);
-        set_reference_camera(sc, st, lane);
-        set_depth_and_ray(sc, st, lane);
-        set_depth_range(sc, st, lane);
-        set_lod(sc, st, lane);
+        double *rat = ratios + (size_t)c * PAIS_MAX_VIS;
+        if (PHASE == 1) {
+            const int refBefore = st->ref_cam, lodBefore = st->lod;
+            remove_invisible_camera(sc, st, hp, table, Hn, flag, rat, lane, wave);
+            set_reference_camera(sc, st, lane);
+            set_depth_and_ray(sc, st, lane);
+            set_depth_range(sc, st, lane);
+            set_lod(sc, st, lane);
 
-        bool again = false;
-        if (st->type != PAIS_TYPE_EXPAND && !st->dropped) {
-            // patch.cpp:170-171 then the while condition of :140
-            const int afterRef = st->ref_cam, afterNum = st->num_cam;
-            const int cnt = st->count;
-            const bool cond = (st->before_ref != afterRef || st->before_num != afterNum) && (cnt <= st->total_cam_num);
-            __syncthreads();
-            if (lead) {
-                st->after_ref = afterRef;
-                st->after_num = afterNum;
-                st->count = cnt + 1; // count++ is evaluated whenever the first operand is true ... (see note)
-            }
-            __syncthreads();
-            if (cond) {
-                if (st->num_cam < sc.cfg.minCamNum) { // :142-147
-                    __syncthreads();
-                    if (lead) {
-                        st->fitness = DBL_MAX;
-                        st->priority = DBL_MAX;
-                        st->dropped = 1;
+            bool again = false;
+            if (st->type != PAIS_TYPE_EXPAND && !st->dropped) {
+                // patch.cpp:170-171 then the while condition of :140
+                const int afterRef = st->ref_cam, afterNum = st->num_cam;
+                const int cnt = st->count;
+                const bool cond = (st->before_ref != afterRef || st->before_num != afterNum) && (cnt <= st->total_cam_num);
+                __syncthreads();
+                if (lead) {
+                    st->after_ref = afterRef;
+                    st->after_num = afterNum;
+                    st->count = cnt + 1; // count++ is evaluated whenever the first operand is true ... (see note)
+                }
+                __syncthreads();
+                if (cond) {
+                    if (st->num_cam < sc.cfg.minCamNum) { // :142-147
+                        __syncthreads();
+                        if (lead) {
+                            st->fitness = DBL_MAX;
+                            st->priority = DBL_MAX;
+                            st->dropped = 1;
+                        }
+                        __syncthreads();
+                    } else {
+                        again = true;
+                        __syncthreads();
+                        if (lead) {
+                            st->before_ref = st->ref_cam;
+                            st->before_num = st->num_cam;
+                            st->stage = PAIS_STAGE_PSO;
+                        }
+                        __syncthreads();
                     }
-                    __syncthreads();
-                } else {
-                    again = true;
-                    __syncthreads();
-                    if (lead) {
-                        st->before_ref = st->ref_cam;
-                        st->before_num = st->num_cam;
-                        st->stage = PAIS_STAGE_PSO;
-                    }
-                    __syncthreads();
                 }
             }
-        }
-        if (!again) {
-            set_priority_and_image_point(sc, st, lane);
-            remove_invisible_camera(sc, st, hp, table, Hn, tmp, lane, wave); // mvs.cpp:215 / :574
+            if (!again) {
+                set_priority_and_image_point(sc, st, lane);
+                __syncthreads();
+                // mvs.cpp:215 / :574 follows.  Centre and normal are those of the first call; with the same reference camera
+                // and LOD the homographies -- and so the region ratios of the cameras that stayed -- are too
+                if (lead)
+                    st->stage = st->dropped ? PAIS_STAGE_DONE
+                                            : ((st->ref_cam == refBefore && st->lod == lodBefore) ? PAIS_STAGE_AFTER2_KEEP : PAIS_STAGE_AFTER2);
+            }
+            __syncthreads();
+            if (lead && again) atomicAdd(&counters[1], 1);
+        } else {
+            remove_invisible_camera(sc, st, hp, table, Hn, flag, rat, lane, wave); // mvs.cpp:215 / :574
             __syncthreads();
             if (lead) st->stage = PAIS_STAGE_DONE;
         }
         __syncthreads();
         if (lead) {
-            if (again) atomicAdd(&counters[1], 1);
             atomicAdd(&stat[3], (unsigned long long)(st->ncc_tables - nccBefore));
             atomicAdd(&stat[4], (unsigned long long)(st->ncc_tables - nccBefore) * (unsigned long long)st->total_cam_num);
         }
         __syncthreads();
-        copy_record(&recs[c], st, threadIdx.x, 128);
+        copy_record(&recs[c], st, threadIdx.x, 64 * AFTER_WAVES);
     }
 }
 
@@ -1395,7 +1438,7 @@ static size_t after_lds_bytes(int Kmax)
     size_t off = (sizeof(pais_patch_result) + 15) & ~(size_t)15;
     off += sizeof(double) * Kmax * Kmax;
     off += sizeof(double) * 9 * Kmax;
-    off += sizeof(double) * (Kmax + 1); // region ratios + the drop flag of remove_invisible_camera
+    off += 16; // the drop flag of remove_invisible_camera
     return off;
 }
 // two window pixels per lane only while the LDS scratch leaves >= 3 waves per SIMD (M = K - 1 cameras are tapped)
@@ -1534,14 +1577,23 @@ hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *
 }
 
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
-                 unsigned long long *stat, int Kmax, hipStream_t stream)
+                 unsigned long long *stat, int Kmax, double *ratios, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    static LdsAttr attr;
+    static LdsAttr attr1, attr2;
     size_t lds = after_lds_bytes(Kmax);
-    hipError_t e = attr.ensure((const void *)k_after, lds);
+    const size_t hpBytes = sizeof(double) * (size_t)Kmax * sc.cfg.patchSize * sc.cfg.patchSize;
+    const int hpInLds = hpBytes <= 60 * 1024 ? 1 : 0; // <= 2 workgroups per CU otherwise
+    if (hpInLds) lds += hpBytes;
+    hipError_t e = attr1.ensure((const void *)k_after<1>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_after, dim3(grid), dim3(128), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax);
+    e = attr2.ensure((const void *)k_after<2>, lds);
+    if (e != hipSuccess) return e;
+    const int rgrid = (int)(((long)n * Kmax + 63) / 64);
+    hipLaunchKernelGGL(k_region_ratio, dim3(rgrid), dim3(64), 0, stream, sc, recs, n, PAIS_STAGE_AFTER, ratios, Kmax);
+    hipLaunchKernelGGL((k_after<1>), dim3(grid), dim3(64 * AFTER_WAVES), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax, ratios, hpInLds);
+    hipLaunchKernelGGL(k_region_ratio, dim3(rgrid), dim3(64), 0, stream, sc, recs, n, PAIS_STAGE_AFTER2, ratios, Kmax);
+    hipLaunchKernelGGL((k_after<2>), dim3(grid), dim3(64 * AFTER_WAVES), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax, ratios, hpInLds);
     return hipGetLastError();
 }
 
