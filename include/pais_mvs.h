@@ -91,12 +91,13 @@ int  pais_mvs_set_thin_front(pais_mvs *m, int thin_front);
  * candidates into `world` contiguous, count-balanced shards; a rank refines its shard (pais_refine_batch_device,
  * records stay in HBM) and the fixed-size pais_patch_result records are exchanged with ONE all-gather per batch --
  * ncclAllGather (RCCL over xGMI) on the context's stream -- after which every rank replays the identical
- * host bookkeeping.  Batches with fewer than PAIS_REPLICATE_BELOW_PER_RANK candidates per rank are latency bound
- * on one GPU already: every rank refines all of them itself (the refinement is deterministic, so the replicas agree
- * bit for bit) and no collective is issued.  The cloud is identical for every world size.
+ * host bookkeeping.  Batches of fewer than PAIS_REPLICATE_BELOW_WAVES evaluation waves per PSO iteration (candidates x
+ * particles) are latency bound on one GPU already -- their launches take one wave's latency however many GPUs share
+ * them -- so every rank refines all of them itself (the refinement is deterministic: the replicas agree bit for bit) and
+ * no collective is issued.  The cloud is identical for every world size.
  * This is what shards MVS::expansionPatches (mvs.cpp:233-275) and MVS::refineSeedPatches (:196-231). */
 #define PAIS_UNIQUE_ID_BYTES 128          /* == NCCL_UNIQUE_ID_BYTES */
-#define PAIS_REPLICATE_BELOW_PER_RANK 64
+#define PAIS_REPLICATE_BELOW_WAVES 1024   /* 68 expansion candidates / 34 seeds at particleNum 15 */
 typedef struct pais_unique_id { char bytes[PAIS_UNIQUE_ID_BYTES]; } pais_unique_id;
 /* ncclGetUniqueId: call on ONE rank, hand the 128 bytes to the others (MPI_Bcast, a file, a TCP store ...) */
 int  pais_comm_get_unique_id(pais_unique_id *out);
@@ -110,9 +111,9 @@ int  pais_mvs_create_ranked(const pais_config *cfg, int num_cams, const pais_cam
  * pointers; returns 0 on success.  The driver stages the records through pinned host memory around the call. */
 typedef int (*pais_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
 int  pais_mvs_comm_init_callback(pais_mvs *m, int rank, int world, pais_allgather_fn fn, void *user);
-/* Candidates per rank below which a multi-rank batch is replicated instead of sharded (default
- * PAIS_REPLICATE_BELOW_PER_RANK; 0 = always shard).  Must be the same on every rank. */
-int  pais_mvs_set_replicate_below(pais_mvs *m, int per_rank);
+/* Evaluation waves per iteration below which a multi-rank batch is replicated instead of sharded (default
+ * PAIS_REPLICATE_BELOW_WAVES; 0 = always shard).  Must be the same on every rank. */
+int  pais_mvs_set_replicate_below(pais_mvs *m, int waves);
 /* A driver created with device < 0 owns no GPU and never computes a record.  This callback lets the owner of the
  * records (a process that has the GPU, a test's checker) feed the monolithic entry points above -- the stepwise
  * entry points below folded into a callback; n candidates in, n records out, host pointers. */

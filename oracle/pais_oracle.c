@@ -703,6 +703,27 @@ static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const
     const int hasRef = firstRef >= 0;
     const double invK = 1.0 / (double)K, invDiffW = 1.0 / s->cfg.diffWeighting;
     const double a0 = pt[0] - r, b0 = pt[1] - r;
+    /* corners_inside (pais_eval.hpp): if every other camera maps the four window corners into [2, w-3) x [2, h-3) with a
+     * denominator of one sign, no tap of the (convex) window can leave the image: the per-tap test of :999 is skipped
+     * for this evaluation; otherwise it is applied tap by tap as the reference does */
+    int fast = 1;
+    for (int i = 0; i < M && fast; ++i) {
+        const double *Hi = H + 9 * other[i];
+        const po_camera *cam = &s->cams[patch->camIdx[other[i]]];
+        int npos = 0, nneg = 0;
+        for (int corner = 0; corner < 4; ++corner) {
+            const double x = a0 + (double)((corner & 1) ? (S - 1) : 0), y = b0 + (double)((corner & 2) ? (S - 1) : 0);
+            const double w = fma(Hi[7], y, fma(Hi[6], x, Hi[8]));
+            const double rw = 1.0 / w;
+            const double ix = fma(Hi[1], y, fma(Hi[0], x, Hi[2])) * rw, iy = fma(Hi[4], y, fma(Hi[3], x, Hi[5])) * rw;
+            /* (int) of a NaN / out-of-range double is 0 / saturated on the GPU: rejected either way */
+            const int okx = ix >= 2 && ix < (double)(cam->width[LOD] - 3), oky = iy >= 2 && iy < (double)(cam->height[LOD] - 3);
+            if (!(okx && oky)) fast = 0;
+            npos += w > 0.0;
+            nneg += w < 0.0;
+        }
+        if (!(npos == 4 || nneg == 4)) fast = 0;
+    }
     double pf[4][64] = {{0}}, pw[4][64] = {{0}};
     double c[PO_MAX_VIS];
     for (int k = 0; k < S * S; ++k) {
@@ -743,7 +764,7 @@ static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const
                 const po_camera *cam = &s->cams[patch->camIdx[other[i0 + u]]];
                 const int cols = cam->width[LOD], rows = cam->height[LOD];
                 const double jx = nx[u] * rw[u], jy = ny[u] * rw[u];
-                if (!(jx >= 2 && jx < cols - 3 && jy >= 2 && jy < rows - 3)) return DBL_MAX; /* :999 -- whole call */
+                if (!fast && !(jx >= 2 && jx < cols - 3 && jy >= 2 && jy < rows - 3)) return DBL_MAX; /* :999 -- whole call */
                 const int qx = (int)jx, qy = (int)jy;
                 c[i0 + u] = lerp3_u8(cam->img[LOD], cols, qx, qy, jx - (double)qx, jy - (double)qy);
                 sum += c[i0 + u];

@@ -229,7 +229,9 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
 // G consecutive cameras of NS window pixels of this lane: homography (fma), ONE reciprocal per (group, pixel),
 // bounds test, two 8-byte row loads and three fma lerps per tap.  No lane-dependent branches; the loads of the
 // G x NS taps are independent so they overlap.
-template <int G, int NS>
+// CHECK = false: the evaluation has established that no tap of the window can leave the image (corners_inside below):
+// no clamping, no flags.
+template <int G, int NS, bool CHECK>
 __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
                                           int c0, double *x, double *y, uint32_t *badBits, double *sum)
 {
@@ -290,8 +292,12 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
             // w == 0 needs no test of its own: the reciprocal is inf / NaN).  The clamped q addresses the tap,
             // q != clamp(q) flags the overflow.  frac(ix) == ix - (double)q exactly for an accepted ix.
             const int qx = (int)ix, qy = (int)iy;
-            const int px = clamp_i32(qx, 2, qxmax), py = clamp_i32(qy, 2, qymax);
-            badBits[q] = badBits[q] | (uint32_t)(px ^ qx) | (uint32_t)(py ^ qy);
+            int px = qx, py = qy;
+            if (CHECK) {
+                px = clamp_i32(qx, 2, qxmax);
+                py = clamp_i32(qy, 2, qymax);
+                badBits[q] = badBits[q] | (uint32_t)(px ^ qx) | (uint32_t)(py ^ qy);
+            }
             bx[q][u] = __builtin_amdgcn_fract(ix);
             by[q][u] = __builtin_amdgcn_fract(iy);
             off[q][u] = (__umul24((uint32_t)py, cw) + (uint32_t)px) * (uint32_t)sizeof(PaisImgT); // byte offset in the level (w < 2^24)
@@ -336,6 +342,40 @@ __host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax)
 // computes all four (nparts = 1), or `nparts` (2 / 4) waves compute the sub-accumulators a with
 // a mod nparts == part and whoever consumes the fitness adds them -- the same bits either way.
 // Returns 0 and fills f4/w4 (zeros for the sub-accumulators of other parts), or 1 if the call is DBL_MAX.
+template <int NS, bool CHECK>
+__device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
+                           const WinPix *win, int lane, int part, int nparts, double *f4, double *w4);
+
+// The taps of a window are the images of its pixels under maps (h0 x + h1 y + h2) / (h6 x + h7 y + h8): where the
+// denominator keeps one sign over the window -- it is affine, so: at the four corners -- the image of the (convex) window
+// is convex and lies inside the bounding box of the four corner images.  If every camera maps all four corners into
+// [2, w-3) x [2, h-3) no tap can leave it, the whole-call DBL_MAX of patch.cpp:999-1002 cannot trigger and the per-tap
+// clamp / flag logic (5 of 39 instructions per tap) is dropped for this evaluation.  Otherwise (a particle that grazes an
+// image border, or a degenerate plane) the evaluation runs the checked loop: the reference's rule tap by tap.
+// One (corner, camera) pair per lane; the corner taps use a plain quotient n * (1 / w).
+__device__ __forceinline__ bool corners_inside(const EvalPatch *ep, const EvalCam *cams, const double *Hbuf, int S, int lane)
+{
+    const int M = ep->M;
+    bool ok = true;
+    for (int t0 = 0; t0 < 4 * M; t0 += 64) {
+        const int t = t0 + lane;
+        const int c = (t < 4 * M) ? (t >> 2) : 0, corner = t & 3;
+        const double x = ep->a0 + (double)((corner & 1) ? (S - 1) : 0), y = ep->b0 + (double)((corner & 2) ? (S - 1) : 0);
+        const double *H = Hbuf + 9 * c;
+        const double w = fma(H[7], y, fma(H[6], x, H[8]));
+        const double rw = rcp_cr(w);
+        const double ix = fma(H[1], y, fma(H[0], x, H[2])) * rw, iy = fma(H[4], y, fma(H[3], x, H[5])) * rw;
+        const int qx = (int)ix, qy = (int)iy;
+        bool in = qx >= 2 && qx <= cams[c].qxmax && qy >= 2 && qy <= cams[c].qymax;
+        // one sign of w over the four corners of a camera: lanes 4c .. 4c+3
+        const unsigned long long neg = __ballot(w < 0.0), pos = __ballot(w > 0.0);
+        const unsigned long long grp = 0xFull << (lane & ~3);
+        in = in && (((neg & grp) == 0) || ((pos & grp) == 0)) && (((neg | pos) & grp) == grp);
+        ok = ok && (in || t >= 4 * M);
+    }
+    return __all(ok);
+}
+
 template <int NS>
 __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                                   const WinPix *win, double theta, double phi, double depth, int lane, int part, int nparts,
@@ -377,7 +417,19 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
         }
     }
     wave_sync();
+#if PAIS_CORNER_FASTPATH
+    if (corners_inside(ep, cams, Hbuf, sc.cfg.patchSize, lane))
+        return eval_window<NS, false>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
+#endif
+    return eval_window<NS, true>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
+}
 
+// the window walk of one evaluation (homographies in Hbuf); CHECK: see corners_inside
+template <int NS, bool CHECK>
+__device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
+                           const WinPix *win, int lane, int part, int nparts, double *f4, double *w4)
+{
+    const int M = ep->M, K = ep->K;
     const int S = sc.cfg.patchSize, S2 = S * S;
     const double a0 = ep->a0, b0 = ep->b0;
     const double invDiffW = 1.0 / sc.cfg.diffWeighting;
@@ -425,9 +477,9 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
 #pragma unroll
         for (int q = 0; q < NS; ++q) sum[q] = hasRef ? wp[q].refCol : 0.0;
         int c0 = 0;
-        for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
-        if (M - c0 == 3) tap_group<3, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
-        else if (M - c0 == 1) tap_group<1, NS>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // a single camera
+        for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS, CHECK>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
+        if (M - c0 == 3) tap_group<3, NS, CHECK>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
+        else if (M - c0 == 1) tap_group<1, NS, CHECK>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // a single camera
         // mean and mean absolute deviation of the K colours: one pass over the cameras serves the lane's NS pixels
         double mean[NS], sad[NS];
 #pragma unroll
@@ -443,7 +495,7 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
         for (int q = 0; q < NS; ++q) {
             if (64 * (st + q * nparts) >= S2) break; // uniform: the window has no such step
             const bool act = wp[q].wStat >= 0.0;
-            if (__any(act && badBits[q] != 0)) return 1; // :1001 -- whole call
+            if (CHECK && __any(act && badBits[q] != 0)) return 1; // :1001 -- whole call
             const double sadq = sad[q] * invK;
             double weight = wp[q].wStat;
             if (useDiff) weight *= det_exp_poly(-(sadq * sadq) * invDiffW);

@@ -39,7 +39,7 @@ struct DevCamera {
 //   3  the byte blob itself            -- a tap row = one 2-byte load + two byte->float conversions; a quarter of the
 //                                         float copy's cache footprint
 #ifndef PAIS_IMG_MODE
-#define PAIS_IMG_MODE 0
+#define PAIS_IMG_MODE 1
 #endif
 #if PAIS_IMG_MODE == 0
 typedef float PaisImgT;

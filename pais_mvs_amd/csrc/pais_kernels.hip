@@ -34,6 +34,10 @@ using namespace pais;
 #ifndef PAIS_ACC_REG
 #define PAIS_ACC_REG 0
 #endif
+//   PAIS_CORNER_FASTPATH  1: evaluations whose window corners map inside every image skip the per-tap bounds logic
+#ifndef PAIS_CORNER_FASTPATH
+#define PAIS_CORNER_FASTPATH 1
+#endif
 //   PAIS_WG_WAVES    waves (= consecutive evaluation tasks: particles of one candidate) per workgroup of the evaluation
 //                    kernels: the waves of a workgroup run on one CU and share its L1 -- the taps of a candidate's particles
 //                    fall into the same few image windows.  LDS scratch stays private to each wave: no barriers.

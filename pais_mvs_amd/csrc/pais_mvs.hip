@@ -133,7 +133,7 @@ struct pais_mvs {
     rccl::Comm nccl = nullptr;
     pais_allgather_fn gatherCb = nullptr;
     void *gatherUser = nullptr;
-    int replicateBelow = PAIS_REPLICATE_BELOW_PER_RANK;
+    int replicateBelow = PAIS_REPLICATE_BELOW_WAVES;
     pais_record_source_fn recordSource = nullptr;
     void *recordUser = nullptr;
     pais_candidate *d_shardC = nullptr, *h_shardC = nullptr;       // this rank's shard of a batch (device / pinned)
@@ -705,7 +705,11 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
     if (n <= 0) return 0;
     const int world = m->world;
     if (world <= 1 && !m->nccl && !m->gatherCb) return refine_local(m, n, c, out, has_seeds);
-    if ((long)n < (long)m->replicateBelow * world) { // thin batch: replicated, no collective
+    // a batch of fewer than replicateBelow evaluation waves per PSO iteration (candidates x particles; seeds run twice the
+    // particles) is latency bound on ONE GPU: its per-iteration launches take one evaluation wave's latency whatever the
+    // number of GPUs, so splitting it buys nothing and the exchange costs -- replicated, no collective
+    const long wavesPerIter = (long)n * m->cfg.particleNum * (has_seeds ? 2 : 1);
+    if (wavesPerIter < (long)m->replicateBelow) {
         m->st.batches_replicated++;
         return refine_local(m, n, c, out, has_seeds);
     }
@@ -827,10 +831,10 @@ extern "C" int pais_mvs_comm_init_callback(pais_mvs *m, int rank, int world, pai
     return 0;
 }
 
-extern "C" int pais_mvs_set_replicate_below(pais_mvs *m, int per_rank)
+extern "C" int pais_mvs_set_replicate_below(pais_mvs *m, int waves)
 {
-    if (!m || per_rank < 0) return mfail("pais_mvs_set_replicate_below: bad argument");
-    m->replicateBelow = per_rank;
+    if (!m || waves < 0) return mfail("pais_mvs_set_replicate_below: bad argument");
+    m->replicateBelow = waves;
     return 0;
 }
 

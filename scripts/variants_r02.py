@@ -8,8 +8,8 @@ SRC = os.path.join(ROOT, "pais_mvs_amd", "csrc")
 OUT = os.path.join(SRC, "variants")
 VARS = {
     "base": [],
-    "ns1w3": ["-DPAIS_NS1_WAVES=3"],
-    "ns1w2": ["-DPAIS_NS1_WAVES=2"],
+    "nofast": ["-DPAIS_CORNER_FASTPATH=0"],
+    "img1": ["-DPAIS_IMG_MODE=1"],
 }
 FILES = ["pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip"]
 

@@ -70,11 +70,11 @@ def _run(world, replicate_below):
 
 
 def test_two_rank_sharded_reconstruction_is_rank_count_invariant():
-    ref = _run(1, 64)[0]
+    ref = _run(1, 1024)[0]
     assert ref[2][0] > 24 and ref[4] == 0 and ref[5] == 0         # one rank: nothing sharded, nothing replicated
-    # replicate_below = 6 candidates per rank: rounds of >= 12 candidates are sharded, thinner ones replicated --
-    # both kinds of batch must occur so that both code paths run
-    two = _run(2, 6)
+    # replicate_below = 72 evaluation waves (6 particles: 12 expansion candidates): thinner batches are replicated, the
+    # others sharded -- both kinds of batch must occur so that both code paths run
+    two = _run(2, 72)
     for rank, blob, shape, eff, sharded, replicated, cands in two:
         assert shape == ref[2] and blob == ref[1] and eff == ref[3], rank
         assert sharded > 0 and replicated > 0, (sharded, replicated)

@@ -388,8 +388,8 @@ def test_multi_rank_paths_under_the_c_abi_on_one_gpu(tmp_path):
     assert int(direct[3]) > 24
     rccl1 = _run_dist(tmp_path, "rccl", 1, replicate=0, port=29542)[0]
     assert rccl1[2] == direct[2] and int(rccl1[4]) > 0 and int(rccl1[5]) == 0, (direct, rccl1)
-    for rep in (0, 40):
-        two = _run_dist(tmp_path, "host", 2, replicate=rep, port=29543 + rep)
+    for rep in (0, 600):          # evaluation waves per iteration: 600 = 40 expansion candidates at 15 particles
+        two = _run_dist(tmp_path, "host", 2, replicate=rep, port=29543 + (1 if rep else 0))
         for o in two:
             assert o[2] == direct[2], (rep, direct, o)
             assert int(o[4]) > 0 and (rep == 0 or int(o[5]) > 0), o
