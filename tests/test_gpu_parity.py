@@ -347,8 +347,12 @@ from pais_mvs_amd import synth, distributed as D
 from pais_mvs_amd.config import readme_config
 from pais_mvs_amd.mvs import MVS
 job = D.job_from_env(force_group=True)
-scene = synth.pawn_scene(width=320, height=240, n_seeds=24)
-cfg = readme_config()
+if os.environ.get("PAIS_TEST_SCENE") == "ring":     # BASELINE configs[3] in small: ring of cameras, all adaptive weights
+    scene = synth.ring_scene(n_cams=24, width=480, height=360, focal=450.0, radius=3.0, n_seeds=30)
+    cfg = readme_config(adaptiveGradientEnable=True, particleNum=8, maxIteration=12)
+else:
+    scene = synth.pawn_scene(width=320, height=240, n_seeds=24)
+    cfg = readme_config()
 m = MVS(cfg, scene.cameras, device=0, seed=42)
 mode = os.environ["PAIS_TEST_MODE"]
 if mode != "direct":
@@ -362,14 +366,14 @@ m.close(); job.close()
 """
 
 
-def _run_dist(tmp_path, mode, world, replicate=0, port=29541):
+def _run_dist(tmp_path, mode, world, replicate=0, port=29541, scene="pawn"):
     import subprocess, sys, os
     script = tmp_path / "dist_job.py"
     script.write_text(_DIST_SCRIPT % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PAIS_TEST_MODE=mode, PAIS_TEST_REPLICATE=str(replicate), PAIS_NO_BUILD="1")
+                   PAIS_TEST_MODE=mode, PAIS_TEST_REPLICATE=str(replicate), PAIS_NO_BUILD="1", PAIS_TEST_SCENE=scene)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -393,6 +397,16 @@ def test_multi_rank_paths_under_the_c_abi_on_one_gpu(tmp_path):
         for o in two:
             assert o[2] == direct[2], (rep, direct, o)
             assert int(o[4]) > 0 and (rep == 0 or int(o[5]) > 0), o
+
+
+def test_ring_sharded_over_two_ranks_equals_one_rank(tmp_path):
+    """BASELINE configs[3] (ring of cameras, candidates of a round sharded over the ranks, one all-gather per round) at
+    test size: 24 cameras 480x360, K = 7..11, all adaptive weights; two ranks share the one GPU of the box through the
+    host transport and every batch is sharded.  The cloud must be the single-process cloud byte for byte."""
+    direct = _run_dist(tmp_path, "direct", 1, port=29551, scene="ring")[0]
+    assert int(direct[3]) > 30
+    for o in _run_dist(tmp_path, "host", 2, replicate=0, port=29552, scene="ring"):
+        assert o[2] == direct[2] and int(o[4]) > 0 and int(o[5]) == 0, (direct, o)
 
 
 def test_bench_refuses_a_rank_count_it_cannot_run():
