@@ -264,7 +264,7 @@ def main():
         traffic = None
         tnote = "no PMC summary found under profiles/"
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same command
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             traffic = pj["eval_hbm_read_bytes_per_launch"]
             tnote = pj.get("note", "")
         except Exception:
