@@ -26,12 +26,15 @@
 struct EvalCam {        // one visible camera other than (the first occurrence of) the reference camera
     double KR[9];
     double KT[3];
+    // what a tap reads, one aligned 16-byte LDS read (ds_read_b128: wave-uniform operands cost LDS cycles, not VALU)
     uint64_t imgOff;    // into DevScene::imgBlob / imgF at the patch's LOD
-    int w, h;
-    int cam;
-    int qxmax, qymax;   // w - 4, h - 4: largest truncated tap coordinate that passes patch.cpp:999
-    int pad;
+    int w;
+    uint32_t qpack;     // (w - 4) | (h - 4) << 16: largest truncated tap coordinates that pass patch.cpp:999
+    int h, cam, pad0, pad1;
 };
+struct TapInfo { uint64_t imgOff; int w; uint32_t qpack; };
+static_assert(sizeof(EvalCam) == 128 && offsetof(EvalCam, imgOff) == 96, "EvalCam layout");
+#define PAIS_H_STRIDE 10 // doubles per homography in LDS: 9 + 1 padding, so that rows are 16-byte aligned (ds_read_b128)
 struct EvalPatch {
     double ray[3], Cref[3], optNref[3], KRref[9], KTref[3];
     double lodScale;
@@ -41,7 +44,9 @@ struct EvalPatch {
     int hasRef;         // the reference camera is among the visible ones (always, for patches refine() builds)
     int valid;          // the window lies inside [2, dim-3) of the reference level (patch.cpp:952-962)
     int LOD, refCam;
+    int pad16[2];       // sizeof % 16 == 0: EvalCam[] and the homographies behind it stay 16-byte aligned
 };
+static_assert(sizeof(EvalPatch) % 16 == 0, "EvalPatch layout");
 struct WinPix {
     double refCol;      // bilinear sample of the reference level at (x, y)
     double wStat;       // [dist] G(x, y) * [grad] exp(-1 / (edge * gradientWeighting)); -1: masked pixel / padding
@@ -160,9 +165,8 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
         e.w = dc.w[LOD];
         e.h = dc.h[LOD];
         e.cam = myCam;
-        e.qxmax = dc.w[LOD] - 4;
-        e.qymax = dc.h[LOD] - 4;
-        e.pad = 0;
+        e.qpack = (uint32_t)((dc.w[LOD] - 4) & 0xffff) | ((uint32_t)((dc.h[LOD] - 4) & 0xffff) << 16); // levels are < 65540 wide
+        e.pad0 = e.pad1 = 0;
     }
     const double s = sc.lodScale[LOD];
     const int refW = rc.w[LOD], refH = rc.h[LOD];
@@ -245,8 +249,10 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
     uint32_t off[NS][G], cwv[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        const double *H = Hbuf + 9 * (c0 + u);
-        const double h0 = H[0], h1 = H[1], h2 = H[2], h3 = H[3], h4 = H[4], h5 = H[5], h6 = H[6], h7 = H[7], h8 = H[8];
+        // five 16-byte LDS reads per homography (half the LDS cycles of nine 8-byte ones)
+        const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
+        const double2 ha = H2[0], hb = H2[1], hc = H2[2], hd = H2[3], he = H2[4];
+        const double h0 = ha.x, h1 = ha.y, h2 = hb.x, h3 = hb.y, h4 = hc.x, h5 = hc.y, h6 = hd.x, h7 = hd.y, h8 = he.x;
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             w[q][u] = fma(h7, y[q], fma(h6, x[q], h8));
@@ -276,10 +282,12 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         const int c = c0 + u;
-        const int qxmax = cams[c].qxmax, qymax = cams[c].qymax;
-        const uint32_t cw = (uint32_t)cams[c].w;
+        TapInfo ti;
+        __builtin_memcpy(&ti, __builtin_assume_aligned(&cams[c].imgOff, 16), sizeof(ti));
+        const int qxmax = (int)(ti.qpack & 0xffffu), qymax = (int)(ti.qpack >> 16);
+        const uint32_t cw = (uint32_t)ti.w;
         {   // wave-uniform: keep the base in SGPRs so that the taps are global_load ... v_off, s[base] (no 64-bit VALU address math)
-            const uint64_t io = cams[c].imgOff;
+            const uint64_t io = ti.imgOff;
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)io), hi = __builtin_amdgcn_readfirstlane((uint32_t)(io >> 32));
             base[u] = sc.imgF + (((uint64_t)hi << 32) | lo);
         }
@@ -322,7 +330,7 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 }
 
 // LDS scratch of one evaluating wave
-//   Hbuf : M*9 doubles            (homographies, patch.cpp:290-330)
+//   Hbuf : M*PAIS_H_STRIDE doubles (homographies, patch.cpp:290-330)
 //   cbuf : (NS*M + 8)*64 doubles  (per-camera colour of the lane's NS pixels; last 8 rows: the lane's 4 x (fitness,
 //          weight) sub-accumulators)
 // The lane's four (fitness, weight) sub-accumulators: LDS rows for the two-pixel kernels (few cameras: registers are the
@@ -331,10 +339,14 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 #define PAIS_ACC_IN_REGS(NS) (PAIS_ACC_REG || (NS) == 1)
 #define PAIS_CBUF_ROWS(NS, M) ((NS) * (M) + (PAIS_ACC_IN_REGS(NS) ? 0 : 8))
 __host__ __device__ inline size_t eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
-__host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax)
+// colg: the colour rows live in a global scratch slab instead (many cameras: 512 B per camera per wave would leave a
+// single wave per SIMD at 40 cameras; the slab is written and read back by the same lane within microseconds -- L2)
+__host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax, bool colg = false)
 {
-    return eval_block_bytes(Kmax) + sizeof(double) * 9 * (size_t)Kmax + sizeof(double) * 64 * (size_t)PAIS_CBUF_ROWS(NS, Kmax);
+    return eval_block_bytes(Kmax) + sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax + (colg ? 0 : sizeof(double) * 64 * (size_t)PAIS_CBUF_ROWS(NS, Kmax));
 }
+// colour rows of one wave in the global slab (one-pixel kernels only: accumulators are in registers there)
+__host__ __device__ inline size_t eval_colg_doubles(int Kmax) { return (size_t)64 * Kmax; }
 
 // Reduction shape (canonical, independent of how many waves share one evaluation): the 64-pixel steps of the
 // window are dealt round-robin to FOUR sub-accumulators (step mod 4); each is summed per lane over its steps,
@@ -361,12 +373,13 @@ __device__ __forceinline__ bool corners_inside(const EvalPatch *ep, const EvalCa
         const int t = t0 + lane;
         const int c = (t < 4 * M) ? (t >> 2) : 0, corner = t & 3;
         const double x = ep->a0 + (double)((corner & 1) ? (S - 1) : 0), y = ep->b0 + (double)((corner & 2) ? (S - 1) : 0);
-        const double *H = Hbuf + 9 * c;
+        const double *H = Hbuf + PAIS_H_STRIDE * c;
         const double w = fma(H[7], y, fma(H[6], x, H[8]));
         const double rw = rcp_cr(w);
         const double ix = fma(H[1], y, fma(H[0], x, H[2])) * rw, iy = fma(H[4], y, fma(H[3], x, H[5])) * rw;
         const int qx = (int)ix, qy = (int)iy;
-        bool in = qx >= 2 && qx <= cams[c].qxmax && qy >= 2 && qy <= cams[c].qymax;
+        const uint32_t qp = cams[c].qpack;
+        bool in = qx >= 2 && qx <= (int)(qp & 0xffffu) && qy >= 2 && qy <= (int)(qp >> 16);
         // one sign of w over the four corners of a camera: lanes 4c .. 4c+3
         const unsigned long long neg = __ballot(w < 0.0), pos = __ballot(w > 0.0);
         const unsigned long long grp = 0xFull << (lane & ~3);
@@ -413,7 +426,7 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
                 plane_matrix(d, s, kr, kt, n, Mc);
                 mul33(Mc, invH, H);
             }
-            for (int i = 0; i < 9; ++i) Hbuf[c * 9 + i] = H[i];
+            for (int i = 0; i < 9; ++i) Hbuf[c * PAIS_H_STRIDE + i] = H[i];
         }
     }
     wave_sync();

@@ -68,8 +68,10 @@ namespace pais_launch {
 // evaluation block of a PSO run (pais_eval.hpp): EvalPatch + EvalCam[Kmax] bytes per candidate, and the reference window
 size_t eval_block_bytes_host(int Kmax);
 size_t win_bytes_per_candidate(const DevScene &sc);
+// batches of many cameras keep the colour rows of the evaluation in a global slab of colour_slab_bytes(Kmax) bytes
+size_t colour_slab_bytes(int Kmax);
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
-                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream);
+                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, double *colScratch, hipStream_t stream);
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream);
 hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream);
 hipError_t expand_image(const uint8_t *img, PaisImgT *out, size_t n, hipStream_t stream);
@@ -78,10 +80,10 @@ size_t pso_state_bytes_host(int Nmax);
 hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
                     int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    hipStream_t stream);
+                    double *colScratch, hipStream_t stream);
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                    int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream);
+                    int nparts, const unsigned char *evalBlocks, const void *win, double *colScratch, hipStream_t stream);
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                     unsigned long long *stat, hipStream_t stream);
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,

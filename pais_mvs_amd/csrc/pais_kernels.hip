@@ -52,7 +52,10 @@ using namespace pais;
 #ifndef PAIS_NS1_WAVES
 #define PAIS_NS1_WAVES 3
 #endif
-#define PAIS_EVAL_BOUNDS(NS) __launch_bounds__(64 * PAIS_WG_WAVES, (NS) == 1 ? PAIS_NS1_WAVES : 3)
+#ifndef PAIS_NS2_WAVES
+#define PAIS_NS2_WAVES 3
+#endif
+#define PAIS_EVAL_BOUNDS(NS) __launch_bounds__(64 * PAIS_WG_WAVES, (NS) == 1 ? PAIS_NS1_WAVES : PAIS_NS2_WAVES)
 //   PAIS_TWO_PIXELS_MAXK  largest camera count of a batch that still runs two window pixels per lane (NS = 2)
 #ifndef PAIS_TWO_PIXELS_MAXK
 #define PAIS_TWO_PIXELS_MAXK 6
@@ -108,17 +111,17 @@ __global__ __launch_bounds__(64) void k_state_blocks(DevScene sc, const pais_pat
                          st->num_cam, st->cam_idx, lane);
     }
 }
-template <int NS>
+template <int NS, bool COLG>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_fitness(DevScene sc, const int32_t *stateIndex, const double *particles, double *out,
                                                                   int nEvals, int Kmax, const unsigned char *evalBlocks, size_t evalBlockBytes,
-                                                                  const WinPix *win)
+                                                                  const WinPix *win, double *colScratch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, COLG); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
-    double *cbuf = Hbuf + Kmax * 9;
+    double *cbuf = COLG ? colScratch + eval_colg_doubles(Kmax) * ((size_t)blockIdx.x * PAIS_WG_WAVES + (threadIdx.x >> 6)) : Hbuf + Kmax * PAIS_H_STRIDE;
     const int lane = threadIdx.x & 63;
     const int WS = win_stride(sc);
     const int nw = (int)(eval_block_bytes(Kmax) / 8);
@@ -701,16 +704,17 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 
 // The evaluation launch of large batches (split pipeline): one wave per (candidate, particle), nothing but the cost.
 // The candidate's constants come from the block k_pso_init prepared; positions from swarm buffer 0 (k_pso_step).
-template <int NS>
+template <int NS, bool COLG>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
-                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
+                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
+                                                                    double *colScratch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, COLG); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
-    double *cbuf = Hbuf + Kmax * 9;
+    double *cbuf = COLG ? colScratch + eval_colg_doubles(Kmax) * ((size_t)blockIdx.x * PAIS_WG_WAVES + (threadIdx.x >> 6)) : Hbuf + Kmax * PAIS_H_STRIDE;
     const int lane = threadIdx.x & 63;
     const size_t SB = pso_state_bytes(Nmax);
     const int total = n * Nmax;
@@ -825,18 +829,18 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 // Tasks: positions [listLo, min(listHi, *activeCount)) of the active list written by k_pso_init.
 // NS = 2 (3 waves per SIMD) for patches seen by few cameras, NS = 1 (4 waves per SIMD) beyond: a wave's LDS scratch
 // grows with NS * K and caps the occupancy (measured: K ~ 4: NS 2 +3 %, K ~ 7: NS 1 +9 %)
-template <int nparts, int NS>
+template <int nparts, int NS, bool COLG>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
                                             const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                                            const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
+                                            const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win, double *colScratch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, COLG); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
-    double *cbuf = Hbuf + Kmax * 9;
+    double *cbuf = COLG ? colScratch + eval_colg_doubles(Kmax) * ((size_t)blockIdx.x * PAIS_WG_WAVES + (threadIdx.x >> 6)) : Hbuf + Kmax * PAIS_H_STRIDE;
     const int lane = threadIdx.x & 63;
     const size_t SB = pso_state_bytes(Nmax);
     const int WS = win_stride(sc);
@@ -1457,33 +1461,42 @@ static inline int eval_grid(long tasks)
     return (int)(g < 1 ? 1 : g);
 }
 static inline bool two_pixels(int Kmax) { return Kmax <= PAIS_TWO_PIXELS_MAXK; }
+// batches with more cameras than this keep the colour rows in the global slab (LDS per wave: 9 KB instead of 9 + K/2 KB)
+#ifndef PAIS_COLG_ABOVE
+#define PAIS_COLG_ABOVE 16
+#endif
+#define PAIS_COLG_GRID 8192 // workgroups of a launch in that mode (grid-stride): bounds the slab
+bool colours_in_global(int Kmax) { return Kmax > PAIS_COLG_ABOVE; }
+size_t colour_slab_bytes(int Kmax) { return colours_in_global(Kmax) ? sizeof(double) * eval_colg_doubles(Kmax) * PAIS_COLG_GRID * PAIS_WG_WAVES : 0; }
+static inline int colg_grid(int grid) { return grid < PAIS_COLG_GRID ? grid : PAIS_COLG_GRID; }
 
 size_t eval_block_bytes_host(int Kmax) { return eval_block_bytes(Kmax); }
 size_t win_bytes_per_candidate(const DevScene &sc) { return sizeof(WinPix) * (size_t)win_stride(sc); }
 
-template <int NS>
+template <int NS, bool COLG>
 static hipError_t fitness_launch(const DevScene &sc, const int32_t *idx, const double *particles, double *out, int nEvals, int Kmax,
-                                 const unsigned char *evalBlocks, const void *win, hipStream_t stream)
+                                 const unsigned char *evalBlocks, const void *win, double *colScratch, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_fitness<NS>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax, COLG) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_fitness<NS, COLG>, lds);
     if (e != hipSuccess) return e;
-    const int grid = eval_grid(nEvals);
-    hipLaunchKernelGGL((k_fitness<NS>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win);
+    const int grid = COLG ? colg_grid(eval_grid(nEvals)) : eval_grid(nEvals);
+    hipLaunchKernelGGL((k_fitness<NS, COLG>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win, colScratch);
     return hipGetLastError();
 }
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
-                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream)
+                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, double *colScratch, hipStream_t stream)
 {
     if (nEvals <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_state_blocks, dim3(nStates < 65536 ? nStates : 65536), dim3(64), 0, stream, sc, states, nStates, evalBlocks,
                        eval_block_bytes(Kmax), (WinPix *)win);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return two_pixels(Kmax) ? fitness_launch<2>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream)
-                            : fitness_launch<1>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
+    if (colours_in_global(Kmax)) return fitness_launch<1, true>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, colScratch, stream);
+    return two_pixels(Kmax) ? fitness_launch<2, false>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, nullptr, stream)
+                            : fitness_launch<1, false>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, nullptr, stream);
 }
 
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream)
@@ -1523,53 +1536,58 @@ hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, un
                        eval_block_bytes(Kmax), (WinPix *)win);
     return hipGetLastError();
 }
-template <int NS>
+template <int NS, bool COLG>
 static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
-                                   const void *win, hipStream_t stream)
+                                   const void *win, double *colScratch, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_pso_eval2<NS>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax, COLG) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_pso_eval2<NS, COLG>, lds);
     if (e != hipSuccess) return e;
-    const int grid = eval_grid((long)n * Nmax);
-    hipLaunchKernelGGL((k_pso_eval2<NS>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks, eval_block_bytes(Kmax),
-                       (const WinPix *)win);
+    const int grid = COLG ? colg_grid(eval_grid((long)n * Nmax)) : eval_grid((long)n * Nmax);
+    hipLaunchKernelGGL((k_pso_eval2<NS, COLG>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win, colScratch);
     return hipGetLastError();
 }
 // the evaluation launch of large batches: `states`, `evalBlocks`, `win` point at the slice's first candidate
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    hipStream_t stream)
+                    double *colScratch, hipStream_t stream)
 {
-    return two_pixels(Kmax) ? pso_eval2_launch<2>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream)
-                            : pso_eval2_launch<1>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream);
+    if (colours_in_global(Kmax)) return pso_eval2_launch<1, true>(sc, states, n, Nmax, Kmax, evalBlocks, win, colScratch, stream);
+    return two_pixels(Kmax) ? pso_eval2_launch<2, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, nullptr, stream)
+                            : pso_eval2_launch<1, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, nullptr, stream);
 }
-template <int P, int NS>
+template <int P, int NS, bool COLG>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,
                                   int listLo, int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L,
-                                  int finishOnly, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
+                                  int finishOnly, const unsigned char *evalBlocks, const void *win, double *colScratch, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_pso_iter<P, NS>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax, COLG) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_pso_iter<P, NS, COLG>, lds);
     if (e != hipSuccess) return e;
-    const int grid = eval_grid((long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P));
-    hipLaunchKernelGGL((k_pso_iter<P, NS>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, activeList, activeCount, listLo, listHi, Nmax,
-                       Kmax, recs, stat, L, finishOnly, evalBlocks, eval_block_bytes(Kmax), (const WinPix *)win);
+    int grid = eval_grid((long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P));
+    if (COLG) grid = colg_grid(grid);
+    hipLaunchKernelGGL((k_pso_iter<P, NS, COLG>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, activeList, activeCount, listLo,
+                       listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, eval_block_bytes(Kmax), (const WinPix *)win, colScratch);
     return hipGetLastError();
 }
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                    int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
+                    int nparts, const unsigned char *evalBlocks, const void *win, double *colScratch, hipStream_t stream)
 {
     if (listHi <= listLo) return hipSuccess;
-    const bool two = two_pixels(Kmax);
-#define PAIS_DISPATCH(P)                                                                                                            \
-    return two ? pso_iter_launch<P, 2>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, win, stream) \
-               : pso_iter_launch<P, 1>(sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, win, stream)
+    const int shape = colours_in_global(Kmax) ? 2 : (two_pixels(Kmax) ? 0 : 1);
+#define PAIS_ARGS sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, win
+#define PAIS_DISPATCH(P)                                                                             \
+    return shape == 0 ? pso_iter_launch<P, 2, false>(PAIS_ARGS, nullptr, stream)                     \
+                      : (shape == 1 ? pso_iter_launch<P, 1, false>(PAIS_ARGS, nullptr, stream)       \
+                                    : pso_iter_launch<P, 1, true>(PAIS_ARGS, colScratch, stream))
     if (nparts == 4) { PAIS_DISPATCH(4); }
     if (nparts == 2) { PAIS_DISPATCH(2); }
     PAIS_DISPATCH(1);
 #undef PAIS_DISPATCH
+#undef PAIS_ARGS
 }
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                     unsigned long long *stat, hipStream_t stream)

@@ -8,8 +8,8 @@ SRC = os.path.join(ROOT, "pais_mvs_amd", "csrc")
 OUT = os.path.join(SRC, "variants")
 VARS = {
     "base": [],
-    "nofast": ["-DPAIS_CORNER_FASTPATH=0"],
-    "img1": ["-DPAIS_IMG_MODE=1"],
+    "ns2w4": ["-DPAIS_NS2_WAVES=4"],
+    "ns2w2": ["-DPAIS_NS2_WAVES=2"],
 }
 FILES = ["pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip"]
 
