@@ -57,8 +57,6 @@ struct pais_ctx {
     size_t recCap = 0;
     double *d_hp = nullptr;
     size_t hpBytes = 0;
-    double *d_colScratch = nullptr;     // colour rows of the evaluation waves when a batch has many cameras (one slab per
-    size_t colScratchBytes = 0;         // sub-stream: launches of different sub-streams run concurrently)
     double *d_ratios = nullptr;         // region ratio per (candidate, visible camera) (k_region_ratio)
     size_t ratioBytes = 0;
     int *d_counters = nullptr;          // [1] "needs another pass" count, [2] active-list length
@@ -211,9 +209,16 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
         }
     }
     ctx->imgBytes = imgBytes;
-    // the tap copy is expanded on the device (pais_internal.h PAIS_IMG_MODE)
-    HIPCHK(hipMalloc(&ctx->d_imgF, imgBytes * sizeof(PaisImgT)));
-    HIPCHK(pais_launch::expand_image(ctx->d_img, ctx->d_imgF, imgBytes, ctx->stream));
+    // the float2 tap copy is expanded on the device -- for scenes whose pyramids are small enough for it to pay
+    // (pais_internal.h PaisImgT); larger scenes tap the byte blob
+    {
+        size_t maxMB = 256;
+        if (const char *e = getenv("PAIS_TAP_FLOAT_MAX_MB")) maxMB = (size_t)strtoull(e, nullptr, 10);
+        if (imgBytes <= (maxMB << 20)) {
+            HIPCHK(hipMalloc(&ctx->d_imgF, imgBytes * sizeof(PaisImgT)));
+            HIPCHK(pais_launch::expand_image(ctx->d_img, ctx->d_imgF, imgBytes, ctx->stream));
+        }
+    }
     if (wantEdge && edgesGiven && edgeBytes) {
         HIPCHK(hipMalloc(&ctx->d_edge, edgeBytes));
         for (int c = 0; c < num_cams; ++c) {
@@ -313,7 +318,6 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     (void)hipFree(ctx->d_psoStates);
     (void)hipFree(ctx->d_win);
     (void)hipFree(ctx->d_ratios);
-    (void)hipFree(ctx->d_colScratch);
     (void)hipFree(ctx->d_nbC); (void)hipFree(ctx->d_nbN);
     for (auto st : ctx->sub) (void)hipStreamDestroy(st);
     for (auto ev : ctx->subDone) (void)hipEventDestroy(ev);
@@ -493,14 +497,13 @@ extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_
     }
     if (grow(ctx, ctx->d_evalBlocks, ctx->evalBlockCap, pais_launch::eval_block_bytes_host(Kmax) * (size_t)n_states)) return -2;
     if (grow(ctx, ctx->d_win, ctx->winCap, pais_launch::win_bytes_per_candidate(ctx->sc) * (size_t)n_states)) return -2;
-    if (grow(ctx, ctx->d_colScratch, ctx->colScratchBytes, pais_launch::colour_slab_bytes(Kmax) * (size_t)ctx->psoStreams)) return -2;
     HIPCHK(hipMemcpyAsync(ctx->d_states, states, sizeof(pais_patch_state) * (size_t)n_states, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_idx, state_index, sizeof(int32_t) * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_particles, particles, sizeof(double) * 3 * (size_t)n_evals, hipMemcpyHostToDevice, ctx->stream));
     Timed tf;
     if (tf.begin(ctx, ctx->stream, &ctx->evEval)) return -2; // kernel-only time, reported as eval_ms / eval_launches
     HIPCHK(pais_launch::fitness(ctx->sc, ctx->d_states, n_states, ctx->d_idx, ctx->d_particles, ctx->d_out, n_evals, Kmax,
-                                ctx->d_evalBlocks, ctx->d_win, ctx->d_colScratch, ctx->stream));
+                                ctx->d_evalBlocks, ctx->d_win, ctx->stream));
     if (tf.end()) return -2;
     ctx->evalLaunches++;
     HIPCHK(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)n_evals, hipMemcpyDeviceToHost, ctx->stream));
@@ -540,8 +543,6 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     const size_t SB = pais_launch::pso_state_bytes_host(Nmax);
     if (grow(ctx, ctx->d_psoStates, ctx->psoStateBytes, SB * (size_t)n)) return -2;
     if (grow(ctx, ctx->d_ratios, ctx->ratioBytes, sizeof(double) * PAIS_MAX_VIS * (size_t)n)) return -2;
-    const size_t slabBytes = pais_launch::colour_slab_bytes(Kmax);
-    if (grow(ctx, ctx->d_colScratch, ctx->colScratchBytes, slabBytes * (size_t)ctx->psoStreams)) return -2;
     const size_t EB = pais_launch::eval_block_bytes_host(Kmax), WB = pais_launch::win_bytes_per_candidate(sc);
 
     Timed tb;
@@ -579,7 +580,6 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
             hipStream_t st = own ? ctx->stream : ctx->sub[sI - 1];
             if (!own) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
             unsigned char *stp = ctx->d_psoStates + SB * (size_t)lo;
-            double *slab = ctx->d_colScratch ? (double *)((unsigned char *)ctx->d_colScratch + slabBytes * (size_t)sI) : nullptr;
             // waves per evaluation: a slice that leaves the GPU mostly empty is bound by the latency of
             // one evaluation wave, so share each evaluation among 4 (2) waves while they all stay resident
             int parts = 1;
@@ -592,9 +592,9 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 if (te.begin(ctx, st, &ctx->evEval)) return -2;
                 if (useIter)
                     HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat,
-                                                 it, 0, parts, ctx->d_evalBlocks, ctx->d_win, slab, st));
+                                                 it, 0, parts, ctx->d_evalBlocks, ctx->d_win, st));
                 else
-                    HIPCHK(pais_launch::pso_eval(sc, stp, hi - lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)lo, ctx->d_win + WB * (size_t)lo, slab, st));
+                    HIPCHK(pais_launch::pso_eval(sc, stp, hi - lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)lo, ctx->d_win + WB * (size_t)lo, st));
                 if (te.end()) return -2;
                 ctx->evalLaunches++;
                 if (!useIter) HIPCHK(pais_launch::pso_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
@@ -602,7 +602,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
             // the launch after the last possible iteration only ends the runs still active
             if (useIter)
                 HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat,
-                                             maxIt + 1, 1, parts, ctx->d_evalBlocks, ctx->d_win, slab, st));
+                                             maxIt + 1, 1, parts, ctx->d_evalBlocks, ctx->d_win, st));
             if (!own) {
                 HIPCHK(hipEventRecord(ctx->subDone[sI - 1], st));
                 HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));

@@ -63,49 +63,44 @@ __device__ __forceinline__ int clamp_i32(int v, int lo, int hi)
     return r;
 }
 
-// one row of a bilinear tap: the left pixel and the (exact) difference to its right neighbour, with one global load
-#if PAIS_IMG_MODE == 0
-struct RowTap { float a, b; };   // two adjacent pixels (8 bytes, 4-byte aligned)
-#elif PAIS_IMG_MODE == 1
-typedef float2 RowTap;           // {I, dI}
-#elif PAIS_IMG_MODE == 2
-typedef double2 RowTap;          // {I, dI}
-#else
-typedef uint16_t RowTap;         // two adjacent bytes
-#endif
-__device__ __forceinline__ RowTap load_row(const PaisImgT *p)
-{
-    RowTap v;
-    __builtin_memcpy(&v, p, sizeof(RowTap));
-    return v;
-}
-// the same from a wave-uniform level base + a 32-bit BYTE offset inside the level (a level is far below 4 GB): the form
+// one row of a bilinear tap: the left pixel and the (exact) difference to its right neighbour, with one global load.
+// BYTES = false: from the float2 copy {I, dI}; BYTES = true: two adjacent bytes of the byte blob (pais_internal.h).
+template <bool BYTES> struct Tap;
+template <> struct Tap<false> {
+    typedef float2 Row;
+    static constexpr uint32_t kElem = 8;
+    static __device__ __forceinline__ const unsigned char *blob(const DevScene &sc) { return (const unsigned char *)sc.imgF; }
+};
+template <> struct Tap<true> {
+    typedef uint16_t Row;
+    static constexpr uint32_t kElem = 1;
+    static __device__ __forceinline__ const unsigned char *blob(const DevScene &sc) { return sc.imgBlob; }
+};
+// from a wave-uniform level base + a 32-bit BYTE offset inside the level (a level is far below 4 GB): the form
 // global_load ... v_off, s[base:base+1] needs no 64-bit VALU address arithmetic
-__device__ __forceinline__ RowTap load_row_at(const PaisImgT *levelBase, uint32_t byteOff)
+template <class Row> __device__ __forceinline__ Row load_row_at(const unsigned char *levelBase, uint32_t byteOff)
 {
-    RowTap v;
-    __builtin_memcpy(&v, (const unsigned char *)levelBase + byteOff, sizeof(RowTap));
+    Row v;
+    __builtin_memcpy(&v, levelBase + byteOff, sizeof(Row));
     return v;
 }
 
 // bilinear as three lerps a + f (b - a) from two rows; the pixel differences are exact (small integers)
-__device__ __forceinline__ double lerp3(RowTap r0, RowTap r1, double bx, double by)
+__device__ __forceinline__ double lerp3(double i00, double d0, double i01, double d1, double bx, double by)
 {
-#if PAIS_IMG_MODE == 0
-    const double i00 = (double)r0.a, d0 = (double)(r0.b - r0.a);
-    const double i01 = (double)r1.a, d1 = (double)(r1.b - r1.a);
-#elif PAIS_IMG_MODE == 3
-    const int a0 = (int)(r0 & 0xff), b0 = (int)(r0 >> 8);
-    const int a1 = (int)(r1 & 0xff), b1 = (int)(r1 >> 8);
-    const double i00 = (double)a0, d0 = (double)(b0 - a0);
-    const double i01 = (double)a1, d1 = (double)(b1 - a1);
-#else
-    const double i00 = (double)r0.x, d0 = (double)r0.y;
-    const double i01 = (double)r1.x, d1 = (double)r1.y;
-#endif
     const double t0 = fma(bx, d0, i00);
     const double t1 = fma(bx, d1, i01);
     return fma(by, t1 - t0, t0);
+}
+__device__ __forceinline__ double lerp3(float2 r0, float2 r1, double bx, double by)
+{
+    return lerp3((double)r0.x, (double)r0.y, (double)r1.x, (double)r1.y, bx, by);
+}
+__device__ __forceinline__ double lerp3(uint16_t r0, uint16_t r1, double bx, double by)
+{
+    const int a0 = (int)(r0 & 0xff), b0 = (int)(r0 >> 8);
+    const int a1 = (int)(r1 & 0xff), b1 = (int)(r1 >> 8);
+    return lerp3((double)a0, (double)(b0 - a0), (double)a1, (double)(b1 - a1), bx, by);
 }
 
 // 1 / w, correctly rounded for every w whose reciprocal is a normal number: hardware estimate, two Newton steps
@@ -206,7 +201,6 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
         win[(S2 & ~63) + lane] = pad;
     }
     const uint8_t *refImg = sc.imgBlob + rc.imgOff[LOD];
-    const PaisImgT *refF = sc.imgF + rc.imgOff[LOD];
     const double *refEdge = sc.edgeBlob ? sc.edgeBlob + rc.edgeOff[LOD] : nullptr;
     const double eMin = rc.edgeMin[LOD], eMax = rc.edgeMax[LOD];
     const bool useDist = sc.cfg.adaptiveDistanceEnable != 0, useGrad = sc.cfg.adaptiveGradientEnable != 0;
@@ -219,7 +213,7 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
         const double bx = x - (double)qx, by = y - (double)qy;
         const uint32_t off = (uint32_t)qy * (uint32_t)refW + (uint32_t)qx;
         WinPix wp;
-        wp.refCol = lerp3(load_row(refF + off), load_row(refF + off + (uint32_t)refW), bx, by);
+        wp.refCol = lerp3(load_row_at<uint16_t>(refImg, off), load_row_at<uint16_t>(refImg, off + (uint32_t)refW), bx, by);
         double ws = useDist ? sc.gauss[xi * S + yi] : 1.0;
         if (useGrad) {
             const double e = refEdge ? refEdge[ry * refW + rx] : edge_on_the_fly(refImg, refW, refH, rx, ry, eMin, eMax);
@@ -235,7 +229,7 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
 // G x NS taps are independent so they overlap.
 // CHECK = false: the evaluation has established that no tap of the window can leave the image (corners_inside below):
 // no clamping, no flags.
-template <int G, int NS, bool CHECK>
+template <int G, int NS, bool CHECK, bool BYTES>
 __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cams, const double *Hbuf, double *myc,
                                           int c0, double *x, double *y, uint32_t *badBits, double *sum)
 {
@@ -245,7 +239,9 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 #pragma unroll
     for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
     double bx[NS][G], by[NS][G], nx[NS][G], ny[NS][G], w[NS][G], rw[NS][G];
-    const PaisImgT *base[G];
+    typedef typename Tap<BYTES>::Row RowTap;
+    constexpr uint32_t kElem = Tap<BYTES>::kElem;
+    const unsigned char *base[G];
     uint32_t off[NS][G], cwv[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -289,7 +285,7 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
         {   // wave-uniform: keep the base in SGPRs so that the taps are global_load ... v_off, s[base] (no 64-bit VALU address math)
             const uint64_t io = ti.imgOff;
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)io), hi = __builtin_amdgcn_readfirstlane((uint32_t)(io >> 32));
-            base[u] = sc.imgF + (((uint64_t)hi << 32) | lo);
+            base[u] = Tap<BYTES>::blob(sc) + (((uint64_t)hi << 32) | lo) * kElem;
         }
         cwv[u] = cw;
 #pragma unroll
@@ -308,7 +304,7 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
             }
             bx[q][u] = __builtin_amdgcn_fract(ix);
             by[q][u] = __builtin_amdgcn_fract(iy);
-            off[q][u] = (__umul24((uint32_t)py, cw) + (uint32_t)px) * (uint32_t)sizeof(PaisImgT); // byte offset in the level (w < 2^24)
+            off[q][u] = (__umul24((uint32_t)py, cw) + (uint32_t)px) * kElem; // byte offset in the level (w < 2^24)
         }
     }
     RowTap r0[NS][G], r1[NS][G];
@@ -316,8 +312,8 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
     for (int q = 0; q < NS; ++q)
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            r0[q][u] = load_row_at(base[u], off[q][u]);
-            r1[q][u] = load_row_at(base[u], off[q][u] + cwv[u] * (uint32_t)sizeof(PaisImgT));
+            r0[q][u] = load_row_at<RowTap>(base[u], off[q][u]);
+            r1[q][u] = load_row_at<RowTap>(base[u], off[q][u] + cwv[u] * kElem);
         }
 #pragma unroll
     for (int q = 0; q < NS; ++q)
@@ -339,14 +335,10 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 #define PAIS_ACC_IN_REGS(NS) (PAIS_ACC_REG || (NS) == 1)
 #define PAIS_CBUF_ROWS(NS, M) ((NS) * (M) + (PAIS_ACC_IN_REGS(NS) ? 0 : 8))
 __host__ __device__ inline size_t eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
-// colg: the colour rows live in a global scratch slab instead (many cameras: 512 B per camera per wave would leave a
-// single wave per SIMD at 40 cameras; the slab is written and read back by the same lane within microseconds -- L2)
-__host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax, bool colg = false)
+__host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax)
 {
-    return eval_block_bytes(Kmax) + sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax + (colg ? 0 : sizeof(double) * 64 * (size_t)PAIS_CBUF_ROWS(NS, Kmax));
+    return eval_block_bytes(Kmax) + sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax + sizeof(double) * 64 * (size_t)PAIS_CBUF_ROWS(NS, Kmax);
 }
-// colour rows of one wave in the global slab (one-pixel kernels only: accumulators are in registers there)
-__host__ __device__ inline size_t eval_colg_doubles(int Kmax) { return (size_t)64 * Kmax; }
 
 // Reduction shape (canonical, independent of how many waves share one evaluation): the 64-pixel steps of the
 // window are dealt round-robin to FOUR sub-accumulators (step mod 4); each is summed per lane over its steps,
@@ -354,7 +346,7 @@ __host__ __device__ inline size_t eval_colg_doubles(int Kmax) { return (size_t)6
 // computes all four (nparts = 1), or `nparts` (2 / 4) waves compute the sub-accumulators a with
 // a mod nparts == part and whoever consumes the fitness adds them -- the same bits either way.
 // Returns 0 and fills f4/w4 (zeros for the sub-accumulators of other parts), or 1 if the call is DBL_MAX.
-template <int NS, bool CHECK>
+template <int NS, bool CHECK, bool BYTES>
 __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                            const WinPix *win, int lane, int part, int nparts, double *f4, double *w4);
 
@@ -389,7 +381,7 @@ __device__ __forceinline__ bool corners_inside(const EvalPatch *ep, const EvalCa
     return __all(ok);
 }
 
-template <int NS>
+template <int NS, bool BYTES>
 __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                                   const WinPix *win, double theta, double phi, double depth, int lane, int part, int nparts,
                                   double *f4, double *w4)
@@ -432,13 +424,13 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     wave_sync();
 #if PAIS_CORNER_FASTPATH
     if (corners_inside(ep, cams, Hbuf, sc.cfg.patchSize, lane))
-        return eval_window<NS, false>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
+        return eval_window<NS, false, BYTES>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
 #endif
-    return eval_window<NS, true>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
+    return eval_window<NS, true, BYTES>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
 }
 
 // the window walk of one evaluation (homographies in Hbuf); CHECK: see corners_inside
-template <int NS, bool CHECK>
+template <int NS, bool CHECK, bool BYTES>
 __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                            const WinPix *win, int lane, int part, int nparts, double *f4, double *w4)
 {
@@ -490,9 +482,9 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
 #pragma unroll
         for (int q = 0; q < NS; ++q) sum[q] = hasRef ? wp[q].refCol : 0.0;
         int c0 = 0;
-        for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS, CHECK>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
-        if (M - c0 == 3) tap_group<3, NS, CHECK>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
-        else if (M - c0 == 1) tap_group<1, NS, CHECK>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // a single camera
+        for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
+        if (M - c0 == 3) tap_group<3, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
+        else if (M - c0 == 1) tap_group<1, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // a single camera
         // mean and mean absolute deviation of the K colours: one pass over the cameras serves the lane's NS pixels
         double mean[NS], sad[NS];
 #pragma unroll

@@ -15,8 +15,8 @@
 // HBM layout: one DevCamera per camera in a dense array;
 // every pyramid level of every camera repacked row-major with stride == width
 // into one byte blob (levels 256-byte aligned), edge levels likewise as doubles.
-// The cost kernel's bilinear taps read a float copy of the byte blob (imgF): two adjacent pixels come
-// back with one 8-byte load and need no unpacking (4 fewer VALU instructions per tap).
+// The cost kernel's bilinear taps read either a float2 copy of the byte blob (imgF) or the byte blob itself
+// (DevScene::imgF == nullptr): see PaisImgT below.
 struct DevCamera {
     double KR[9], KT[3], R[9], T[3], C[3], optN[3], focal[2], pp[2];
     int maxLOD;
@@ -31,31 +31,22 @@ struct DevCamera {
     double edgeMin[PAIS_MAX_LEVELS], edgeMax[PAIS_MAX_LEVELS];
 };
 
-// What the cost taps read: a copy of the byte blob with identical element offsets (imgOff), in a layout that needs no
-// unpacking.  PAIS_IMG_MODE (compile time; the sampled values are identical in every mode):
-//   0  float I(x)                      -- a tap row = two adjacent floats, one 8-byte load, b - a in float
-//   1  float2 {I(x), I(x+1) - I(x)}    -- a tap row = one aligned 8-byte load, no subtraction
-//   2  double2 {I(x), I(x+1) - I(x)}   -- a tap row = one aligned 16-byte load, no conversion either (4x the bytes)
-//   3  the byte blob itself            -- a tap row = one 2-byte load + two byte->float conversions; a quarter of the
-//                                         float copy's cache footprint
-#ifndef PAIS_IMG_MODE
-#define PAIS_IMG_MODE 1
-#endif
-#if PAIS_IMG_MODE == 0
-typedef float PaisImgT;
-#elif PAIS_IMG_MODE == 1
+// What the cost taps read (a property of the uploaded scene; the sampled values are identical either way):
+//   float2 {I(x), I(x+1) - I(x)}  a copy of the byte blob with identical element offsets (imgOff): a tap row = one aligned
+//                                 8-byte load, no unpacking, no subtraction.  +10 % evaluations/s where the working set
+//                                 of a batch sits in L2 anyway (pawn: 107 vs 97 M evaluations/s) -- at 8x the bytes;
+//   the byte blob itself          a tap row = one 2-byte load + byte->double conversions and one subtraction.  An eighth
+//                                 of the footprint: +21 % patches/s on the 128 x 12.6 MP dome (4.5 GB instead of 36 GB
+//                                 of pyramids, and the taps of a batch stop missing L2 / the TLB); equal on the ring.
+// pais_create expands the float2 copy when the byte pyramids are at most PAIS_TAP_FLOAT_MAX_MB (default 256 MB, i.e. a
+// 2 GB copy); larger scenes run the BYTES instantiations of the evaluation kernels.
 typedef float2 PaisImgT;
-#elif PAIS_IMG_MODE == 2
-typedef double2 PaisImgT;
-#else
-typedef uint8_t PaisImgT;
-#endif
 
 struct DevScene {
     pais_config cfg;
     const DevCamera *cams;
     const uint8_t *imgBlob;
-    const PaisImgT *imgF;   // tap copy of imgBlob, same element offsets (imgOff)
+    const PaisImgT *imgF;   // tap copy of imgBlob, same element offsets (imgOff); nullptr: the taps read imgBlob (BYTES kernels)
     const double *edgeBlob; // normalised Sobel magnitude per level as the caller built it; nullptr: evaluated on the fly
     const double *gauss; // patchDistWeight, S*S, indexed [x*S + y] (mvs.cpp:104-109)
     double lodScale[PAIS_MAX_LEVELS]; // pow(lodRatio, LOD) (camera.cpp:157, patch.cpp:309)
@@ -68,10 +59,8 @@ namespace pais_launch {
 // evaluation block of a PSO run (pais_eval.hpp): EvalPatch + EvalCam[Kmax] bytes per candidate, and the reference window
 size_t eval_block_bytes_host(int Kmax);
 size_t win_bytes_per_candidate(const DevScene &sc);
-// batches of many cameras keep the colour rows of the evaluation in a global slab of colour_slab_bytes(Kmax) bytes
-size_t colour_slab_bytes(int Kmax);
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
-                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, double *colScratch, hipStream_t stream);
+                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream);
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream);
 hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream);
 hipError_t expand_image(const uint8_t *img, PaisImgT *out, size_t n, hipStream_t stream);
@@ -80,10 +69,10 @@ size_t pso_state_bytes_host(int Nmax);
 hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
                     int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    double *colScratch, hipStream_t stream);
+                    hipStream_t stream);
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                    int nparts, const unsigned char *evalBlocks, const void *win, double *colScratch, hipStream_t stream);
+                    int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream);
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                     unsigned long long *stat, hipStream_t stream);
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,

@@ -111,17 +111,17 @@ __global__ __launch_bounds__(64) void k_state_blocks(DevScene sc, const pais_pat
                          st->num_cam, st->cam_idx, lane);
     }
 }
-template <int NS, bool COLG>
+template <int NS, bool BYTES>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_fitness(DevScene sc, const int32_t *stateIndex, const double *particles, double *out,
                                                                   int nEvals, int Kmax, const unsigned char *evalBlocks, size_t evalBlockBytes,
-                                                                  const WinPix *win, double *colScratch)
+                                                                  const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, COLG); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
-    double *cbuf = COLG ? colScratch + eval_colg_doubles(Kmax) * ((size_t)blockIdx.x * PAIS_WG_WAVES + (threadIdx.x >> 6)) : Hbuf + Kmax * PAIS_H_STRIDE;
+    double *cbuf = Hbuf + Kmax * PAIS_H_STRIDE;
     const int lane = threadIdx.x & 63;
     const int WS = win_stride(sc);
     const int nw = (int)(eval_block_bytes(Kmax) / 8);
@@ -133,7 +133,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_fitness(DevScene sc, const int32_t *state
         stage_eval_block(smem, src, nw, lane, v0, v1);
         wave_sync();
         double f4[4], w4[4];
-        const int bad = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)s * WS, particles[3 * e], particles[3 * e + 1],
+        const int bad = eval_fitness_parts<NS, BYTES>(sc, ep, cams, Hbuf, cbuf, win + (size_t)s * WS, particles[3 * e], particles[3 * e + 1],
                                                particles[3 * e + 2], lane, 0, 1, f4, w4);
         if (lane == 0) out[e] = bad ? DBL_MAX : combine_parts(f4, w4);
     }
@@ -704,17 +704,16 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 
 // The evaluation launch of large batches (split pipeline): one wave per (candidate, particle), nothing but the cost.
 // The candidate's constants come from the block k_pso_init prepared; positions from swarm buffer 0 (k_pso_step).
-template <int NS, bool COLG>
+template <int NS, bool BYTES>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
-                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
-                                                                    double *colScratch)
+                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, COLG); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
-    double *cbuf = COLG ? colScratch + eval_colg_doubles(Kmax) * ((size_t)blockIdx.x * PAIS_WG_WAVES + (threadIdx.x >> 6)) : Hbuf + Kmax * PAIS_H_STRIDE;
+    double *cbuf = Hbuf + Kmax * PAIS_H_STRIDE;
     const int lane = threadIdx.x & 63;
     const size_t SB = pso_state_bytes(Nmax);
     const int total = n * Nmax;
@@ -736,7 +735,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
         stage_eval_block(smem, src, nwMax, lane, v0, v1);
         wave_sync();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
+        const int st = eval_fitness_parts<NS, BYTES>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
         if (lane == 0) A.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
     }
 }
@@ -829,18 +828,18 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 // Tasks: positions [listLo, min(listHi, *activeCount)) of the active list written by k_pso_init.
 // NS = 2 (3 waves per SIMD) for patches seen by few cameras, NS = 1 (4 waves per SIMD) beyond: a wave's LDS scratch
 // grows with NS * K and caps the occupancy (measured: K ~ 4: NS 2 +3 %, K ~ 7: NS 1 +9 %)
-template <int nparts, int NS, bool COLG>
+template <int nparts, int NS, bool BYTES>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
                                             const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                                            const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win, double *colScratch)
+                                            const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, COLG); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
-    double *cbuf = COLG ? colScratch + eval_colg_doubles(Kmax) * ((size_t)blockIdx.x * PAIS_WG_WAVES + (threadIdx.x >> 6)) : Hbuf + Kmax * PAIS_H_STRIDE;
+    double *cbuf = Hbuf + Kmax * PAIS_H_STRIDE;
     const int lane = threadIdx.x & 63;
     const size_t SB = pso_state_bytes(Nmax);
     const int WS = win_stride(sc);
@@ -1023,7 +1022,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *stat
         stage_eval_block(smem, src, nwMax, lane, v0, v1); // the run's evaluation block, prepared by k_pso_init
         wave_sync();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, part, nparts, f4, w4);
+        const int st = eval_fitness_parts<NS, BYTES>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, part, nparts, f4, w4);
         if (lane == 0) {
             if (nparts == 1) {
                 Wb.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
@@ -1330,22 +1329,16 @@ __global__ __launch_bounds__(64 * AFTER_WAVES) void k_after(DevScene sc, pais_pa
 }
 
 // ------------------------------------------------------- scene preparation ---
-// tap copy of the byte blob (pais_internal.h PAIS_IMG_MODE): one thread per pixel, coalesced
+// float2 tap copy of the byte blob (pais_internal.h PaisImgT): one thread per pixel, coalesced
 __global__ __launch_bounds__(256) void k_expand_image(const uint8_t *img, PaisImgT *out, size_t n)
 {
     // grid-stride: a blob of several GB has more pixels than one launch may have threads (2^32)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-#if PAIS_IMG_MODE == 0
-        out[i] = (float)img[i];
-#elif PAIS_IMG_MODE == 3
-        out[i] = img[i];
-#else
         const int a = img[i], b = (i + 1 < n) ? img[i + 1] : 0; // the last column's difference is never tapped
         PaisImgT v;
         v.x = a;
         v.y = b - a;
         out[i] = v;
-#endif
     }
 }
 // minimum / maximum Sobel magnitude of one level (the statements of k_sobel_mag in pais_pyramid.hip without the map):
@@ -1461,42 +1454,38 @@ static inline int eval_grid(long tasks)
     return (int)(g < 1 ? 1 : g);
 }
 static inline bool two_pixels(int Kmax) { return Kmax <= PAIS_TWO_PIXELS_MAXK; }
-// batches with more cameras than this keep the colour rows in the global slab (LDS per wave: 9 KB instead of 9 + K/2 KB)
-#ifndef PAIS_COLG_ABOVE
-#define PAIS_COLG_ABOVE 16
-#endif
-#define PAIS_COLG_GRID 8192 // workgroups of a launch in that mode (grid-stride): bounds the slab
-bool colours_in_global(int Kmax) { return Kmax > PAIS_COLG_ABOVE; }
-size_t colour_slab_bytes(int Kmax) { return colours_in_global(Kmax) ? sizeof(double) * eval_colg_doubles(Kmax) * PAIS_COLG_GRID * PAIS_WG_WAVES : 0; }
-static inline int colg_grid(int grid) { return grid < PAIS_COLG_GRID ? grid : PAIS_COLG_GRID; }
+// the scene decides what the taps read (pais_internal.h PaisImgT)
+static inline bool byte_taps(const DevScene &sc) { return sc.imgF == nullptr; }
 
 size_t eval_block_bytes_host(int Kmax) { return eval_block_bytes(Kmax); }
 size_t win_bytes_per_candidate(const DevScene &sc) { return sizeof(WinPix) * (size_t)win_stride(sc); }
 
-template <int NS, bool COLG>
+template <int NS, bool BYTES>
 static hipError_t fitness_launch(const DevScene &sc, const int32_t *idx, const double *particles, double *out, int nEvals, int Kmax,
-                                 const unsigned char *evalBlocks, const void *win, double *colScratch, hipStream_t stream)
+                                 const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax, COLG) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_fitness<NS, COLG>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_fitness<NS, BYTES>, lds);
     if (e != hipSuccess) return e;
-    const int grid = COLG ? colg_grid(eval_grid(nEvals)) : eval_grid(nEvals);
-    hipLaunchKernelGGL((k_fitness<NS, COLG>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win, colScratch);
+    const int grid = eval_grid(nEvals);
+    hipLaunchKernelGGL((k_fitness<NS, BYTES>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
-                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, double *colScratch, hipStream_t stream)
+                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream)
 {
     if (nEvals <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_state_blocks, dim3(nStates < 65536 ? nStates : 65536), dim3(64), 0, stream, sc, states, nStates, evalBlocks,
                        eval_block_bytes(Kmax), (WinPix *)win);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (colours_in_global(Kmax)) return fitness_launch<1, true>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, colScratch, stream);
-    return two_pixels(Kmax) ? fitness_launch<2, false>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, nullptr, stream)
-                            : fitness_launch<1, false>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, nullptr, stream);
+    if (byte_taps(sc))
+        return two_pixels(Kmax) ? fitness_launch<2, true>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream)
+                                : fitness_launch<1, true>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
+    return two_pixels(Kmax) ? fitness_launch<2, false>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream)
+                            : fitness_launch<1, false>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
 }
 
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream)
@@ -1536,53 +1525,55 @@ hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, un
                        eval_block_bytes(Kmax), (WinPix *)win);
     return hipGetLastError();
 }
-template <int NS, bool COLG>
+template <int NS, bool BYTES>
 static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
-                                   const void *win, double *colScratch, hipStream_t stream)
+                                   const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax, COLG) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_pso_eval2<NS, COLG>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_pso_eval2<NS, BYTES>, lds);
     if (e != hipSuccess) return e;
-    const int grid = COLG ? colg_grid(eval_grid((long)n * Nmax)) : eval_grid((long)n * Nmax);
-    hipLaunchKernelGGL((k_pso_eval2<NS, COLG>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win, colScratch);
+    const int grid = eval_grid((long)n * Nmax);
+    hipLaunchKernelGGL((k_pso_eval2<NS, BYTES>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }
 // the evaluation launch of large batches: `states`, `evalBlocks`, `win` point at the slice's first candidate
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    double *colScratch, hipStream_t stream)
+                    hipStream_t stream)
 {
-    if (colours_in_global(Kmax)) return pso_eval2_launch<1, true>(sc, states, n, Nmax, Kmax, evalBlocks, win, colScratch, stream);
-    return two_pixels(Kmax) ? pso_eval2_launch<2, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, nullptr, stream)
-                            : pso_eval2_launch<1, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, nullptr, stream);
+    if (byte_taps(sc))
+        return two_pixels(Kmax) ? pso_eval2_launch<2, true>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream)
+                                : pso_eval2_launch<1, true>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream);
+    return two_pixels(Kmax) ? pso_eval2_launch<2, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream)
+                            : pso_eval2_launch<1, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream);
 }
-template <int P, int NS, bool COLG>
+template <int P, int NS, bool BYTES>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,
                                   int listLo, int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L,
-                                  int finishOnly, const unsigned char *evalBlocks, const void *win, double *colScratch, hipStream_t stream)
+                                  int finishOnly, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax, COLG) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_pso_iter<P, NS, COLG>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_pso_iter<P, NS, BYTES>, lds);
     if (e != hipSuccess) return e;
-    int grid = eval_grid((long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P));
-    if (COLG) grid = colg_grid(grid);
-    hipLaunchKernelGGL((k_pso_iter<P, NS, COLG>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, activeList, activeCount, listLo,
-                       listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, eval_block_bytes(Kmax), (const WinPix *)win, colScratch);
+    const int grid = eval_grid((long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P));
+    hipLaunchKernelGGL((k_pso_iter<P, NS, BYTES>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, activeList, activeCount, listLo,
+                       listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
-                    int nparts, const unsigned char *evalBlocks, const void *win, double *colScratch, hipStream_t stream)
+                    int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     if (listHi <= listLo) return hipSuccess;
-    const int shape = colours_in_global(Kmax) ? 2 : (two_pixels(Kmax) ? 0 : 1);
+    const int shape = (two_pixels(Kmax) ? 0 : 1) + (byte_taps(sc) ? 2 : 0);
 #define PAIS_ARGS sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, win
 #define PAIS_DISPATCH(P)                                                                             \
-    return shape == 0 ? pso_iter_launch<P, 2, false>(PAIS_ARGS, nullptr, stream)                     \
-                      : (shape == 1 ? pso_iter_launch<P, 1, false>(PAIS_ARGS, nullptr, stream)       \
-                                    : pso_iter_launch<P, 1, true>(PAIS_ARGS, colScratch, stream))
+    return shape == 0 ? pso_iter_launch<P, 2, false>(PAIS_ARGS, stream)                              \
+                      : (shape == 1 ? pso_iter_launch<P, 1, false>(PAIS_ARGS, stream)                \
+                                    : (shape == 2 ? pso_iter_launch<P, 2, true>(PAIS_ARGS, stream)   \
+                                                  : pso_iter_launch<P, 1, true>(PAIS_ARGS, stream)))
     if (nparts == 4) { PAIS_DISPATCH(4); }
     if (nparts == 2) { PAIS_DISPATCH(2); }
     PAIS_DISPATCH(1);

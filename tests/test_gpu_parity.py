@@ -626,6 +626,36 @@ def test_pipeline_shapes_are_bit_identical(pawn_small, monkeypatch):
     for parts in ("1", "2", "4"):
         monkeypatch.setenv("PAIS_EVAL_PARTS", parts)
         assert run() == ref, parts
+    monkeypatch.delenv("PAIS_EVAL_PARTS")
+    # what the taps read is a property of the uploaded scene (float2 copy for small pyramids, the byte blob for large
+    # ones: pais_internal.h PaisImgT); the sampled values are the same
+    monkeypatch.setenv("PAIS_TAP_FLOAT_MAX_MB", "0")
+    assert run() == ref, "byte taps"
+    monkeypatch.setenv("PAIS_SPLIT_ABOVE", "1")
+    assert run() == ref, "byte taps, split"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["pawn_small", "ring_small"])
+def test_byte_taps_cost_is_the_float_copy_cost(request, scene_name, monkeypatch):
+    """The BYTES instantiations of the evaluation kernels (two-pixel and one-pixel shapes) against the oracle, bit for bit."""
+    from pais_mvs_amd.config import readme_config
+    scene = request.getfixturevalue(scene_name)
+    cfg = readme_config(adaptiveGradientEnable=True)
+    S = common.oracle_scene(cfg, scene)
+    monkeypatch.setenv("PAIS_TAP_FLOAT_MAX_MB", "0")
+    ctx = _ctx(cfg, scene)
+    rng = np.random.default_rng(11)
+    states, pats, idx, parts = _states_and_particles(S, scene, rng)
+    got = ctx.fitness_batch(states, idx, parts)
+    S.set_kernel_arithmetic(True)
+    n_fin = 0
+    for e, (si, pos) in enumerate(zip(idx, parts)):
+        want = S.fitness(pats[si], pos)
+        assert common.same_value(got[e], want, RTOL_EXACT), (e, got[e], want)
+        n_fin += want != DBL_MAX
+    assert n_fin > 50
+    ctx.close()
 
 
 @pytest.mark.gpu
@@ -768,7 +798,7 @@ def test_dome_full_size_bounded_rounds():
     """BASELINE.json configs[4] on ONE GPU at FULL size: 128 cameras 4096x3072 on a Fibonacci dome, patchRadius 25
     (S^2 = 2601), reduceNormalRange 4, all adaptive weights on.  The renders and pyramids are produced on the GPU (hours in
     numpy), the edge maps are never materialised; seeds + a bounded number of expansion rounds; properties as above and the
-    HBM footprint is reported (~4.5 GB of gray pyramids + their tap copy)."""
+    HBM footprint is reported (~4.5 GB of gray pyramids, which the taps read directly at this size)."""
     import torch
     from pais_mvs_amd import synth
     from pais_mvs_amd.config import readme_config
@@ -793,7 +823,7 @@ def test_dome_full_size_bounded_rounds():
     print("\ndome 128 x 4096 x 3072: scene in HBM %.1f GB, peak working set %.1f GB of %.0f GB; %d seeds kept, %d patches after 2 rounds, "
           "K max %d, %d candidates refined" % (scene_gb, (free1 - free3) / 2 ** 30, total / 2 ** 30, n_seed, len(ps), max(p.num_cam for p in ps),
                                               st.candidates_refined))
-    assert 10.0 < scene_gb < 80.0
+    assert 3.0 < scene_gb < 8.0              # no float2 tap copy (36 GB) at this size: the BYTES kernels run
     assert n_seed >= len(scene.seeds) // 3 and len(ps) > 2 * n_seed
     assert max(p.num_cam for p in ps) >= 12
     for p in ps[:: max(1, len(ps) // 300)]:
