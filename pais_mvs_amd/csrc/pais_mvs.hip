@@ -57,12 +57,40 @@ struct HostPatch { // AbstractPatch fields the expansion loop reads (abstractpat
 
 struct CellEntry { int id, next; };
 
-class CellMap { // cellmap.h:15-32
+// cellmap.h:15-32.  The reference holds one vector per cell (128 cameras x 2048 x 1536 cells at configs[4]: 400 M vectors).
+// Here a cell is the head of a linked list in a shared pool, and the heads live in 32 x 32 tiles that are allocated when
+// the first patch lands in them: setCellMaps touches a tile table (3 K entries per 12.6 MP camera), not 1.6 GB of heads.
+class CellMap {
 public:
-    int width = 0, height = 0;
-    std::vector<int32_t> head;
-    void init(int w, int h) { width = w; height = h; head.assign((size_t)w * h, -1); }
+    static constexpr int kTile = 32, kShift = 5, kTileCells = kTile * kTile;
+    int width = 0, height = 0, tilesX = 0;
+    std::vector<int32_t> tileOf; // tile table: index into `heads` / kTileCells, or -1
+    std::vector<int32_t> heads;
+    void init(int w, int h)
+    {
+        width = w; height = h;
+        tilesX = (w + kTile - 1) >> kShift;
+        tileOf.assign((size_t)tilesX * ((h + kTile - 1) >> kShift), -1);
+        heads.clear();
+    }
     bool inMap(int x, int y) const { return !(x < 0 || y < 0 || x >= width || y >= height); } // cellmap.cpp:18-23
+    bool tileEmpty(int x, int y) const { return tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)] < 0; }
+    // first pool entry of the cell, -1 if it is empty
+    int32_t first(int x, int y) const
+    {
+        const int32_t t = tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)];
+        return t < 0 ? -1 : heads[(size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1))];
+    }
+    // the cell's head for writing (valid until the next call that allocates a tile)
+    int32_t *slot(int x, int y)
+    {
+        int32_t &t = tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)];
+        if (t < 0) {
+            t = (int32_t)(heads.size() / kTileCells);
+            heads.resize(heads.size() + kTileCells, -1);
+        }
+        return &heads[(size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1))];
+    }
 };
 
 struct Unit { int id, slot, j; };        // expansion attempt: neighbour j of camera slot `slot` of parent `id`
@@ -195,7 +223,7 @@ struct pais_mvs {
     int cellCount(const CellMap &m, int x, int y) const
     {
         int n = 0;
-        for (int e = m.head[(size_t)y * m.width + x]; e >= 0; e = pool[e].next) ++n;
+        for (int e = m.first(x, y); e >= 0; e = pool[e].next) ++n;
         return n;
     }
     bool cellInsert(CellMap &m, int x, int y, int id) // cellmap.cpp:25-29
@@ -204,16 +232,17 @@ struct pais_mvs {
         int e;
         if (freeEntry >= 0) { e = freeEntry; freeEntry = pool[e].next; }
         else { e = (int)pool.size(); pool.push_back(CellEntry()); }
-        int32_t &h = m.head[(size_t)y * m.width + x];
+        int32_t *h = m.slot(x, y);
         pool[e].id = id;
-        pool[e].next = h;
-        h = e;
+        pool[e].next = *h;
+        *h = e;
         return true;
     }
     bool cellDrop(CellMap &m, int x, int y, int id) // cellmap.cpp:31-38
     {
         if (!m.inMap(x, y)) return false;
-        int32_t *link = &m.head[(size_t)y * m.width + x];
+        if (m.first(x, y) < 0) return false;
+        int32_t *link = m.slot(x, y);
         while (*link >= 0) {
             int e = *link;
             if (pool[e].id == id) {
@@ -242,13 +271,13 @@ struct pais_mvs {
     bool skipNeighborCell(const CellMap &m, int x, int y, const pais_patch_result &ref, int beforeRound) const
     {
         int pthNum = 0;
-        for (int e = m.head[(size_t)y * m.width + x]; e >= 0; e = pool[e].next) {
+        for (int e = m.first(x, y); e >= 0; e = pool[e].next) {
             const HostPatch *p = patches[pool[e].id];
             if (beforeRound >= 0 && p && p->born >= beforeRound) continue;
             ++pthNum;
         }
         if (pthNum >= cfg.maxCellPatchNum) return true;
-        for (int e = m.head[(size_t)y * m.width + x]; e >= 0; e = pool[e].next) {
+        for (int e = m.first(x, y); e >= 0; e = pool[e].next) {
             const HostPatch *p = patches[pool[e].id];
             if (!p) continue;
             if (beforeRound >= 0 && p->born >= beforeRound) continue;
@@ -346,7 +375,7 @@ struct pais_mvs {
             if (!m.inMap(cx, cy)) continue;
             bool found = false;
             int n = 0;
-            for (int e = m.head[(size_t)cy * m.width + cx]; e >= 0; e = pool[e].next) {
+            for (int e = m.first(cx, cy); e >= 0; e = pool[e].next) {
                 ++n;
                 if (pool[e].id == id) found = true;
             }
@@ -1085,7 +1114,7 @@ static void filter_prepare(pais_mvs *m)
 static void cell_ids(const pais_mvs *m, const CellMap &map, int x, int y, std::vector<int> &out)
 {
     out.clear();
-    for (int e = map.head[(size_t)y * map.width + x]; e >= 0; e = m->pool[e].next) out.push_back(m->pool[e].id);
+    for (int e = map.first(x, y); e >= 0; e = m->pool[e].next) out.push_back(m->pool[e].id);
     std::reverse(out.begin(), out.end());
 }
 
@@ -1099,7 +1128,8 @@ extern "C" int pais_mvs_cell_filtering(pais_mvs *m)
         CellMap &map = m->cellMaps[ci];
         for (int x = 0; x < map.width; ++x) {
             for (int y = 0; y < map.height; ++y) {
-                if (map.head[(size_t)y * map.width + x] < 0) continue;
+                if (map.tileEmpty(x, y)) { y |= CellMap::kTile - 1; continue; } // same visiting order, empty tiles skipped
+                if (map.first(x, y) < 0) continue;
                 cell_ids(m, map, x, y, cell);
                 removeIdx.clear();
                 const int pthNum = (int)cell.size();
@@ -1139,7 +1169,7 @@ extern "C" int pais_mvs_visibility_filtering(pais_mvs *m)
             const int cx = (int)(r.imgPoint[i][0] / m->cfg.cellSize), cy = (int)(r.imgPoint[i][1] / m->cfg.cellSize);
             const CellMap &map = m->cellMaps[r.cam_idx[i]];
             if (!map.inMap(cx, cy)) continue; // getCell on an outside cell is undefined in the reference; loaded patches project inside
-            for (int e = map.head[(size_t)cy * map.width + cx]; e >= 0; e = m->pool[e].next) {
+            for (int e = map.first(cx, cy); e >= 0; e = m->pool[e].next) {
                 if (m->pool[e].id == (int)id) continue;
                 const HostPatch *q = m->patches[m->pool[e].id];
                 if (!q) continue;
@@ -1165,7 +1195,8 @@ extern "C" int pais_mvs_neighbor_cell_filtering(pais_mvs *m, double neighbor_rat
         CellMap &map = m->cellMaps[ci];
         for (int x = 0; x < map.width; ++x) {
             for (int y = 0; y < map.height; ++y) {
-                if (map.head[(size_t)y * map.width + x] < 0) continue;
+                if (map.tileEmpty(x, y)) { y |= CellMap::kTile - 1; continue; } // same visiting order, empty tiles skipped
+                if (map.first(x, y) < 0) continue;
                 cell_ids(m, map, x, y, cell);
                 removeIdx.clear();
                 const int nx[9] = {x, x - 1, x + 1, x - 1, x + 1, x + 1, x, x - 1, x};
@@ -1176,7 +1207,7 @@ extern "C" int pais_mvs_neighbor_cell_filtering(pais_mvs *m, double neighbor_rat
                     int neighborPthSum = 0, neighborPthNum = 0;
                     for (int j = 0; j < 9; ++j) {
                         if (!map.inMap(nx[j], ny[j])) continue;
-                        for (int e = map.head[(size_t)ny[j] * map.width + nx[j]]; e >= 0; e = m->pool[e].next) {
+                        for (int e = map.first(nx[j], ny[j]); e >= 0; e = m->pool[e].next) {
                             ++neighborPthSum;
                             const HostPatch *q = m->patches[m->pool[e].id];
                             if (!q) continue;
