@@ -7,7 +7,8 @@ from pais_mvs_amd import synth, _lib
 from pais_mvs_amd.config import readme_config
 from pais_mvs_amd.context import Context, make_candidate
 sc = synth.pawn_scene(n_seeds=64, build_edges=False)
-cfg = readme_config()
+# MB_CFG='adaptiveDifferenceEnable=0,...': timing experiments with parts of the cost switched off
+cfg = readme_config(**{k: bool(int(v)) for k, v in (kv.split('=') for kv in os.environ.get('MB_CFG', '').split(',') if kv)})
 ctx = Context(cfg, sc.cameras, 0, 42)
 # refine the seeds on the GPU to get realistic patch states
 cands = []
