@@ -572,41 +572,59 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         if (nRun < S * minPer) S = (nRun + minPer - 1) / minPer;
         if (S < 1) S = 1;
         if (S > 1) HIPCHK(hipEventRecord(ctx->forkEv, ctx->stream));
+        // slice 0 stays on the context's own stream, the others fork to sub-streams and join back
+        struct Slice { int lo, hi, parts; hipStream_t st; bool own; };
+        Slice sl[16];
+        int nSl = 0;
         for (int sI = 0; sI < S; ++sI) {
-            const int lo = (int)((long)nRun * sI / S), hi = (int)((long)nRun * (sI + 1) / S);
-            if (hi <= lo) continue;
-            // slice 0 stays on the context's own stream, the others fork to sub-streams and join back
-            const bool own = (S == 1) || (sI == 0);
-            hipStream_t st = own ? ctx->stream : ctx->sub[sI - 1];
-            if (!own) HIPCHK(hipStreamWaitEvent(st, ctx->forkEv, 0));
-            unsigned char *stp = ctx->d_psoStates + SB * (size_t)lo;
+            Slice q;
+            q.lo = (int)((long)nRun * sI / S);
+            q.hi = (int)((long)nRun * (sI + 1) / S);
+            if (q.hi <= q.lo) continue;
+            q.own = (S == 1) || (sI == 0);
+            q.st = q.own ? ctx->stream : ctx->sub[sI - 1];
+            if (!q.own) HIPCHK(hipStreamWaitEvent(q.st, ctx->forkEv, 0));
             // waves per evaluation: a slice that leaves the GPU mostly empty is bound by the latency of
             // one evaluation wave, so share each evaluation among 4 (2) waves while they all stay resident
-            int parts = 1;
+            q.parts = 1;
             if (useIter) {
-                const long waves = (long)(hi - lo) * Nmax, resident = (long)((double)ctx->numCUs * 16 * ctx->partFill);
-                parts = ctx->evalParts > 0 ? ctx->evalParts : (waves * 4 <= resident ? 4 : (waves * 2 <= resident ? 2 : 1));
+                const long waves = (long)(q.hi - q.lo) * Nmax, resident = (long)((double)ctx->numCUs * 16 * ctx->partFill);
+                q.parts = ctx->evalParts > 0 ? ctx->evalParts : (waves * 4 <= resident ? 4 : (waves * 2 <= resident ? 2 : 1));
             }
-            for (int it = 0; it <= maxIt; ++it) {
+            sl[nSl++] = q;
+        }
+        // enqueued iteration by iteration across the slices: every sub-stream has work from the start (slice by slice, the
+        // second slice would begin one host enqueue pass -- 62 launches -- after the first)
+        for (int it = 0; it <= maxIt; ++it) {
+            for (int k = 0; k < nSl; ++k) {
+                const Slice &q = sl[k];
+                unsigned char *stp = ctx->d_psoStates + SB * (size_t)q.lo;
                 Timed te; // events on the stream the kernel is launched on
-                if (te.begin(ctx, st, &ctx->evEval)) return -2;
+                if (te.begin(ctx, q.st, &ctx->evEval)) return -2;
                 if (useIter)
-                    HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat,
-                                                 it, 0, parts, ctx->d_evalBlocks, ctx->d_win, st));
+                    HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, q.lo, q.hi, Nmax, Kmax, d_out,
+                                                 ctx->d_stat, it, 0, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
                 else
-                    HIPCHK(pais_launch::pso_eval(sc, stp, hi - lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)lo, ctx->d_win + WB * (size_t)lo, st));
+                    HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
+                                                 ctx->d_win + WB * (size_t)q.lo, q.st));
                 if (te.end()) return -2;
                 ctx->evalLaunches++;
-                if (!useIter) HIPCHK(pais_launch::pso_step(sc, d_out + lo, stp, hi - lo, Nmax, ctx->d_stat, st));
+                if (!useIter) HIPCHK(pais_launch::pso_step(sc, d_out + q.lo, stp, q.hi - q.lo, Nmax, ctx->d_stat, q.st));
             }
+        }
+        for (int k = 0; k < nSl; ++k) {
+            const Slice &q = sl[k];
             // the launch after the last possible iteration only ends the runs still active
             if (useIter)
-                HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, lo, hi, Nmax, Kmax, d_out, ctx->d_stat,
-                                             maxIt + 1, 1, parts, ctx->d_evalBlocks, ctx->d_win, st));
-            if (!own) {
-                HIPCHK(hipEventRecord(ctx->subDone[sI - 1], st));
-                HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
-            }
+                HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, q.lo, q.hi, Nmax, Kmax, d_out,
+                                             ctx->d_stat, maxIt + 1, 1, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
+        }
+        for (int sI = 1; sI < S; ++sI) {
+            bool used = false;
+            for (int k = 0; k < nSl; ++k) used = used || (sl[k].st == ctx->sub[sI - 1]);
+            if (!used) continue;
+            HIPCHK(hipEventRecord(ctx->subDone[sI - 1], ctx->sub[sI - 1]));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
         }
         if (tp.end()) return -2;
         ctx->psoLaunches++;

@@ -53,6 +53,12 @@ struct HostPatch { // AbstractPatch fields the expansion loop reads (abstractpat
     int id;
     int born;    // expansion round in which it was inserted (-1: seed / before expansion)
     bool expanded;
+    // what every child of this patch inherits (Patch(center, parent), patch.cpp:36-43): the normal in spherical form
+    // and the cameras of expandVisibleCamera (:723-761) -- functions of the parent's normal and cameras alone, built
+    // when the first child is made (childCams < 0: not yet)
+    int childCams = -1;
+    double childNormalS[2];
+    int childCamIdx[PAIS_MAX_VIS];
 };
 
 struct CellEntry { int id, next; };
@@ -307,13 +313,21 @@ struct pais_mvs {
     }
 
     // ---- Patch(center, parent) constructor, patch.cpp:36-43 incl. expandVisibleCamera :723-761
-    void makeExpandCandidate(const pais_patch_result &parent, const double *center, uint64_t key, pais_candidate *c)
+    void makeExpandCandidate(HostPatch *hp, const double *center, uint64_t key, pais_candidate *c)
     {
+        const pais_patch_result &parent = hp->r;
         memset(c, 0, sizeof(*c));
         for (int i = 0; i < 3; ++i) { c->center[i] = center[i]; c->normal[i] = parent.normal[i]; }
-        pais::normal2spherical(c->normal, c->normalS); // setNormal(Vec3d), abstractpatch.cpp:43-46
         c->key = key;
         c->type = PAIS_TYPE_EXPAND;
+        if (hp->childCams >= 0) { // a sibling was made before: same normal, same cameras
+            c->normalS[0] = hp->childNormalS[0];
+            c->normalS[1] = hp->childNormalS[1];
+            c->num_cam = hp->childCams;
+            for (int i = 0; i < hp->childCams; ++i) c->cam_idx[i] = hp->childCamIdx[i];
+            return;
+        }
+        pais::normal2spherical(c->normal, c->normalS); // setNormal(Vec3d), abstractpatch.cpp:43-46
         int exp[PAIS_MAX_VIS * 2];
         int n = 0;
         for (int i = 0; i < (int)cams.size(); ++i) {
@@ -335,6 +349,10 @@ struct pais_mvs {
         if (n > PAIS_MAX_VIS) n = PAIS_MAX_VIS;
         c->num_cam = n; // < minCamNum => refine() drops it (patch.cpp:118-123), as `drop` would
         for (int i = 0; i < n; ++i) c->cam_idx[i] = exp[i];
+        hp->childCams = n;
+        hp->childNormalS[0] = c->normalS[0];
+        hp->childNormalS[1] = c->normalS[1];
+        for (int i = 0; i < n; ++i) hp->childCamIdx[i] = exp[i];
     }
 
     // ---- MVS::runtimeFiltering, mvs.cpp:838-898
@@ -1001,7 +1019,7 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
         double center[3];
         m->expansionCenter(camI, pr, x, y, center);
         pais_candidate rec;
-        m->makeExpandCandidate(pr, center, pais_child_key(pr.key, camI, x, y), &rec);
+        m->makeExpandCandidate(m->patches[u.id], center, pais_child_key(pr.key, camI, x, y), &rec);
         m->cands.push_back(Candidate{u, camI, x, y});
         m->candRecs.push_back(rec);
     };
