@@ -155,6 +155,15 @@ typedef struct pais_patch_result {
     int32_t  ncc_tables;         /* setCorrelationTable() calls             */
 } pais_patch_result;
 
+/* pais_patch_result.stage of a returned record (other values are internal to a batch call).
+ * The scene half of MVS::runtimeFiltering (mvs.cpp:851-863: EVERY camera of the scene projects
+ * the centre inside its image, on a non-background pixel) depends on the record and the scene
+ * alone; the batch evaluates it on the device -- one lane per camera -- so that the host test
+ * that follows every refine (mvs.cpp:583) keeps only its cell-map half. */
+#define PAIS_DONE            0  /* finished; scene test not evaluated (dropped records, host-built records) */
+#define PAIS_DONE_IN_SCENE   5  /* finished, not dropped, the scene test passes */
+#define PAIS_DONE_OFF_SCENE  6  /* finished, not dropped, the scene test fails  */
+
 typedef struct pais_ctx pais_ctx;
 
 /* Create the per-scene context on HIP device `device`: copies config, camera
@@ -179,6 +188,10 @@ int  pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_state *sta
 /* For each candidate: Patch::refine() followed by Patch::removeInvisibleCamera()
  * (mvs.cpp:214-215 / 573-574).  Host pointers; synchronous at return. */
 int  pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *cands, pais_patch_result *out);
+/* Same without the last host copy: *view points at the n records in the context's
+ * pinned staging buffer, valid until the next batch call on this context (what
+ * MVS::refineSeedPatches / expansionPatches need: they read every record once). */
+int  pais_refine_batch_view(pais_ctx *ctx, int n, const pais_candidate *cands, const pais_patch_result **view);
 
 /* Same, with device pointers (results stay in HBM, e.g. as the send buffer of
  * the per-round RCCL all-gather).  Work is enqueued on the context's stream

@@ -641,11 +641,13 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     return 0;
 }
 
-extern "C" int pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *cands, pais_patch_result *out)
+// pais_refine_batch without the last copy: *view points at the context's pinned staging buffer (valid until the next batch
+// of this context).  The drivers in pais_mvs.hip commit straight from it (2.9 MB of records per large round).
+extern "C" int pais_refine_batch_view(pais_ctx *ctx, int n, const pais_candidate *cands, const pais_patch_result **view)
 {
     if (!ctx || n < 0) return fail_msg("pais_refine_batch: bad argument");
     if (n == 0) return 0;
-    if (!cands || !out) return fail_msg("pais_refine_batch: null pointer");
+    if (!cands || !view) return fail_msg("pais_refine_batch: null pointer");
     HIPCHK(hipSetDevice(ctx->device));
     int Kmax = 1, hasSeeds = 0;
     for (int i = 0; i < n; ++i) {
@@ -677,7 +679,17 @@ extern "C" int pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *can
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->h_recs, ctx->d_recs, sizeof(pais_patch_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    memcpy(out, ctx->h_recs, sizeof(pais_patch_result) * (size_t)n);
+    *view = ctx->h_recs;
+    return 0;
+}
+
+extern "C" int pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *cands, pais_patch_result *out)
+{
+    if (n > 0 && !out) return fail_msg("pais_refine_batch: null pointer");
+    const pais_patch_result *view = nullptr;
+    int rc = pais_refine_batch_view(ctx, n, cands, &view);
+    if (rc || n <= 0) return rc;
+    memcpy(out, view, sizeof(pais_patch_result) * (size_t)n);
     return 0;
 }
 

@@ -1316,7 +1316,27 @@ __global__ __launch_bounds__(64 * AFTER_WAVES) void k_after(DevScene sc, pais_pa
         } else {
             remove_invisible_camera(sc, st, hp, table, Hn, flag, rat, lane, wave); // mvs.cpp:215 / :574
             __syncthreads();
-            if (lead) st->stage = PAIS_STAGE_DONE;
+            // the scene half of MVS::runtimeFiltering (mvs.cpp:851-863) for the caller's insertPatch: one thread per camera
+            int finalStage = PAIS_DONE;
+            if (!st->dropped) {
+                bool off = false;
+                const double X[3] = {st->center[0], st->center[1], st->center[2]};
+                for (int i = threadIdx.x; i < sc.numCams; i += 64 * AFTER_WAVES) {
+                    const DevCamera &cam = sc.cams[i];
+                    double pt[2];
+                    project_raw(cam.R, cam.T, cam.focal, cam.pp, 1.0, X, pt);
+                    if (!in_image_d(pt, cam.w[0], cam.h[0])) {
+                        off = true;
+                    } else {
+                        // (the reference reads at(cvRound(y), cvRound(x)); defined as the edge pixel within half a pixel of the
+                        // right / bottom edge, as in the host statement)
+                        const int rx = min(cv_round(pt[0]), cam.w[0] - 1), ry = min(cv_round(pt[1]), cam.h[0] - 1);
+                        if (sc.imgBlob[cam.imgOff[0] + (size_t)ry * cam.w[0] + rx] == 0) off = true;
+                    }
+                }
+                finalStage = __syncthreads_or(off ? 1 : 0) ? PAIS_DONE_OFF_SCENE : PAIS_DONE_IN_SCENE;
+            }
+            if (lead) st->stage = finalStage;
         }
         __syncthreads();
         if (lead) {

@@ -56,9 +56,17 @@ struct HostPatch { // AbstractPatch fields the expansion loop reads (abstractpat
     // what every child of this patch inherits (Patch(center, parent), patch.cpp:36-43): the normal in spherical form
     // and the cameras of expandVisibleCamera (:723-761) -- functions of the parent's normal and cameras alone, built
     // when the first child is made (childCams < 0: not yet)
+    bool inScene = false; // a runtimeFiltering call has kept this patch: the camera loop (mvs.cpp:851-863) passes for it
     int childCams = -1;
     double childNormalS[2];
     int childCamIdx[PAIS_MAX_VIS];
+};
+
+// what skipNeighborCell reads of a patch, one cache line per patch in a dense array (a HostPatch is a 1.5 KB heap object;
+// the skip test runs for every neighbour cell of every active parent in every round)
+struct HotPatch {
+    double center[3], normal[3], correlation;
+    int born, alive;
 };
 
 struct CellEntry { int id, next; };
@@ -177,6 +185,8 @@ struct pais_mvs {
     std::vector<HostCamera> cams;
     std::vector<HostPatch *> patches; // index == id; nullptr once deleted  (map<int,Patch>, mvs.h:86)
     int alive = 0;
+    bool trustSceneStage = true;       // PAIS_HOST_SCENE_TEST=1: always evaluate the camera loop of runtimeFiltering on the host
+    std::vector<HotPatch> hot;         // hot[id]: dense copy of what skipNeighborCell reads of patches[id]
     std::vector<CellMap> cellMaps;     // mvs.h:88 (empty until setCellMaps)
     std::vector<CellEntry> pool;
     int freeEntry = -1;
@@ -276,19 +286,26 @@ struct pais_mvs {
     //      (patches inserted during it are ignored; cell-claim rule of R(B))
     bool skipNeighborCell(const CellMap &m, int x, int y, const pais_patch_result &ref, int beforeRound) const
     {
+        const int first = m.first(x, y);
+        if (first < 0) return false;
         int pthNum = 0;
-        for (int e = m.first(x, y); e >= 0; e = pool[e].next) {
-            const HostPatch *p = patches[pool[e].id];
-            if (beforeRound >= 0 && p && p->born >= beforeRound) continue;
+        for (int e = first; e >= 0; e = pool[e].next) {
+            const HotPatch &p = hot[pool[e].id];
+            if (beforeRound >= 0 && p.alive && p.born >= beforeRound) continue;
             ++pthNum;
         }
         if (pthNum >= cfg.maxCellPatchNum) return true;
-        for (int e = m.first(x, y); e >= 0; e = pool[e].next) {
-            const HostPatch *p = patches[pool[e].id];
-            if (!p) continue;
-            if (beforeRound >= 0 && p->born >= beforeRound) continue;
-            if (p->r.correlation > cfg.minCorrelation) return true;
-            if (isNeighbor(ref, p->r)) return true;
+        for (int e = first; e >= 0; e = pool[e].next) {
+            const HotPatch &p = hot[pool[e].id];
+            if (!p.alive) continue;
+            if (beforeRound >= 0 && p.born >= beforeRound) continue;
+            if (p.correlation > cfg.minCorrelation) return true;
+            // Patch::isNeighbor (above) on the dense copy
+            const double d[3] = {ref.center[0] - p.center[0], ref.center[1] - p.center[1], ref.center[2] - p.center[2]};
+            double dist = 0;
+            dist += fabs(dot3h(d, ref.normal));
+            dist += fabs(dot3h(d, p.normal));
+            if (dist <= neighborRadius) return true;
         }
         return false;
     }
@@ -356,7 +373,10 @@ struct pais_mvs {
     }
 
     // ---- MVS::runtimeFiltering, mvs.cpp:838-898
-    bool runtimeFiltering(const pais_patch_result &p, int id) const
+    //      scene: what is known of the camera loop (:851-863), a function of the record and the scene alone:
+    //      0 nothing -- evaluated here; 1 it passes (the device evaluated it, or the patch was kept by an earlier call);
+    //      2 it fails
+    bool runtimeFiltering(const pais_patch_result &p, int id, int scene = 0) const
     {
         if (p.dropped) return false;
         if (p.num_cam < cfg.minCamNum) return false;
@@ -367,8 +387,9 @@ struct pais_mvs {
         if (std::isnan(p.priority)) return false;
         if (std::isnan(p.correlation)) return false;
         if (p.correlation < cfg.minCorrelation) return false;
+        if (scene == 2) return false;
         double pt[2];
-        for (int i = 0; i < (int)cams.size(); i++) {
+        for (int i = 0; scene == 0 && i < (int)cams.size(); i++) {
             if (!project0(i, p.center, pt)) return false;
             const HostCamera &cam = cams[i];
             // mvs.cpp:860 reads at(cvRound(y), cvRound(x)) after 0 <= pt < dim only: within half a pixel of the right /
@@ -412,6 +433,12 @@ struct pais_mvs {
         hp->expanded = false;
         hp->born = curRound;
         patches.push_back(hp);
+        HotPatch h;
+        for (int i = 0; i < 3; ++i) { h.center[i] = r.center[i]; h.normal[i] = r.normal[i]; }
+        h.correlation = r.correlation;
+        h.born = hp->born;
+        h.alive = 1;
+        hot.push_back(h);
         ++alive;
         return hp->id;
     }
@@ -474,16 +501,25 @@ struct pais_mvs {
         }
         delete p;
         patches[id] = nullptr;
+        hot[id].alive = 0;
         --alive;
         st.patches_deleted++;
+    }
+
+    // what the batch call reports of the scene half of runtimeFiltering (include/pais_hip.h PAIS_DONE_*)
+    int sceneKnowledge(const pais_patch_result &r) const
+    {
+        if (!trustSceneStage) return 0;
+        return r.stage == PAIS_DONE_IN_SCENE ? 1 : (r.stage == PAIS_DONE_OFF_SCENE ? 2 : 0);
     }
 
     // ---- MVS::insertPatch, mvs.cpp:579-601
     bool insertPatch(const pais_patch_result &r)
     {
         const int newId = (int)patches.size();
-        if (!runtimeFiltering(r, newId)) return false;
+        if (!runtimeFiltering(r, newId, sceneKnowledge(r))) return false;
         int id = storePatch(r);
+        patches[id]->inScene = true;
         queuePush(id);
         for (int i = 0; i < r.num_cam; ++i) {
             int cx = (int)(r.imgPoint[i][0] / cfg.cellSize);
@@ -550,6 +586,7 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
 {
     if (!cfg || !cams || !out || num_cams <= 0) return mfail("pais_mvs_create: bad argument");
     pais_mvs *m = new pais_mvs();
+    if (const char *e = getenv("PAIS_HOST_SCENE_TEST")) m->trustSceneStage = atoi(e) == 0;
     if (const char *e = getenv("PAIS_THIN_FRONT")) m->thinFront = atoi(e) < 0 ? 0 : atoi(e); // tuning sweeps (scripts/)
     memset(&m->st, 0, sizeof(m->st));
     m->cfg = *cfg;
@@ -591,6 +628,7 @@ extern "C" int pais_mvs_reset(pais_mvs *m)
     if (!m) return mfail("bad argument");
     for (auto *p : m->patches) delete p;
     m->patches.clear();
+    m->hot.clear();
     m->alive = 0;
     m->cellMaps.clear();
     m->pool.clear();
@@ -724,11 +762,14 @@ extern "C" int pais_mvs_add_seed_measured(pais_mvs *m, const double center[3], i
     } while (0)
 
 // n candidates -> n records on one rank: the GPU context, or the record source of a GPU-less driver
-static int refine_local(pais_mvs *m, int n, const pais_candidate *c, pais_patch_result *out, int has_seeds)
+// view != nullptr: the records may stay where they were produced (*view: valid until the next batch); else -> out
+static int refine_local(pais_mvs *m, int n, const pais_candidate *c, pais_patch_result *out, int has_seeds,
+                        const pais_patch_result **view = nullptr)
 {
     if (n <= 0) return 0;
+    if (view) *view = out;
     if (m->ctx) {
-        int rc = pais_refine_batch(m->ctx, n, c, out);
+        int rc = view ? pais_refine_batch_view(m->ctx, n, c, view) : pais_refine_batch(m->ctx, n, c, out);
         if (rc) g_mvs_err = pais_last_error();
         return rc;
     }
@@ -747,18 +788,20 @@ static int all_gather_host(pais_mvs *m, const void *send, void *recv, size_t byt
 }
 
 // The batch entry of the drivers: one rank -> pais_refine_batch; several ranks -> shard, refine, all-gather.
-static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_result *out, int has_seeds)
+// *view: where the n records are (out, or a pinned staging buffer that stays valid until the next batch)
+static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_result *out, int has_seeds, const pais_patch_result **view)
 {
+    *view = out;
     if (n <= 0) return 0;
     const int world = m->world;
-    if (world <= 1 && !m->nccl && !m->gatherCb) return refine_local(m, n, c, out, has_seeds);
+    if (world <= 1 && !m->nccl && !m->gatherCb) return refine_local(m, n, c, out, has_seeds, view);
     // a batch of fewer than replicateBelow evaluation waves per PSO iteration (candidates x particles; seeds run twice the
     // particles) is latency bound on ONE GPU: its per-iteration launches take one evaluation wave's latency whatever the
     // number of GPUs, so splitting it buys nothing and the exchange costs -- replicated, no collective
     const long wavesPerIter = (long)n * m->cfg.particleNum * (has_seeds ? 2 : 1);
     if (wavesPerIter < (long)m->replicateBelow) {
         m->st.batches_replicated++;
-        return refine_local(m, n, c, out, has_seeds);
+        return refine_local(m, n, c, out, has_seeds, view);
     }
     m->st.batches_sharded++;
     const int per = (n + world - 1) / world;
@@ -819,7 +862,7 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
     MHIP(hipMemcpyAsync(m->h_allR, m->d_allR, SZ_R * (size_t)n, hipMemcpyDeviceToHost, st));
     MHIP(hipStreamSynchronize(st));
     m->st.exchange_ms += now_ms() - t0;
-    memcpy(out, m->h_allR, SZ_R * (size_t)n);
+    *view = m->h_allR;
     return 0;
 }
 
@@ -928,9 +971,16 @@ extern "C" int pais_mvs_seed_commit(pais_mvs *m, const pais_patch_result *result
         const int id = m->seedIds[k];
         HostPatch *p = m->patches[id];
         p->r = results[k];
+        p->childCams = -1;
+        {
+            HotPatch &h = m->hot[id];
+            for (int i = 0; i < 3; ++i) { h.center[i] = p->r.center[i]; h.normal[i] = p->r.normal[i]; }
+            h.correlation = p->r.correlation;
+        }
         m->st.seeds_refined++;
         m->st.pso_evals_effective += results[k].pso_evals;
-        if (!m->runtimeFiltering(p->r, id)) m->deletePatch(id); // :217-220
+        if (!m->runtimeFiltering(p->r, id, m->sceneKnowledge(p->r))) m->deletePatch(id); // :217-220
+        else p->inScene = true;
     }
     m->setNeighborRadius(); // :230
     m->seedIds.clear();
@@ -947,10 +997,11 @@ extern "C" int pais_mvs_refine_seed_patches(pais_mvs *m)
     if (!m->ctx && !m->recordSource) return mfail("pais_mvs_refine_seed_patches: this driver was created without a GPU context");
     m->results.resize((size_t)n);
     double t0 = now_ms();
-    rc = refine_any(m, n, c, m->results.data(), 1);
+    const pais_patch_result *recs = nullptr;
+    rc = refine_any(m, n, c, m->results.data(), 1, &recs);
     m->st.gpu_refine_ms += now_ms() - t0;
     if (rc) return rc;
-    return pais_mvs_seed_commit(m, m->results.data(), n);
+    return pais_mvs_seed_commit(m, recs, n);
 }
 
 extern "C" int pais_mvs_expansion_begin(pais_mvs *m)
@@ -994,7 +1045,8 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
         HostPatch *p = m->patches[id];
         p->expanded = true;                                   // :250
         m->st.parents_popped++;
-        if (!m->runtimeFiltering(p->r, p->id)) { m->deletePatch(id); continue; } // :255-260
+        // (a patch kept by the runtimeFiltering of its insertion: the camera loop cannot answer otherwise now)
+        if (!m->runtimeFiltering(p->r, p->id, (m->trustSceneStage && p->inScene) ? 1 : 0)) { m->deletePatch(id); continue; } // :255-260
         m->active.push_back(Active{id, 0});
     }
     if (m->active.empty() && m->deferred.empty()) return 1;
@@ -1289,6 +1341,7 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
     int rounds = 0;
     for (;;) {
         const pais_candidate *c;
+        const pais_patch_result *recs = m->results.data();
         int n;
         rc = pais_mvs_round_begin(m, B, &c, &n);
         if (rc < 0) return rc;
@@ -1296,11 +1349,11 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         m->results.resize((size_t)(n > 0 ? n : 1));
         if (n > 0) {
             double t0 = now_ms();
-            rc = refine_any(m, n, c, m->results.data(), 0);
+            rc = refine_any(m, n, c, m->results.data(), 0, &recs);
             m->st.gpu_refine_ms += now_ms() - t0;
             if (rc) return rc;
         }
-        rc = pais_mvs_round_commit(m, m->results.data(), n);
+        rc = pais_mvs_round_commit(m, n > 0 ? recs : m->results.data(), n);
         if (rc) return rc;
         if (max_rounds > 0 && ++rounds >= max_rounds) break;
     }

@@ -831,3 +831,56 @@ def test_dome_full_size_bounded_rounds():
         assert len(set(p.cams())) == p.num_cam and p.ref_cam in p.cams()
     assert _surface_error(scene, ps, max(1, len(ps) // 200)) < 2e-3
     m.close()
+
+
+@pytest.mark.gpu
+def test_scene_half_of_runtime_filtering_on_the_device(pawn_small, monkeypatch):
+    """include/pais_hip.h PAIS_DONE_*: the camera loop of MVS::runtimeFiltering (mvs.cpp:851-863) is evaluated by the batch
+    call, one lane per camera; the drivers then run only the cell-map half on the host.  Same cloud as with the host
+    evaluating everything, and every flag of a seed batch equals a numpy statement of the loop."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import Context
+    from pais_mvs_amd.mvs import MVS
+    cfg = readme_config()
+
+    def cloud():
+        m = MVS(cfg, pawn_small.cameras, device=0, seed=42)
+        for X, vis in pawn_small.seeds:
+            m.add_seed(X, vis)
+        m.refineSeedPatches()
+        m.expansionPatches(64, 12)
+        out = m.cloud().tobytes(), m.stats().candidates_effective
+        m.close()
+        return out
+
+    ref = cloud()
+    monkeypatch.setenv("PAIS_HOST_SCENE_TEST", "1")
+    assert cloud() == ref
+    monkeypatch.delenv("PAIS_HOST_SCENE_TEST")
+
+    S = common.oracle_scene(cfg, pawn_small)
+    _, cands = common.seed_candidates(S, pawn_small)
+    ctx = Context(cfg, pawn_small.cameras, device=0, seed=42)
+    res = ctx.refine_batch(cands)
+    seen = set()
+    for r in res:
+        if r.dropped:
+            assert r.stage == 0
+            continue
+        ok = True
+        for cam in pawn_small.cameras:
+            q = cam.rotation @ np.array(r.center[:]) + cam.translation
+            x = cam.focal[0] * q[0] / q[2] + cam.principle_point[0]
+            y = cam.focal[1] * q[1] / q[2] + cam.principle_point[1]
+            h, w = cam.image.shape
+            if not (0 <= x < w and 0 <= y < h):
+                ok = False
+                break
+            rx, ry = min(int(np.rint(x)), w - 1), min(int(np.rint(y)), h - 1)
+            if cam.image[ry, rx] == 0:
+                ok = False
+                break
+        assert r.stage == (5 if ok else 6), (r.stage, ok)
+        seen.add(r.stage)
+    assert 5 in seen
+    ctx.close()
