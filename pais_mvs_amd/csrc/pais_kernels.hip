@@ -81,6 +81,15 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// value of lane `src` for a WAVE-UNIFORM src (a loop counter, this wave's particle, the winner of a wave-wide selection):
+// two v_readlane_b32 through an SGPR index instead of two ds_bpermute_b32 through the LDS crossbar -- the step replay of
+// k_pso_iter is chains of such broadcasts (one per particle and quantity), each a ~130-cycle round trip as a bpermute
+__device__ __forceinline__ double lane_get(double v, int src)
+{
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), s), hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -780,7 +789,7 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
     const double pw = 1.2, gw = 1.5, lw = 1.0, nw = 1.0; // psosolver.h:110
     const double pVecW = pw * u[0], gVecW = gw * u[1], lVecW = lw * u[2], nVecW = nw * u[3];
     const bool pv = lane < N;
-    const double pp0 = __shfl(pb[0], i, 64), pp1 = __shfl(pb[1], i, 64), pp2 = __shfl(pb[2], i, 64);
+    const double pp0 = lane_get(pb[0], i), pp1 = lane_get(pb[1], i), pp2 = lane_get(pb[2], i);
     // getLocalBest: the localK nearest pBests by (squared distance, index); among them the first strict minimum
     // of pBestFitness in selection order
     double dj;
@@ -795,25 +804,25 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
     }
     int rank = 0;
     for (int j = 0; j < N; ++j) {
-        const double o = __shfl(dj, j, 64);
+        const double o = lane_get(dj, j);
         rank += (o < dj || (o == dj && j < lane)) ? 1 : 0;
     }
     const bool sel = pv && rank < localK;
     const int w = wave_argmin_lex(sel && pbf < DBL_MAX, pbf, rank * 64 + lane);
     const int lIdx = (w < 0) ? i : (w & 63);
     // setNearNeighborBest: per dimension the first maximum of the fitness-distance ratio
-    const double fitI = __shfl(fitj, i, 64);
+    const double fitI = lane_get(fitj, i);
     for (int d = 0; d < 3; ++d) {
-        const double pd = __shfl(pos[d], i, 64);
+        const double pd = lane_get(pos[d], i);
         const double FDR = (fitI - pbf) / fabs(pd - pb[d]);
         const bool cand = pv && lane != i && FDR > -DBL_MAX;
         const int wn = wave_argmin_lex(cand, -FDR, lane);
-        const double o = __shfl(pb[d], wn < 0 ? 0 : wn, 64);
+        const double o = lane_get(pb[d], wn < 0 ? 0 : wn);
         outNb[d] = (wn < 0) ? nbI[d] : o;
     }
     for (int d = 0; d < 3; ++d) {
-        double p = __shfl(pos[d], i, 64);
-        const double pbi = __shfl(pb[d], i, 64), pbl = __shfl(pb[d], lIdx, 64);
+        double p = lane_get(pos[d], i);
+        const double pbi = lane_get(pb[d], i), pbl = lane_get(pb[d], lIdx);
         double v = iw * vecI[d] + pVecW * (pbi - p) + gVecW * (gB[d] - p) + lVecW * (pbl - p) + nVecW * (outNb[d] - p);
         outV[d] = v;
         p += v;
@@ -868,6 +877,11 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *stat
         const int jl = lane < Nmax ? lane : 0;
         const int active = hd->active, N = hd->N, maxIt = hd->maxIt;
         const PsoState::IterDyn dr = hd->dyn[(L > 0 ? L - 1 : 0) & 1];
+        // (what only moveParticles reads is requested here too: behind the convergence test it would be a second round trip)
+        const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
+        const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
+        const uint64_t streamBase = hd->streamBase;
+        const int runIdx = hd->run, localK = hd->localK;
         double pos[3], pb[3];
         for (int d = 0; d < 3; ++d) {
             pos[d] = Rb.pos[jl][d];
@@ -903,7 +917,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *stat
                 // initFitness (:112-119) + run(): gBest = particles[0].pBest; updateGbest (:137-149)
                 pbf = fitj;
                 g = 0;
-                gf = __shfl(pbf, 0, 64);
+                gf = lane_get(pbf, 0);
                 iw = dr.iw;
                 it = 0;
             } else {
@@ -921,31 +935,31 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *stat
                 it = dr.iteration + 1;
             }
             for (int j = 0; j < N; ++j) {
-                const double v = __shfl(pbf, j, 64);
+                const double v = lane_get(pbf, j);
                 if (v <= gf) {
                     gf = v;
                     g = j;
                 }
             }
-            const double gB[3] = {__shfl(pb[0], g, 64), __shfl(pb[1], g, 64), __shfl(pb[2], g, 64)};
+            const double gB[3] = {lane_get(pb[0], g), lane_get(pb[1], g), lane_get(pb[2], g)};
             // loop head of run(): `iteration < maxIteration`, then the convergence break (:293-297)
             bool finished = it >= maxIt;
             if (!finished) {
                 const double a0 = fabs(pos[0] - gB[0]), a1 = fabs(pos[1] - gB[1]), a2 = fabs(pos[2] - gB[2]);
                 double disp = 0;
                 for (int j = 0; j < N; ++j) {
-                    disp += __shfl(a0, j, 64);
-                    disp += __shfl(a1, j, 64);
-                    disp += __shfl(a2, j, 64);
+                    disp += lane_get(a0, j);
+                    disp += lane_get(a1, j);
+                    disp += lane_get(a2, j);
                 }
                 disp /= (double)(3 * N);
                 if (disp < 0.01) {
                     const double v0 = fabs(Rb.vec[jl][0]), v1 = fabs(Rb.vec[jl][1]), v2 = fabs(Rb.vec[jl][2]);
                     double vel = 0;
                     for (int j = 0; j < N; ++j) {
-                        vel += __shfl(v0, j, 64);
-                        vel += __shfl(v1, j, 64);
-                        vel += __shfl(v2, j, 64);
+                        vel += lane_get(v0, j);
+                        vel += lane_get(v1, j);
+                        vel += lane_get(v2, j);
                     }
                     vel /= (double)(3 * N);
                     finished = vel < 0.01;
@@ -985,15 +999,13 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *stat
                 continue;
             }
             // moveParticles (:220-265) for iteration `it`, own particle only
-            const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
-            const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
             double u[4];
             const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
-            for (int q = 0; q < 4; ++q) u[q] = uniform_from(hd->streamBase, (uint32_t)hd->run, k0 + q);
+            for (int q = 0; q < 4; ++q) u[q] = uniform_from(streamBase, (uint32_t)runIdx, k0 + q);
             double nP[3], nV[3], nNb[3];
-            pso_move_own(i, N, hd->localK, iw, u, pos, pb, fitj, pbf, lane, gB, rl, ru, vecI, nbI, nP, nV, nNb);
-            const double pbI[3] = {__shfl(pb[0], i, 64), __shfl(pb[1], i, 64), __shfl(pb[2], i, 64)};
-            const double pbfI = __shfl(pbf, i, 64);
+            pso_move_own(i, N, localK, iw, u, pos, pb, fitj, pbf, lane, gB, rl, ru, vecI, nbI, nP, nV, nNb);
+            const double pbI[3] = {lane_get(pb[0], i), lane_get(pb[1], i), lane_get(pb[2], i)};
+            const double pbfI = lane_get(pbf, i);
             if (lane == 0 && part == 0) {
                 for (int d = 0; d < 3; ++d) {
                     Wb.pos[i][d] = nP[d];

@@ -1055,15 +1055,8 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
     m->candRecs.clear();
     m->nextDeferred.clear();
     m->claims.clear();
-    auto consider = [&](const Unit &u) {
-        const pais_patch_result &pr = m->patches[u.id]->r;
-        const int camI = pr.cam_idx[u.slot];
-        const CellMap &map = m->cellMaps[camI];
-        const int cx = (int)(pr.imgPoint[u.slot][0] / m->cfg.cellSize);
-        const int cy = (int)(pr.imgPoint[u.slot][1] / m->cfg.cellSize);
-        const int nx[4] = {cx - 1, cx, cx + 1, cx};
-        const int ny[4] = {cy, cy - 1, cy, cy + 1};
-        const int x = nx[u.j], y = ny[u.j];
+    // one neighbour cell (x, y) of camera camI of the parent of unit u
+    auto considerCell = [&](const Unit &u, const pais_patch_result &pr, int camI, const CellMap &map, int x, int y) {
         if (!map.inMap(x, y)) return;
         if (m->skipNeighborCell(map, x, y, pr, m->curRound)) return; // blocked before the round (== live: nothing inserted yet)
         const uint64_t key = (((uint64_t)(uint32_t)camI) << 48) ^ (((uint64_t)(uint32_t)x) << 24) ^ (uint64_t)(uint32_t)y;
@@ -1075,14 +1068,27 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
         m->cands.push_back(Candidate{u, camI, x, y});
         m->candRecs.push_back(rec);
     };
-    for (const Unit &u : m->deferred) consider(u);
+    static const int dx[4] = {-1, 0, 1, 0}, dy[4] = {0, -1, 0, 1}; // neighbour j of a cell: left, up, right, down
+    for (const Unit &u : m->deferred) {
+        const pais_patch_result &pr = m->patches[u.id]->r;
+        const int camI = pr.cam_idx[u.slot];
+        const int cx = (int)(pr.imgPoint[u.slot][0] / m->cfg.cellSize);
+        const int cy = (int)(pr.imgPoint[u.slot][1] / m->cfg.cellSize);
+        considerCell(u, pr, camI, m->cellMaps[camI], cx + dx[u.j], cy + dy[u.j]);
+    }
     // one camera slot of every active parent; a thin front (few active parents: the long tail of the
     // expansion, where a round is pure latency) takes all remaining slots of its parents at once
     const bool thin = (int)m->active.size() <= m->thinFront;
     for (Active &a : m->active) {
-        const int sEnd = thin ? m->patches[a.id]->r.num_cam : a.slot + 1;
-        for (int sl = a.slot; sl < sEnd; ++sl)
-            for (int j = 0; j < 4; ++j) consider(Unit{a.id, sl, j});
+        const pais_patch_result &pr = m->patches[a.id]->r;
+        const int sEnd = thin ? pr.num_cam : a.slot + 1;
+        for (int sl = a.slot; sl < sEnd; ++sl) {
+            const int camI = pr.cam_idx[sl];
+            const CellMap &map = m->cellMaps[camI];
+            const int cx = (int)(pr.imgPoint[sl][0] / m->cfg.cellSize);
+            const int cy = (int)(pr.imgPoint[sl][1] / m->cfg.cellSize);
+            for (int j = 0; j < 4; ++j) considerCell(Unit{a.id, sl, j}, pr, camI, map, cx + dx[j], cy + dy[j]);
+        }
         a.slot = sEnd - 1; // round_commit advances past it
     }
     if (m->truncatedVisible > 0) {
