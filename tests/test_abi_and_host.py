@@ -106,3 +106,40 @@ def test_new_entry_points_reject_bad_arguments(pawn_small):
     assert m.num_patches() == 1
     m.set_thin_front(-5)                                                     # clamped to 0
     m.close()
+
+
+def test_headers_are_plain_c_and_link_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: every header under include/ compiles as C99 and as C++11 on its own (no HIP, no
+    torch types in the signatures), and a C program linked against libpais_hip.so calls through it."""
+    import glob
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    headers = sorted(os.path.basename(h) for h in glob.glob(os.path.join(inc, "*.h")))
+    assert {"pais_hip.h", "pais_mvs.h", "pais_io.h", "pais_pyramid.h"} <= set(headers)
+    src = tmp_path / "abi.c"
+    src.write_text("".join('#include "%s"\n' % h for h in headers) + """
+#include <stdio.h>
+#include <string.h>
+int main(void)
+{
+    /* sizes the reference-side binding relies on (INTEGRATION.md) */
+    if (sizeof(pais_patch_result) != (size_t)pais_sizeof_patch_result()) return 2;
+    if (sizeof(pais_candidate) != (size_t)pais_sizeof_candidate()) return 3;
+    if (sizeof(pais_config) != (size_t)pais_sizeof_config()) return 4;
+    /* an entry point that needs no GPU: bad arguments are refused with a message */
+    if (pais_mvs_create(NULL, 0, NULL, -1, 0, NULL) == 0) return 5;
+    if (strlen(pais_mvs_last_error()) == 0) return 6;
+    printf("ok %d %d\\n", (int)sizeof(pais_patch_result), PAIS_MAX_VIS);
+    return 0;
+}
+""")
+    lib_dir = os.path.join(ROOT, "pais_mvs_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    cpp = tmp_path / "abi.cpp"
+    cpp.write_text("".join('#include "%s"\n' % h for h in headers) + "int main() { return 0; }\n")
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)], check=True)
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", lib_dir, "-lpais_hip", "-Wl,-rpath," + lib_dir],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok 1488 64"), (out.returncode, out.stdout, out.stderr)
