@@ -332,12 +332,16 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 // The lane's four (fitness, weight) sub-accumulators: LDS rows for the two-pixel kernels (few cameras: registers are the
 // scarce resource there), registers for the one-pixel kernels (many cameras: the LDS scratch caps the occupancy;
 // measured +17 % on the 32-camera ring, -1 % on the 5-camera pawn scene if used there too)
+// Three shapes of the evaluation kernels (template parameters NS, ACCR; chosen by the batch's largest camera count):
+//   NS 2, LDS accumulators       K <= PAIS_TWO_PIXELS_MAXK (6)   registers are the scarce resource (168 VGPRs at 3 waves / SIMD)
+//   NS 2, register accumulators  K <= PAIS_TWO_PIXELS_REG_MAXK (12)  ring (K 7..11): +5.7 % over the one-pixel kernel
+//   NS 1, register accumulators  beyond                          the colour rows (NS x M x 512 B) cap the occupancy
 #define PAIS_ACC_IN_REGS(NS) (PAIS_ACC_REG || (NS) == 1)
-#define PAIS_CBUF_ROWS(NS, M) ((NS) * (M) + (PAIS_ACC_IN_REGS(NS) ? 0 : 8))
+#define PAIS_CBUF_ROWS(NS, M, ACCR) ((NS) * (M) + ((ACCR) ? 0 : 8))
 __host__ __device__ inline size_t eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
-__host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax)
+__host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax, bool accr)
 {
-    return eval_block_bytes(Kmax) + sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax + sizeof(double) * 64 * (size_t)PAIS_CBUF_ROWS(NS, Kmax);
+    return eval_block_bytes(Kmax) + sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax + sizeof(double) * 64 * (size_t)PAIS_CBUF_ROWS(NS, Kmax, accr);
 }
 
 // Reduction shape (canonical, independent of how many waves share one evaluation): the 64-pixel steps of the
@@ -346,7 +350,7 @@ __host__ __device__ inline size_t eval_lds_bytes(int NS, int Kmax)
 // computes all four (nparts = 1), or `nparts` (2 / 4) waves compute the sub-accumulators a with
 // a mod nparts == part and whoever consumes the fitness adds them -- the same bits either way.
 // Returns 0 and fills f4/w4 (zeros for the sub-accumulators of other parts), or 1 if the call is DBL_MAX.
-template <int NS, bool CHECK, bool BYTES>
+template <int NS, bool CHECK, bool BYTES, bool ACCR>
 __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                            const WinPix *win, int lane, int part, int nparts, double *f4, double *w4);
 
@@ -381,7 +385,7 @@ __device__ __forceinline__ bool corners_inside(const EvalPatch *ep, const EvalCa
     return __all(ok);
 }
 
-template <int NS, bool BYTES>
+template <int NS, bool BYTES, bool ACCR>
 __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                                   const WinPix *win, double theta, double phi, double depth, int lane, int part, int nparts,
                                   double *f4, double *w4)
@@ -424,13 +428,13 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     wave_sync();
 #if PAIS_CORNER_FASTPATH
     if (corners_inside(ep, cams, Hbuf, sc.cfg.patchSize, lane))
-        return eval_window<NS, false, BYTES>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
+        return eval_window<NS, false, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
 #endif
-    return eval_window<NS, true, BYTES>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
+    return eval_window<NS, true, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
 }
 
 // the window walk of one evaluation (homographies in Hbuf); CHECK: see corners_inside
-template <int NS, bool CHECK, bool BYTES>
+template <int NS, bool CHECK, bool BYTES, bool ACCR>
 __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                            const WinPix *win, int lane, int part, int nparts, double *f4, double *w4)
 {
@@ -442,7 +446,7 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
     const bool hasRef = ep->hasRef != 0;
     const double invK = 1.0 / (double)K;
     double *myc = cbuf + lane;
-    constexpr bool ACCREG = PAIS_ACC_IN_REGS(NS);
+    constexpr bool ACCREG = ACCR;
     double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0}; // the lane's sub-accumulators (ACCREG)
     double *myacc = cbuf + (size_t)M * NS * 64 + lane;     // [2a] fitness, [2a+1] weight of sub-accumulator a (!ACCREG)
     if (!ACCREG) {

@@ -120,13 +120,13 @@ __global__ __launch_bounds__(64) void k_state_blocks(DevScene sc, const pais_pat
                          st->num_cam, st->cam_idx, lane);
     }
 }
-template <int NS, bool BYTES>
+template <int NS, bool BYTES, bool ACCR>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_fitness(DevScene sc, const int32_t *stateIndex, const double *particles, double *out,
                                                                   int nEvals, int Kmax, const unsigned char *evalBlocks, size_t evalBlockBytes,
                                                                   const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, ACCR); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
@@ -142,7 +142,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_fitness(DevScene sc, const int32_t *state
         stage_eval_block(smem, src, nw, lane, v0, v1);
         wave_sync();
         double f4[4], w4[4];
-        const int bad = eval_fitness_parts<NS, BYTES>(sc, ep, cams, Hbuf, cbuf, win + (size_t)s * WS, particles[3 * e], particles[3 * e + 1],
+        const int bad = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)s * WS, particles[3 * e], particles[3 * e + 1],
                                                particles[3 * e + 2], lane, 0, 1, f4, w4);
         if (lane == 0) out[e] = bad ? DBL_MAX : combine_parts(f4, w4);
     }
@@ -713,12 +713,12 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 
 // The evaluation launch of large batches (split pipeline): one wave per (candidate, particle), nothing but the cost.
 // The candidate's constants come from the block k_pso_init prepared; positions from swarm buffer 0 (k_pso_step).
-template <int NS, bool BYTES>
+template <int NS, bool BYTES, bool ACCR>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                                                     const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, ACCR); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
@@ -744,7 +744,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
         stage_eval_block(smem, src, nwMax, lane, v0, v1);
         wave_sync();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS, BYTES>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
+        const int st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
         if (lane == 0) A.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
     }
 }
@@ -837,14 +837,14 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 // Tasks: positions [listLo, min(listHi, *activeCount)) of the active list written by k_pso_init.
 // NS = 2 (3 waves per SIMD) for patches seen by few cameras, NS = 1 (4 waves per SIMD) beyond: a wave's LDS scratch
 // grows with NS * K and caps the occupancy (measured: K ~ 4: NS 2 +3 %, K ~ 7: NS 1 +9 %)
-template <int nparts, int NS, bool BYTES>
+template <int nparts, int NS, bool BYTES, bool ACCR>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
                                             const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                                             const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
-    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax); // wave-private scratch
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, ACCR); // wave-private scratch
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
@@ -1034,7 +1034,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *stat
         stage_eval_block(smem, src, nwMax, lane, v0, v1); // the run's evaluation block, prepared by k_pso_init
         wave_sync();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS, BYTES>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, part, nparts, f4, w4);
+        const int st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, part, nparts, f4, w4);
         if (lane == 0) {
             if (nparts == 1) {
                 Wb.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
@@ -1485,23 +1485,38 @@ static inline int eval_grid(long tasks)
 #endif
     return (int)(g < 1 ? 1 : g);
 }
-static inline bool two_pixels(int Kmax) { return Kmax <= PAIS_TWO_PIXELS_MAXK; }
+// shape of the evaluation kernels for a batch (pais_eval.hpp): 0: NS 2 / LDS accumulators, 1: NS 2 / register
+// accumulators, 2: NS 1 / register accumulators
+#ifndef PAIS_TWO_PIXELS_REG_MAXK
+#define PAIS_TWO_PIXELS_REG_MAXK 12
+#endif
+static inline int eval_shape(int Kmax) { return Kmax <= PAIS_TWO_PIXELS_MAXK ? 0 : (Kmax <= PAIS_TWO_PIXELS_REG_MAXK ? 1 : 2); }
+// calls F<NS, BYTES, ACCR>(args...) for the batch's shape and the scene's tap representation
+#define PAIS_SHAPE_DISPATCH(F, ...)                                                                         \
+    do {                                                                                                     \
+        const int shape_ = eval_shape(Kmax);                                                                 \
+        if (byte_taps(sc))                                                                                   \
+            return shape_ == 0 ? F<2, true, false>(__VA_ARGS__)                                              \
+                               : (shape_ == 1 ? F<2, true, true>(__VA_ARGS__) : F<1, true, true>(__VA_ARGS__)); \
+        return shape_ == 0 ? F<2, false, false>(__VA_ARGS__)                                                 \
+                           : (shape_ == 1 ? F<2, false, true>(__VA_ARGS__) : F<1, false, true>(__VA_ARGS__)); \
+    } while (0)
 // the scene decides what the taps read (pais_internal.h PaisImgT)
 static inline bool byte_taps(const DevScene &sc) { return sc.imgF == nullptr; }
 
 size_t eval_block_bytes_host(int Kmax) { return eval_block_bytes(Kmax); }
 size_t win_bytes_per_candidate(const DevScene &sc) { return sizeof(WinPix) * (size_t)win_stride(sc); }
 
-template <int NS, bool BYTES>
+template <int NS, bool BYTES, bool ACCR>
 static hipError_t fitness_launch(const DevScene &sc, const int32_t *idx, const double *particles, double *out, int nEvals, int Kmax,
                                  const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_fitness<NS, BYTES>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax, ACCR) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_fitness<NS, BYTES, ACCR>, lds);
     if (e != hipSuccess) return e;
     const int grid = eval_grid(nEvals);
-    hipLaunchKernelGGL((k_fitness<NS, BYTES>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
+    hipLaunchKernelGGL((k_fitness<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, idx, particles, out, nEvals, Kmax, evalBlocks,
                        eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }
@@ -1513,11 +1528,7 @@ hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStat
                        eval_block_bytes(Kmax), (WinPix *)win);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (byte_taps(sc))
-        return two_pixels(Kmax) ? fitness_launch<2, true>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream)
-                                : fitness_launch<1, true>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
-    return two_pixels(Kmax) ? fitness_launch<2, false>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream)
-                            : fitness_launch<1, false>(sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
+    PAIS_SHAPE_DISPATCH(fitness_launch, sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
 }
 
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream)
@@ -1557,16 +1568,16 @@ hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, un
                        eval_block_bytes(Kmax), (WinPix *)win);
     return hipGetLastError();
 }
-template <int NS, bool BYTES>
+template <int NS, bool BYTES, bool ACCR>
 static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
                                    const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_pso_eval2<NS, BYTES>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax, ACCR) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_pso_eval2<NS, BYTES, ACCR>, lds);
     if (e != hipSuccess) return e;
     const int grid = eval_grid((long)n * Nmax);
-    hipLaunchKernelGGL((k_pso_eval2<NS, BYTES>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+    hipLaunchKernelGGL((k_pso_eval2<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
                        eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }
@@ -1574,42 +1585,40 @@ static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, in
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
                     hipStream_t stream)
 {
-    if (byte_taps(sc))
-        return two_pixels(Kmax) ? pso_eval2_launch<2, true>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream)
-                                : pso_eval2_launch<1, true>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream);
-    return two_pixels(Kmax) ? pso_eval2_launch<2, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream)
-                            : pso_eval2_launch<1, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, stream);
+    PAIS_SHAPE_DISPATCH(pso_eval2_launch, sc, states, n, Nmax, Kmax, evalBlocks, win, stream);
 }
-template <int P, int NS, bool BYTES>
+template <int P, int NS, bool BYTES, bool ACCR>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,
                                   int listLo, int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L,
                                   int finishOnly, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = eval_lds_bytes(NS, Kmax) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_pso_iter<P, NS, BYTES>, lds);
+    const size_t lds = eval_lds_bytes(NS, Kmax, ACCR) * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_pso_iter<P, NS, BYTES, ACCR>, lds);
     if (e != hipSuccess) return e;
     const int grid = eval_grid((long)(listHi - listLo) * (finishOnly ? 1 : Nmax * P));
-    hipLaunchKernelGGL((k_pso_iter<P, NS, BYTES>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, activeList, activeCount, listLo,
+    hipLaunchKernelGGL((k_pso_iter<P, NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, activeList, activeCount, listLo,
                        listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, eval_block_bytes(Kmax), (const WinPix *)win);
     return hipGetLastError();
 }
+#define PAIS_ITER_WRAPPER(P)                                                                  \
+    template <int NS, bool BYTES, bool ACCR, class... A> static hipError_t pso_iter_launch##P(const A &...a) \
+    {                                                                                         \
+        return pso_iter_launch<P, NS, BYTES, ACCR>(a...);                                     \
+    }
+PAIS_ITER_WRAPPER(1)
+PAIS_ITER_WRAPPER(2)
+PAIS_ITER_WRAPPER(4)
+#undef PAIS_ITER_WRAPPER
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                     int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream)
 {
     if (listHi <= listLo) return hipSuccess;
-    const int shape = (two_pixels(Kmax) ? 0 : 1) + (byte_taps(sc) ? 2 : 0);
-#define PAIS_ARGS sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, win
-#define PAIS_DISPATCH(P)                                                                             \
-    return shape == 0 ? pso_iter_launch<P, 2, false>(PAIS_ARGS, stream)                              \
-                      : (shape == 1 ? pso_iter_launch<P, 1, false>(PAIS_ARGS, stream)                \
-                                    : (shape == 2 ? pso_iter_launch<P, 2, true>(PAIS_ARGS, stream)   \
-                                                  : pso_iter_launch<P, 1, true>(PAIS_ARGS, stream)))
-    if (nparts == 4) { PAIS_DISPATCH(4); }
-    if (nparts == 2) { PAIS_DISPATCH(2); }
-    PAIS_DISPATCH(1);
-#undef PAIS_DISPATCH
+#define PAIS_ARGS sc, states, activeList, activeCount, listLo, listHi, Nmax, Kmax, recs, stat, L, finishOnly, evalBlocks, win, stream
+    if (nparts == 4) { PAIS_SHAPE_DISPATCH(pso_iter_launch4, PAIS_ARGS); }
+    if (nparts == 2) { PAIS_SHAPE_DISPATCH(pso_iter_launch2, PAIS_ARGS); }
+    PAIS_SHAPE_DISPATCH(pso_iter_launch1, PAIS_ARGS);
 #undef PAIS_ARGS
 }
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
