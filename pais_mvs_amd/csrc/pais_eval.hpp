@@ -336,6 +336,11 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 //   NS 2, LDS accumulators       K <= PAIS_TWO_PIXELS_MAXK (6)   registers are the scarce resource (168 VGPRs at 3 waves / SIMD)
 //   NS 2, register accumulators  K <= PAIS_TWO_PIXELS_REG_MAXK (12)  ring (K 7..11): +5.7 % over the one-pixel kernel
 //   NS 1, register accumulators  beyond                          the colour rows (NS x M x 512 B) cap the occupancy
+// pairs of cameras per trip of the one-pixel kernels' camera loop (dome, K <= 32: 2 with 2 waves / SIMD requested
+// +5.8 % patches/s -- the waves wait 60 % of their cycles at the 1.75 waves / SIMD the colour rows leave; 3 and 4 no better)
+#ifndef PAIS_NS1_UNROLL
+#define PAIS_NS1_UNROLL 2
+#endif
 #define PAIS_ACC_IN_REGS(NS) (PAIS_ACC_REG || (NS) == 1)
 #define PAIS_CBUF_ROWS(NS, M, ACCR) ((NS) * (M) + ((ACCR) ? 0 : 8))
 __host__ __device__ inline size_t eval_block_bytes(int Kmax) { return sizeof(EvalPatch) + sizeof(EvalCam) * (size_t)Kmax; }
@@ -486,6 +491,17 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
 #pragma unroll
         for (int q = 0; q < NS; ++q) sum[q] = hasRef ? wp[q].refCol : 0.0;
         int c0 = 0;
+#if PAIS_NS1_UNROLL > 1
+        // many cameras, one pixel per lane: PAIS_NS1_UNROLL pairs per trip, so that the loads of the later pairs are in flight
+        // while the first is interpolated (same groups, same arithmetic: a trip is taken only where the one-by-one rule
+        // below would take that many pairs anyway)
+        if (NS == 1)
+            for (; M - c0 >= 2 * PAIS_NS1_UNROLL + 2 || M - c0 == 2 * PAIS_NS1_UNROLL; c0 += 2 * PAIS_NS1_UNROLL) {
+#pragma unroll
+                for (int u = 0; u < PAIS_NS1_UNROLL; ++u)
+                    tap_group<2, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0 + 2 * u, x, y, badBits, sum);
+            }
+#endif
         for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
         if (M - c0 == 3) tap_group<3, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
         else if (M - c0 == 1) tap_group<1, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // a single camera

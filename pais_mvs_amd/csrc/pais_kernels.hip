@@ -50,7 +50,7 @@ using namespace pais;
 #endif
 //   PAIS_NS1_WAVES   waves per SIMD the register allocator is asked for in the one-pixel-per-lane kernels (many cameras)
 #ifndef PAIS_NS1_WAVES
-#define PAIS_NS1_WAVES 3
+#define PAIS_NS1_WAVES 2   // only batches of more than 12 cameras run them: their LDS scratch allows < 2 waves per SIMD anyway
 #endif
 #ifndef PAIS_NS2_WAVES
 #define PAIS_NS2_WAVES 3
