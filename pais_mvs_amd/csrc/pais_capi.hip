@@ -185,6 +185,8 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
         if (d.max_lod < 0 || d.max_lod >= PAIS_MAX_LEVELS) { pais_ctx_destroy(ctx); return fail_msg("camera max_lod out of range"); }
         for (int l = 0; l <= d.max_lod; ++l) {
             if (!d.level_image[l] || d.level_width[l] <= 0 || d.level_height[l] <= 0) { pais_ctx_destroy(ctx); return fail_msg("camera level missing"); }
+            // the evaluation packs a level's tap bounds (w - 4, h - 4) into 16 bits each and its row offsets into 24 (pais_eval.hpp)
+            if (d.level_width[l] > 65535 || d.level_height[l] > 65535) { pais_ctx_destroy(ctx); return fail_msg("camera level larger than 65535 pixels in one dimension"); }
             size_t px = (size_t)d.level_width[l] * d.level_height[l];
             imgOff[(size_t)c * PAIS_MAX_LEVELS + l] = imgBytes;
             imgBytes = (imgBytes + px + 16 + 255) & ~(size_t)255; // +16: taps read (px+1, py+1)
