@@ -188,6 +188,7 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
             // the evaluation packs a level's tap bounds (w - 4, h - 4) into 16 bits each and its row offsets into 24 (pais_eval.hpp)
             if (d.level_width[l] > 65535 || d.level_height[l] > 65535) { pais_ctx_destroy(ctx); return fail_msg("camera level larger than 65535 pixels in one dimension"); }
             size_t px = (size_t)d.level_width[l] * d.level_height[l];
+            if (px >= ((size_t)1 << 29)) { pais_ctx_destroy(ctx); return fail_msg("camera level of 2^29 pixels or more (32-bit tap offsets inside a level)"); }
             imgOff[(size_t)c * PAIS_MAX_LEVELS + l] = imgBytes;
             imgBytes = (imgBytes + px + 16 + 255) & ~(size_t)255; // +16: taps read (px+1, py+1)
             if (wantEdge && edgesGiven) {
