@@ -1689,6 +1689,8 @@ int po_mvs_add_seed(po_mvs *m, const double center[3], int numCam, const int *ca
     return mvs_store(m, &p);
 }
 
+void po_svd_solve(int n, int m, const double *A, const double *b, double *x) { svd_solve(n, m, A, b, x); } /* po_seed.c */
+
 /* Patch::reCentering, patch.cpp:67-112 (A.inv(DECOMP_SVD) * b through the SVD back-substitution of the identity) */
 void po_recenter(const po_scene *s, int numCam, const int *camIdx, const double *imgPoints, double center[3])
 {

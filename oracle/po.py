@@ -156,6 +156,17 @@ def lib():
     L.po_mvs_refine_seed_patches.argtypes = [C.c_void_p]
     L.po_mvs_set_thin_front.argtypes = [C.c_void_p, C.c_int]
     L.po_recenter.argtypes = [C.POINTER(SceneS), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    # po_seed.c: FeatureManager::setSeedPatches after the SIFT call
+    fpp = C.POINTER(C.c_float)
+    L.po_seed_fundamental.argtypes = [C.POINTER(CameraS), C.POINTER(CameraS), C.POINTER(C.c_double)]
+    L.po_seed_fundamental.restype = None
+    L.po_seed_match.argtypes = [C.c_int, fpp, C.c_int, fpp, C.c_int, C.POINTER(C.c_int), fpp]
+    L.po_seed_match.restype = None
+    L.po_seed_features.argtypes = [C.POINTER(SceneS), C.POINTER(C.c_int), C.POINTER(fpp), C.POINTER(fpp), C.c_int, C.c_double,
+                                   C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double))]
+    L.po_seed_features.restype = C.c_int
+    L.po_seed_free.argtypes = [C.c_void_p]
+    L.po_seed_free.restype = None
     L.po_mvs_load_patch.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_double, C.c_double]
     L.po_mvs_cell_filtering.argtypes = [C.c_void_p]
     L.po_mvs_visibility_filtering.argtypes = [C.c_void_p]

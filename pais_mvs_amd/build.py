@@ -10,10 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpais_hip.so")
 
-HIP_SOURCES = ["pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip"]  # pais_mvs.hip: host scheduler
+HIP_SOURCES = ["pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip", "pais_seed.hip"]  # pais_mvs.hip: host scheduler
 HEADERS = ["pais_dev.hpp", "pais_detmath.hpp", "pais_internal.h", "pais_eval.hpp", os.path.join("..", "..", "include", "pais_hip.h"),
            os.path.join("..", "..", "include", "pais_mvs.h"), os.path.join("..", "..", "include", "pais_io.h"),
-           os.path.join("..", "..", "include", "pais_pyramid.h")]
+           os.path.join("..", "..", "include", "pais_pyramid.h"), os.path.join("..", "..", "include", "pais_seed.h")]
 # -ffp-contract=off: the PSO position/velocity update and the per-tap arithmetic keep
 # the reference's rounding sequence; measured cost is reported there.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -22,6 +22,7 @@
 #include <deque>
 #include <queue>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -29,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/pais_mvs.h"
+#include "../../include/pais_seed.h"
 #include "pais_dev.hpp"
 
 namespace {
@@ -44,6 +46,7 @@ inline double now_ms()
 
 struct HostCamera { // what the driver needs of PAIS::Camera (camera.h)
     double focal[2], pp[2], R[9], T[3], C[3], optN[3];
+    double KR[9], KT[3]; // P = [KR | KT] (camera.cpp:123-127): the fundamental matrices of the seeding stage
     int w0, h0;
     std::vector<uint8_t> img0; // LOD-0 gray image: background test of runtimeFiltering (mvs.cpp:853-862)
 };
@@ -619,6 +622,8 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
         memcpy(h.T, d.translation, sizeof(h.T));
         memcpy(h.C, d.center, sizeof(h.C));
         memcpy(h.optN, d.optical_normal, sizeof(h.optN));
+        memcpy(h.KR, d.KR, sizeof(h.KR));
+        memcpy(h.KT, d.KT, sizeof(h.KT));
         h.w0 = d.level_width[0];
         h.h0 = d.level_height[0];
         const size_t stride = d.level_stride[0] > 0 ? (size_t)d.level_stride[0] : (size_t)h.w0;
@@ -1424,6 +1429,167 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         if (max_rounds > 0 && ++rounds >= max_rounds) break;
     }
     return pais_mvs_expansion_end(m);
+}
+
+// ------------------------------------------------------ seeds from features ---
+// FeatureManager::setSeedPatches after the descriptor matching (mvs/featuremanager.cpp:41-99, 118-243); include/pais_seed.h.
+// The reference keeps vectors of DMatch per ordered camera pair and erases from them while it scans; the outcome of those
+// scans is stated here over hashed pair sets and a (camera, feature) -> first-feature index, which give the same lists.
+extern "C" int pais_mvs_seeds_from_matches(pais_mvs *m, int num_cams, const pais_keypoints *kp, int num_matches,
+                                           const pais_pair_match *matches, double max_dist, int *num_seeds)
+{
+    if (!m || !kp || num_cams != (int)m->cams.size() || num_matches < 0 || (num_matches && !matches))
+        return mfail("pais_mvs_seeds_from_matches: bad argument");
+    const int C = num_cams;
+    for (int c = 0; c < C; ++c)
+        if (kp[c].n < 0 || (kp[c].n && !kp[c].xy)) return mfail("pais_mvs_seeds_from_matches: bad keypoints");
+    // fundamental matrices, getFundamentalMatrices (:265-287): M[i][j] = F(from j, to i) for i < j, transposed below it
+    std::vector<double> Fs((size_t)C * C * 9, 0.0);
+    {
+        std::vector<pais_camera_desc> d((size_t)C);
+        for (int c = 0; c < C; ++c) {
+            memset(&d[c], 0, sizeof(pais_camera_desc));
+            memcpy(d[c].KR, m->cams[c].KR, sizeof(d[c].KR));
+            memcpy(d[c].KT, m->cams[c].KT, sizeof(d[c].KT));
+            memcpy(d[c].center, m->cams[c].C, sizeof(d[c].center));
+        }
+        for (int i = 0; i < C; ++i)
+            for (int j = i; j < C; ++j) {
+                double *Fij = &Fs[((size_t)i * C + j) * 9], *Fji = &Fs[((size_t)j * C + i) * 9];
+                if (i == j) { Fij[0] = Fij[4] = Fij[8] = 1.0; continue; }
+                if (pais_seed_fundamental(&d[j], &d[i], Fij)) return mfail(pais_seed_last_error());
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) Fji[r * 3 + c] = Fij[c * 3 + r];
+            }
+    }
+    // the match table after epipolarLineFiltering (:158-196)
+    typedef std::pair<int, int> QT;
+    std::vector<std::vector<QT>> table((size_t)C * C);
+    for (int k = 0; k < num_matches; ++k) {
+        const pais_pair_match &mm = matches[k];
+        if (mm.cam_q < 0 || mm.cam_q >= C || mm.cam_t < 0 || mm.cam_t >= C || mm.cam_q == mm.cam_t || mm.q < 0 || mm.q >= kp[mm.cam_q].n ||
+            mm.t < 0 || mm.t >= kp[mm.cam_t].n)
+            return mfail("pais_mvs_seeds_from_matches: bad match");
+        const double *F = &Fs[((size_t)mm.cam_q * C + mm.cam_t) * 9];
+        const double qx = kp[mm.cam_q].xy[2 * mm.q], qy = kp[mm.cam_q].xy[2 * mm.q + 1];
+        const double tx = kp[mm.cam_t].xy[2 * mm.t], ty = kp[mm.cam_t].xy[2 * mm.t + 1];
+        double l[3];
+        for (int c = 0; c < 3; ++c) l[c] = qx * F[c] + qy * F[3 + c] + 1.0 * F[6 + c]; // q^T F
+        const double dist = fabs(l[0] * tx + l[1] * ty + l[2] * 1.0) / sqrt(l[0] * l[0] + l[1] * l[1]);
+        if (dist > max_dist) continue;
+        table[(size_t)mm.cam_q * C + mm.cam_t].push_back(QT(mm.q, mm.t));
+    }
+    // filteroutNonMatches (:198-243), first half: a match of (i, j) stays iff (j, i) still holds its mirror image, which is
+    // consumed.  Matches of a pair are unique per query, so "the first mirror found" is "the mirror".
+    auto key = [](int a, int b) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)b; };
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+            std::vector<QT> &a = table[(size_t)i * C + j], &b = table[(size_t)j * C + i];
+            if (a.empty()) continue;
+            std::unordered_set<uint64_t> mirror;
+            for (const QT &x : b) mirror.insert(key(x.second, x.first)); // as (q of a, t of a)
+            std::unordered_set<uint64_t> consumed;
+            std::vector<QT> keep;
+            for (const QT &x : a)
+                if (mirror.count(key(x.first, x.second)) && !consumed.count(key(x.first, x.second))) {
+                    keep.push_back(x);
+                    consumed.insert(key(x.first, x.second));
+                }
+            if (i != j) {
+                std::vector<QT> rest;
+                for (const QT &x : b)
+                    if (!consumed.count(key(x.second, x.first))) rest.push_back(x);
+                b.swap(rest);
+            }
+            a.swap(keep);
+        }
+    // ... second half: views with fewer than a quarter of the camera's best match count are dropped
+    for (int i = 0; i < C; ++i) {
+        size_t maxMatch = 0;
+        for (int j = 0; j < C; ++j) maxMatch = std::max(maxMatch, table[(size_t)i * C + j].size());
+        for (int j = 0; j < C; ++j)
+            if ((double)table[(size_t)i * C + j].size() < (double)maxMatch / 4.0) table[(size_t)i * C + j].clear();
+    }
+    // union (:56-82, setNVMatch :118-156): a match joins the FIRST n-view feature that holds one of its two ends -- within
+    // that feature the first element that is one of them decides which end is the link -- else it opens a feature
+    struct Node { int cam, feat; };
+    std::vector<std::vector<Node>> nv;
+    std::unordered_map<uint64_t, int> firstFeature; // (cam, feat) -> lowest index of a feature holding it
+    auto hold = [&](int u, int cam, int feat) {
+        auto it = firstFeature.find(key(cam, feat));
+        if (it == firstFeature.end() || it->second > u) firstFeature[key(cam, feat)] = u;
+    };
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) {
+            if (i == j) continue;
+            std::vector<QT> &l = table[(size_t)i * C + j];
+            while (!l.empty()) {
+                const QT mt = l.back();
+                int u = -1;
+                auto a = firstFeature.find(key(i, mt.first)), b = firstFeature.find(key(j, mt.second));
+                if (a != firstFeature.end()) u = a->second;
+                if (b != firstFeature.end() && (u < 0 || b->second < u)) u = b->second;
+                if (u >= 0) {
+                    std::vector<Node> &f = nv[(size_t)u];
+                    for (size_t e = 0; e < f.size(); ++e) {
+                        const bool isQ = f[e].cam == i && f[e].feat == mt.first, isT = f[e].cam == j && f[e].feat == mt.second;
+                        if (!isQ && !isT) continue;
+                        const int addCam = isQ ? j : i, addFeat = isQ ? mt.second : mt.first; // (the query test comes first)
+                        bool present = false;
+                        for (const Node &x : f) present = present || x.feat == addFeat; // the reference compares the feature index alone
+                        if (!present) {
+                            f.push_back(Node{addCam, addFeat});
+                            hold(u, addCam, addFeat);
+                        }
+                        break;
+                    }
+                } else {
+                    nv.push_back(std::vector<Node>{Node{i, mt.first}, Node{j, mt.second}});
+                    hold((int)nv.size() - 1, i, mt.first);
+                    hold((int)nv.size() - 1, j, mt.second);
+                }
+                l.pop_back();
+            }
+        }
+    // seeds (:84-99)
+    int added = 0;
+    const double zero[3] = {0, 0, 0};
+    for (const std::vector<Node> &f : nv) {
+        if ((int)f.size() < m->cfg.minCamNum) continue;
+        if (f.size() > (size_t)PAIS_MAX_VIS) return mfail("pais_mvs_seeds_from_matches: an n-view feature holds more than PAIS_MAX_VIS views");
+        int32_t cams[PAIS_MAX_VIS];
+        double pts[2 * PAIS_MAX_VIS];
+        for (size_t e = 0; e < f.size(); ++e) {
+            cams[e] = f[e].cam;
+            pts[2 * e] = (double)kp[f[e].cam].xy[2 * f[e].feat];
+            pts[2 * e + 1] = (double)kp[f[e].cam].xy[2 * f[e].feat + 1];
+        }
+        const int id = pais_mvs_add_seed_measured(m, zero, (int)f.size(), cams, pts, 1);
+        if (id < 0) return id;
+        ++added;
+    }
+    if (num_seeds) *num_seeds = added;
+    return 0;
+}
+
+extern "C" int pais_mvs_set_seed_patches(pais_mvs *m, int num_cams, const pais_keypoints *kp, int dim, double max_dist, int *num_seeds)
+{
+    if (!m || !kp || num_cams != (int)m->cams.size() || dim <= 0) return mfail("pais_mvs_set_seed_patches: bad argument");
+    if (!m->ctx) return mfail("pais_mvs_set_seed_patches: this driver owns no GPU (the descriptor matching runs on it)");
+    std::vector<pais_pair_match> all;
+    std::vector<int32_t> tq;
+    std::vector<float> dd;
+    for (int i = 0; i < num_cams; ++i)
+        for (int j = 0; j < num_cams; ++j) {
+            if (i == j) continue;
+            tq.assign((size_t)std::max(kp[i].n, 1), -1);
+            dd.assign((size_t)std::max(kp[i].n, 1), 0.f);
+            if (pais_seed_match(m->device, kp[i].n, kp[i].desc, kp[j].n, kp[j].desc, dim, tq.data(), dd.data()))
+                return mfail(pais_seed_last_error());
+            for (int q = 0; q < kp[i].n; ++q)
+                if (tq[(size_t)q] >= 0) all.push_back(pais_pair_match{i, j, q, tq[(size_t)q]});
+        }
+    return pais_mvs_seeds_from_matches(m, num_cams, kp, (int)all.size(), all.data(), max_dist, num_seeds);
 }
 
 extern "C" int pais_mvs_num_patches(const pais_mvs *m) { return m ? m->alive : 0; }

@@ -11,7 +11,7 @@ VARS = {
     "ns2w4": ["-DPAIS_NS2_WAVES=4"],
     "ns2w2": ["-DPAIS_NS2_WAVES=2"],
 }
-FILES = ["pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip"]
+FILES = ["pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip", "pais_seed.hip"]
 
 
 def build(names):
