@@ -71,29 +71,29 @@ extern "C" int pais_seed_match(int device, int nq, const float *query_desc, int 
         for (int q = 0; q < nq; ++q) { train_of_query[q] = -1; dist[q] = FLT_MAX; }
         return 0;
     }
+    if (dim % 4 != 0) return sfail("pais_seed_match: descriptor dimension must be a multiple of 4 (cv::SIFT: 128): rows are read 16 bytes at a time");
     SHIP(hipSetDevice(device));
-    float *dq = nullptr, *dt = nullptr, *dd = nullptr, *dd2 = nullptr;
-    int32_t *bq = nullptr, *bt = nullptr;
-    // rows padded to a multiple of 4 floats would change nothing in the sums' order only if the padding were skipped;
-    // instead unaligned dimensions take the scalar tail of the kernel and rows stay dense
-    if (dim % 4 != 0) return sfail("pais_seed_match: descriptor dimension must be a multiple of 4 (cv::SIFT: 128)");
-    SHIP(hipMalloc(&dq, sizeof(float) * (size_t)nq * dim));
-    SHIP(hipMalloc(&dt, sizeof(float) * (size_t)nt * dim));
-    SHIP(hipMalloc(&dd, sizeof(float) * (size_t)nq));
-    SHIP(hipMalloc(&dd2, sizeof(float) * (size_t)nt));
-    SHIP(hipMalloc(&bq, sizeof(int32_t) * (size_t)nq));
-    SHIP(hipMalloc(&bt, sizeof(int32_t) * (size_t)nt));
-    SHIP(hipMemcpy(dq, query_desc, sizeof(float) * (size_t)nq * dim, hipMemcpyHostToDevice));
-    SHIP(hipMemcpy(dt, train_desc, sizeof(float) * (size_t)nt * dim, hipMemcpyHostToDevice));
+    struct Bufs { // freed on every return path
+        float *dq = nullptr, *dt = nullptr, *dd = nullptr, *dd2 = nullptr;
+        int32_t *bq = nullptr, *bt = nullptr;
+        ~Bufs() { (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(dd); (void)hipFree(dd2); (void)hipFree(bq); (void)hipFree(bt); }
+    } b;
+    SHIP(hipMalloc(&b.dq, sizeof(float) * (size_t)nq * dim));
+    SHIP(hipMalloc(&b.dt, sizeof(float) * (size_t)nt * dim));
+    SHIP(hipMalloc(&b.dd, sizeof(float) * (size_t)nq));
+    SHIP(hipMalloc(&b.dd2, sizeof(float) * (size_t)nt));
+    SHIP(hipMalloc(&b.bq, sizeof(int32_t) * (size_t)nq));
+    SHIP(hipMalloc(&b.bt, sizeof(int32_t) * (size_t)nt));
+    SHIP(hipMemcpy(b.dq, query_desc, sizeof(float) * (size_t)nq * dim, hipMemcpyHostToDevice));
+    SHIP(hipMemcpy(b.dt, train_desc, sizeof(float) * (size_t)nt * dim, hipMemcpyHostToDevice));
     const size_t lds = sizeof(float) * (size_t)dim;
-    hipLaunchKernelGGL(k_nearest_descriptor, dim3(nq < 65536 ? nq : 65536), dim3(64), lds, 0, dq, nq, dt, nt, dim, bq, dd);
-    hipLaunchKernelGGL(k_nearest_descriptor, dim3(nt < 65536 ? nt : 65536), dim3(64), lds, 0, dt, nt, dq, nq, dim, bt, dd2);
+    hipLaunchKernelGGL(k_nearest_descriptor, dim3(nq < 65536 ? nq : 65536), dim3(64), lds, 0, b.dq, nq, b.dt, nt, dim, b.bq, b.dd);
+    hipLaunchKernelGGL(k_nearest_descriptor, dim3(nt < 65536 ? nt : 65536), dim3(64), lds, 0, b.dt, nt, b.dq, nq, dim, b.bt, b.dd2);
     SHIP(hipGetLastError());
     std::vector<int32_t> hq((size_t)nq), ht((size_t)nt);
-    SHIP(hipMemcpy(hq.data(), bq, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
-    SHIP(hipMemcpy(ht.data(), bt, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-    SHIP(hipMemcpy(dist, dd, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost));
-    (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(dd); (void)hipFree(dd2); (void)hipFree(bq); (void)hipFree(bt);
+    SHIP(hipMemcpy(hq.data(), b.bq, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
+    SHIP(hipMemcpy(ht.data(), b.bt, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+    SHIP(hipMemcpy(dist, b.dd, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost));
     // crossCheck: q keeps its nearest train descriptor only if that one's nearest query is q
     for (int q = 0; q < nq; ++q) train_of_query[q] = (hq[q] >= 0 && ht[hq[q]] == q) ? hq[q] : -1;
     return 0;
