@@ -84,12 +84,14 @@ public:
     int width = 0, height = 0, tilesX = 0;
     std::vector<int32_t> tileOf; // tile table: index into `heads` / kTileCells, or -1
     std::vector<int32_t> heads;
+    std::vector<int32_t> claimed; // per cell: the expansion round in which a unit claimed it (R(B), round_begin); -1 never
     void init(int w, int h)
     {
         width = w; height = h;
         tilesX = (w + kTile - 1) >> kShift;
         tileOf.assign((size_t)tilesX * ((h + kTile - 1) >> kShift), -1);
         heads.clear();
+        claimed.clear();
     }
     bool inMap(int x, int y) const { return !(x < 0 || y < 0 || x >= width || y >= height); } // cellmap.cpp:18-23
     bool tileEmpty(int x, int y) const { return tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)] < 0; }
@@ -111,8 +113,17 @@ public:
         if (t < 0) {
             t = (int32_t)(heads.size() / kTileCells);
             heads.resize(heads.size() + kTileCells, -1);
+            claimed.resize(claimed.size() + kTileCells, -1);
         }
         return &heads[(size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1))];
+    }
+    // first call for this cell in `round`: true (and the cell is marked); later calls of the round: false
+    bool claim(int x, int y, int round)
+    {
+        const size_t i = (size_t)(slot(x, y) - heads.data());
+        if (claimed[i] == round) return false;
+        claimed[i] = round;
+        return true;
     }
 };
 
@@ -209,7 +220,6 @@ struct pais_mvs {
     // round state
     std::vector<Active> active;        // ordered active set of the slot-synchronous rounds
     std::vector<Unit> deferred, nextDeferred; // cell-claim rule: units retried at the head of the next round
-    std::unordered_set<uint64_t> claims;
     int curRound = -1;
     int thinFront = PAIS_DEFAULT_THIN_FRONT; // rounds with <= thinFront active parents take all remaining slots of each parent
     bool queueExhausted = false;
@@ -1086,13 +1096,11 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
     m->cands.clear();
     m->candRecs.clear();
     m->nextDeferred.clear();
-    m->claims.clear();
     // one neighbour cell (x, y) of camera camI of the parent of unit u
     auto considerCell = [&](const Unit &u, const pais_patch_result &pr, int camI, const CellMap &map, int x, int y) {
         if (!map.inMap(x, y)) return;
         if (m->skipNeighborCell(map, x, y, pr, m->curRound)) return; // blocked before the round (== live: nothing inserted yet)
-        const uint64_t key = (((uint64_t)(uint32_t)camI) << 48) ^ (((uint64_t)(uint32_t)x) << 24) ^ (uint64_t)(uint32_t)y;
-        if (!m->claims.insert(key).second) { m->nextDeferred.push_back(u); return; } // one attempt per cell per round
+        if (!m->cellMaps[camI].claim(x, y, m->curRound)) { m->nextDeferred.push_back(u); return; } // one attempt per cell per round
         double center[3];
         m->expansionCenter(camI, pr, x, y, center);
         pais_candidate rec;
