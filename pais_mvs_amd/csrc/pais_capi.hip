@@ -59,7 +59,10 @@ struct pais_ctx {
     size_t hpBytes = 0;
     double *d_ratios = nullptr;         // region ratio per (candidate, visible camera) (k_region_ratio)
     size_t ratioBytes = 0;
-    int *d_counters = nullptr;          // [1] "needs another pass" count, [2] active-list length
+    int *d_counters = nullptr;          // two sets of 4: [1] "needs another pass" count, [2] active-list length; pass p uses set
+                                        // passSerial & 1, its k_after<2> clears the other one for the pass that follows
+    unsigned passSerial = 0;
+    bool countersDirty = false;         // a batch ended in an error: both sets are cleared before the next one
     pais_candidate *h_cands = nullptr;  // pinned staging of pais_refine_batch
     pais_patch_result *h_recs = nullptr;
     unsigned char *d_evalBlocks = nullptr; // per candidate: EvalPatch + EvalCam[M] (pais_eval.hpp), written by k_pso_init
@@ -284,8 +287,8 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     ctx->sc.imgF = ctx->d_imgF;
     ctx->sc.edgeBlob = ctx->d_edge;
 
-    HIPCHK(hipMalloc(&ctx->d_counters, sizeof(int) * 4));
-    HIPCHK(hipMemset(ctx->d_counters, 0, sizeof(int) * 4));
+    HIPCHK(hipMalloc(&ctx->d_counters, sizeof(int) * 8));
+    HIPCHK(hipMemset(ctx->d_counters, 0, sizeof(int) * 8));
     HIPCHK(hipMalloc(&ctx->d_stat, sizeof(unsigned long long) * 8));
     HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
     HIPCHK(hipHostMalloc((void **)&ctx->h_counters, sizeof(int) * 4, hipHostMallocDefault));
@@ -548,20 +551,26 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     if (grow(ctx, ctx->d_ratios, ctx->ratioBytes, sizeof(double) * PAIS_MAX_VIS * (size_t)n)) return -2;
     const size_t EB = pais_launch::eval_block_bytes_host(Kmax), WB = pais_launch::win_bytes_per_candidate(sc);
 
+    if (ctx->countersDirty) HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 8, ctx->stream));
+    ctx->countersDirty = true; // until this batch has run through
     Timed tb;
     if (tb.begin(ctx, ctx->stream, &ctx->evBegin)) return -2;
-    HIPCHK(pais_launch::begin(sc, d_cands, d_out, n, ctx->stream));
+    // head of refine() and the set-up of the first PSO run of every candidate in one launch
+    HIPCHK(pais_launch::begin(sc, d_cands, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, ctx->d_counters + 4 * (ctx->passSerial & 1) + 2,
+                              ctx->d_evalBlocks, ctx->d_win, Kmax, ctx->stream));
     if (tb.end()) return -2;
 
     int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
     const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
     const int maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
     for (int pass = 0; pass < maxPass; ++pass) {
-        HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 3, ctx->stream)); // [2]: length of the active list
+        int *cnt = ctx->d_counters + 4 * (ctx->passSerial & 1), *nextCnt = ctx->d_counters + 4 * ((ctx->passSerial + 1) & 1);
+        ctx->passSerial++;
         Timed tp;
         if (tp.begin(ctx, ctx->stream, &ctx->evPso)) return -2;
-        HIPCHK(pais_launch::pso_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, ctx->d_counters + 2, ctx->d_evalBlocks, ctx->d_win,
-                                     Kmax, ctx->stream));
+        if (pass > 0) // (pass 0: done by the begin launch)
+            HIPCHK(pais_launch::pso_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, cnt + 2, ctx->d_evalBlocks, ctx->d_win, Kmax,
+                                         ctx->stream));
         // k_pso_iter needs the swarm of a candidate in the lanes of one wave; a batch of several residency passes
         // (>= 3 x 12 waves per CU) is throughput bound: there the step replay in every evaluation wave (~13 % of a wave's
         // time) costs more than a separate one-wave-per-candidate k_pso_step launch per iteration, whose latency the other
@@ -605,7 +614,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 Timed te; // events on the stream the kernel is launched on
                 if (te.begin(ctx, q.st, &ctx->evEval)) return -2;
                 if (useIter)
-                    HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, q.lo, q.hi, Nmax, Kmax, d_out,
+                    HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, cnt + 2, q.lo, q.hi, Nmax, Kmax, d_out,
                                                  ctx->d_stat, it, 0, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
                 else
                     HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
@@ -619,7 +628,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
             const Slice &q = sl[k];
             // the launch after the last possible iteration only ends the runs still active
             if (useIter)
-                HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, ctx->d_counters + 2, q.lo, q.hi, Nmax, Kmax, d_out,
+                HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, cnt + 2, q.lo, q.hi, Nmax, Kmax, d_out,
                                              ctx->d_stat, maxIt + 1, 1, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
         }
         for (int sI = 1; sI < S; ++sI) {
@@ -633,14 +642,15 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         ctx->psoLaunches++;
         Timed ta;
         if (ta.begin(ctx, ctx->stream, &ctx->evAfter)) return -2;
-        HIPCHK(pais_launch::after(sc, d_out, n, ctx->d_hp, afterGrid, ctx->d_counters, ctx->d_stat, Kmax, ctx->d_ratios, ctx->stream));
+        HIPCHK(pais_launch::after(sc, d_out, n, ctx->d_hp, afterGrid, cnt, ctx->d_stat, Kmax, ctx->d_ratios, nextCnt, ctx->stream));
         if (ta.end()) return -2;
         if (!has_seeds) break;
-        HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->h_counters, cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ctx->h_counters[1] == 0) break;
         againCount = ctx->h_counters[1];
     }
+    ctx->countersDirty = false;
     return 0;
 }
 

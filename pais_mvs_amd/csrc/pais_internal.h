@@ -61,7 +61,8 @@ size_t eval_block_bytes_host(int Kmax);
 size_t win_bytes_per_candidate(const DevScene &sc);
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
                    double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream);
-hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream);
+hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, unsigned char *states, int Nmax,
+                 int *activeList, int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);
 hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream);
 hipError_t expand_image(const uint8_t *img, PaisImgT *out, size_t n, hipStream_t stream);
 hipError_t level_edge_minmax(const uint8_t *img, int w, int h, unsigned long long *minmax, hipStream_t stream);
@@ -76,5 +77,5 @@ hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *active
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                     unsigned long long *stat, hipStream_t stream);
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
-                 unsigned long long *stat, int Kmax, double *ratios, hipStream_t stream);
+                 unsigned long long *stat, int Kmax, double *ratios, int *nextCounters, hipStream_t stream);
 } // namespace pais_launch

@@ -504,7 +504,17 @@ __device__ void copy_record(pais_patch_result *dst, const pais_patch_result *src
 
 // ---------------------------------------------------------------- k_begin ---
 // candidate -> record; head of Patch::refine() (patch.cpp:117-136)
-__global__ __launch_bounds__(64) void k_begin(DevScene sc, const pais_candidate *cands, pais_patch_result *recs, int n)
+struct WinPix;
+__device__ void pso_init_candidate(const DevScene &sc, const pais_patch_result *P, int c, unsigned char *states, int Nmax,
+                                   int *activeList, int *activeCount, unsigned char *evalBlocks, size_t evalBlockBytes, WinPix *win,
+                                   int lane);
+// INIT: the wave goes straight on to the set-up of the candidate's first PSO run (k_pso_init's work) from the record it
+// still holds in LDS -- one launch and one dependent round trip fewer at the head of every batch.  (The pass counters it
+// adds to were cleared by the k_after<2> of the pass before: two sets used alternately, no memset launch per pass.)
+template <bool INIT>
+__global__ __launch_bounds__(64) void k_begin(DevScene sc, const pais_candidate *cands, pais_patch_result *recs, int n,
+                                              unsigned char *states, int Nmax, int *activeList, int *activeCount,
+                                              unsigned char *evalBlocks, size_t evalBlockBytes, WinPix *win)
 {
     __shared__ pais_patch_result st;
     const int lane = threadIdx.x;
@@ -565,6 +575,7 @@ __global__ __launch_bounds__(64) void k_begin(DevScene sc, const pais_candidate 
         }
         __syncthreads();
         copy_record(&recs[c], &st, lane);
+        if (INIT) pso_init_candidate(sc, &st, c, states, Nmax, activeList, activeCount, evalBlocks, evalBlockBytes, win, lane);
     }
 }
 
@@ -623,92 +634,97 @@ __device__ __forceinline__ PsoArrays pso_arrays(unsigned char *base, int Nmax, i
 // evalBlocks / win: per candidate the evaluation block of the run (pais_eval.hpp): EvalPatch + EvalCam[M] exactly as the
 // evaluation keeps them in LDS, and the reference window WinPix[S*S]; built ONCE per PSO run here, copied / read coalesced
 // by every evaluation wave of the run
+// set-up of ONE candidate's PSO run by one wave (P: its record -- in global memory, or the LDS copy k_begin just built)
+__device__ void pso_init_candidate(const DevScene &sc, const pais_patch_result *P, int c, unsigned char *states, int Nmax,
+                                   int *activeList, int *activeCount, unsigned char *evalBlocks, size_t evalBlockBytes, WinPix *win,
+                                   int lane)
+{
+    const size_t SB = pso_state_bytes(Nmax);
+    const int WS = win_stride(sc);
+    PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+    PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+    if (P->stage != PAIS_STAGE_PSO || P->dropped) {
+        if (lane == 0) { hd->active = 0; hd->started = 0; }
+        return;
+    }
+    const int type = P->type;
+    const int N = (type == PAIS_TYPE_SEED) ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
+    const int maxIt = (type == PAIS_TYPE_SEED) ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
+    // Patch::psoOptimization set-up (patch.cpp:183-200), identical in all lanes
+    const double ns0 = P->normalS[0], ns1 = P->normalS[1];
+    double L[3] = {0.0, ns1 - M_PI / 2.0, P->depthRange[0]};
+    double U[3] = {M_PI, ns1 + M_PI / 2.0, P->depthRange[1]};
+    if (type != PAIS_TYPE_SEED) {
+        double lo = ns0 - M_PI / sc.cfg.reduceNormalRange, hi = ns0 + M_PI / sc.cfg.reduceNormalRange;
+        L[0] = 0.0 < lo ? lo : 0.0;
+        U[0] = hi < M_PI ? hi : M_PI;
+        L[1] = ns1 - M_PI / sc.cfg.reduceNormalRange;
+        U[1] = ns1 + M_PI / sc.cfg.reduceNormalRange;
+    }
+    const double init[3] = {ns0, ns1, P->depth};
+    const uint64_t sb = stream_base(sc.seed, P->key);
+    const uint32_t run = (uint32_t)P->pso_runs;
+    if (lane == 0) {
+        for (int d = 0; d < 3; ++d) {
+            hd->rangeL[d] = L[d];
+            hd->rangeU[d] = U[d];
+            hd->rangeInter[d] = U[d] - L[d]; // psosolver.cpp:38
+            hd->init[d] = init[d];
+            hd->ray[d] = P->ray[d];
+        }
+        hd->N = N;
+        hd->maxIt = maxIt;
+        hd->localK = N < 5 ? N : 5; // psosolver.cpp:26
+        hd->run = (int)run;
+        hd->streamBase = sb;
+        hd->iw = 0.8;
+        hd->iteration = 0;
+        hd->gIdx = 0;
+        hd->gBestFitness = DBL_MAX;
+        hd->active = 1;
+        hd->started = 0;
+        hd->dyn[0].iw = 0.8;
+        hd->dyn[0].gBestFitness = DBL_MAX;
+        hd->dyn[0].gIdx = 0;
+        hd->dyn[0].iteration = 0;
+        hd->dyn[0].started = 0;
+        hd->refCam = P->ref_cam;
+        hd->LOD = P->lod;
+        hd->K = P->num_cam;
+        if (activeList) activeList[atomicAdd(activeCount, 1)] = c;
+    }
+    for (int k = lane; k < P->num_cam; k += 64) hd->camIdx[k] = P->cam_idx[k];
+    {
+        unsigned char *blk = evalBlocks + evalBlockBytes * (size_t)c;
+        build_eval_block(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), win + (size_t)c * WS, P->ray, P->ref_cam, P->lod,
+                         P->num_cam, P->cam_idx, lane);
+    }
+    // initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
+    for (int i = lane; i < N; i += 64) {
+        for (int d = 0; d < 3; ++d) {
+            const double ri = U[d] - L[d];
+            const double u1 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i)));
+            const double u2 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i) + 1));
+            double p = (ri * u1) + L[d];
+            double v = (2.0 * ri * u2) - ri;
+            if (i == 0) {
+                p = init[d];
+                v = (2.0 * ri * uniform_from(sb, run, (uint32_t)(6 * N + d))) - ri;
+            }
+            A.pos[i][d] = p;
+            A.vec[i][d] = v;
+            A.pBest[i][d] = p;
+            A.nBest[i][d] = 0; // particle.cpp:16
+        }
+    }
+}
 __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_result *recs, int n, unsigned char *states,
                                                  int Nmax, int *activeList, int *activeCount, unsigned char *evalBlocks,
                                                  size_t evalBlockBytes, WinPix *win)
 {
     const int lane = threadIdx.x;
-    const size_t SB = pso_state_bytes(Nmax);
-    const int WS = win_stride(sc);
-    for (int c = blockIdx.x; c < n; c += gridDim.x) {
-        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
-        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
-        const pais_patch_result *P = &recs[c];
-        if (P->stage != PAIS_STAGE_PSO || P->dropped) {
-            if (lane == 0) { hd->active = 0; hd->started = 0; }
-            continue;
-        }
-        const int type = P->type;
-        const int N = (type == PAIS_TYPE_SEED) ? sc.cfg.particleNum * 2 : sc.cfg.particleNum;
-        const int maxIt = (type == PAIS_TYPE_SEED) ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
-        // Patch::psoOptimization set-up (patch.cpp:183-200), identical in all lanes
-        const double ns0 = P->normalS[0], ns1 = P->normalS[1];
-        double L[3] = {0.0, ns1 - M_PI / 2.0, P->depthRange[0]};
-        double U[3] = {M_PI, ns1 + M_PI / 2.0, P->depthRange[1]};
-        if (type != PAIS_TYPE_SEED) {
-            double lo = ns0 - M_PI / sc.cfg.reduceNormalRange, hi = ns0 + M_PI / sc.cfg.reduceNormalRange;
-            L[0] = 0.0 < lo ? lo : 0.0;
-            U[0] = hi < M_PI ? hi : M_PI;
-            L[1] = ns1 - M_PI / sc.cfg.reduceNormalRange;
-            U[1] = ns1 + M_PI / sc.cfg.reduceNormalRange;
-        }
-        const double init[3] = {ns0, ns1, P->depth};
-        const uint64_t sb = stream_base(sc.seed, P->key);
-        const uint32_t run = (uint32_t)P->pso_runs;
-        if (lane == 0) {
-            for (int d = 0; d < 3; ++d) {
-                hd->rangeL[d] = L[d];
-                hd->rangeU[d] = U[d];
-                hd->rangeInter[d] = U[d] - L[d]; // psosolver.cpp:38
-                hd->init[d] = init[d];
-                hd->ray[d] = P->ray[d];
-            }
-            hd->N = N;
-            hd->maxIt = maxIt;
-            hd->localK = N < 5 ? N : 5; // psosolver.cpp:26
-            hd->run = (int)run;
-            hd->streamBase = sb;
-            hd->iw = 0.8;
-            hd->iteration = 0;
-            hd->gIdx = 0;
-            hd->gBestFitness = DBL_MAX;
-            hd->active = 1;
-            hd->started = 0;
-            hd->dyn[0].iw = 0.8;
-            hd->dyn[0].gBestFitness = DBL_MAX;
-            hd->dyn[0].gIdx = 0;
-            hd->dyn[0].iteration = 0;
-            hd->dyn[0].started = 0;
-            hd->refCam = P->ref_cam;
-            hd->LOD = P->lod;
-            hd->K = P->num_cam;
-            if (activeList) activeList[atomicAdd(activeCount, 1)] = c;
-        }
-        for (int k = lane; k < P->num_cam; k += 64) hd->camIdx[k] = P->cam_idx[k];
-        {
-            unsigned char *blk = evalBlocks + evalBlockBytes * (size_t)c;
-            build_eval_block(sc, (EvalPatch *)blk, (EvalCam *)(blk + sizeof(EvalPatch)), win + (size_t)c * WS, P->ray, P->ref_cam, P->lod,
-                             P->num_cam, P->cam_idx, lane);
-        }
-        // initParticles (psosolver.cpp:94-110) + setParticle(init) (:267-284)
-        for (int i = lane; i < N; i += 64) {
-            for (int d = 0; d < 3; ++d) {
-                const double ri = U[d] - L[d];
-                const double u1 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i)));
-                const double u2 = uniform_from(sb, run, (uint32_t)(2 * (d * N + i) + 1));
-                double p = (ri * u1) + L[d];
-                double v = (2.0 * ri * u2) - ri;
-                if (i == 0) {
-                    p = init[d];
-                    v = (2.0 * ri * uniform_from(sb, run, (uint32_t)(6 * N + d))) - ri;
-                }
-                A.pos[i][d] = p;
-                A.vec[i][d] = v;
-                A.pBest[i][d] = p;
-                A.nBest[i][d] = 0; // particle.cpp:16
-            }
-        }
-    }
+    for (int c = blockIdx.x; c < n; c += gridDim.x)
+        pso_init_candidate(sc, &recs[c], c, states, Nmax, activeList, activeCount, evalBlocks, evalBlockBytes, win, lane);
 }
 
 // The evaluation launch of large batches (split pipeline): one wave per (candidate, particle), nothing but the cost.
@@ -1250,8 +1266,14 @@ __global__ __launch_bounds__(64) void k_region_ratio(DevScene sc, const pais_pat
 template <int PHASE>
 __global__ __launch_bounds__(64 * AFTER_WAVES) void k_after(DevScene sc, pais_patch_result *recs, int n, double *hpScratch,
                                                               int *counters, unsigned long long *stat, int Kmax, double *ratios,
-                                                              int hpInLds)
+                                                              int hpInLds, int *nextCounters)
 {
+    // the counters the NEXT pass (of this or the next batch) will add to; nothing of this pass touches that set
+    if (PHASE == 2 && nextCounters && blockIdx.x == 0 && threadIdx.x == 0) {
+        nextCounters[0] = 0;
+        nextCounters[1] = 0;
+        nextCounters[2] = 0;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     pais_patch_result *st = (pais_patch_result *)smem;
     size_t off = (sizeof(pais_patch_result) + 15) & ~(size_t)15;
@@ -1531,11 +1553,14 @@ hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStat
     PAIS_SHAPE_DISPATCH(fitness_launch, sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
 }
 
-hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, hipStream_t stream)
+// k_begin + the set-up of the first PSO run of every candidate (what k_pso_init does in later passes)
+hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, unsigned char *states, int Nmax,
+                 int *activeList, int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     int grid = n < 16384 ? n : 16384;
-    hipLaunchKernelGGL(k_begin, dim3(grid), dim3(64), 0, stream, sc, cands, recs, n);
+    hipLaunchKernelGGL((k_begin<true>), dim3(grid), dim3(64), 0, stream, sc, cands, recs, n, states, Nmax, activeList, activeCount, evalBlocks,
+                       eval_block_bytes(Kmax), (WinPix *)win);
     return hipGetLastError();
 }
 
@@ -1631,7 +1656,7 @@ hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *
 }
 
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
-                 unsigned long long *stat, int Kmax, double *ratios, hipStream_t stream)
+                 unsigned long long *stat, int Kmax, double *ratios, int *nextCounters, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     static LdsAttr attr1, attr2;
@@ -1645,9 +1670,11 @@ hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpS
     if (e != hipSuccess) return e;
     const int rgrid = (int)(((long)n * Kmax + 63) / 64);
     hipLaunchKernelGGL(k_region_ratio, dim3(rgrid), dim3(64), 0, stream, sc, recs, n, PAIS_STAGE_AFTER, ratios, Kmax);
-    hipLaunchKernelGGL((k_after<1>), dim3(grid), dim3(64 * AFTER_WAVES), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax, ratios, hpInLds);
+    hipLaunchKernelGGL((k_after<1>), dim3(grid), dim3(64 * AFTER_WAVES), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax, ratios, hpInLds,
+                       (int *)nullptr);
     hipLaunchKernelGGL(k_region_ratio, dim3(rgrid), dim3(64), 0, stream, sc, recs, n, PAIS_STAGE_AFTER2, ratios, Kmax);
-    hipLaunchKernelGGL((k_after<2>), dim3(grid), dim3(64 * AFTER_WAVES), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax, ratios, hpInLds);
+    hipLaunchKernelGGL((k_after<2>), dim3(grid), dim3(64 * AFTER_WAVES), lds, stream, sc, recs, n, hpScratch, counters, stat, Kmax, ratios, hpInLds,
+                       nextCounters);
     return hipGetLastError();
 }
 
