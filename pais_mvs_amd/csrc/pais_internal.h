@@ -11,6 +11,7 @@
 #define PAIS_STAGE_AFTER 2  /* PSO finished, removeInvisibleCamera etc. pending     */
 #define PAIS_STAGE_AFTER2 3 /* refine() has ended: the caller's removeInvisibleCamera (mvs.cpp:215 / :574) pending */
 #define PAIS_STAGE_AFTER2_KEEP 4 /* ... and the region ratios of the first call are still valid                     */
+#define PAIS_STAGE_AFTER2_SAME 7 /* ... and the first call removed no camera: the second one sees the very same inputs (5, 6: PAIS_DONE_*) */
 
 // HBM layout: one DevCamera per camera in a dense array;
 // every pyramid level of every camera repacked row-major with stride == width

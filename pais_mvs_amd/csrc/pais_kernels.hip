@@ -1287,7 +1287,8 @@ __global__ __launch_bounds__(64 * AFTER_WAVES) void k_after(DevScene sc, pais_pa
     double *hp = hpInLds ? (double *)(smem + off) : hpScratch + (size_t)blockIdx.x * Kmax * S2;
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
         const int stg = recs[c].stage;
-        if (PHASE == 1 ? (stg != PAIS_STAGE_AFTER) : (stg != PAIS_STAGE_AFTER2 && stg != PAIS_STAGE_AFTER2_KEEP)) continue;
+        if (PHASE == 1 ? (stg != PAIS_STAGE_AFTER) : (stg != PAIS_STAGE_AFTER2 && stg != PAIS_STAGE_AFTER2_KEEP && stg != PAIS_STAGE_AFTER2_SAME))
+            continue;
         __syncthreads();
         copy_record(st, &recs[c], threadIdx.x, 64 * AFTER_WAVES);
         __syncthreads();
@@ -1295,8 +1296,9 @@ __global__ __launch_bounds__(64 * AFTER_WAVES) void k_after(DevScene sc, pais_pa
         const int nccBefore = st->ncc_tables;
         double *rat = ratios + (size_t)c * PAIS_MAX_VIS;
         if (PHASE == 1) {
-            const int refBefore = st->ref_cam, lodBefore = st->lod;
+            const int refBefore = st->ref_cam, lodBefore = st->lod, numBefore = st->num_cam;
             remove_invisible_camera(sc, st, hp, table, Hn, flag, rat, lane, wave);
+            const bool removedNone = st->num_cam == numBefore; // (read behind the call's closing barrier, by every thread alike)
             set_reference_camera(sc, st, lane);
             set_depth_and_ray(sc, st, lane);
             set_depth_range(sc, st, lane);
@@ -1343,12 +1345,21 @@ __global__ __launch_bounds__(64 * AFTER_WAVES) void k_after(DevScene sc, pais_pa
                 // and LOD the homographies -- and so the region ratios of the cameras that stayed -- are too
                 if (lead)
                     st->stage = st->dropped ? PAIS_STAGE_DONE
-                                            : ((st->ref_cam == refBefore && st->lod == lodBefore) ? PAIS_STAGE_AFTER2_KEEP : PAIS_STAGE_AFTER2);
+                                            : ((st->ref_cam == refBefore && st->lod == lodBefore)
+                                                   ? (removedNone ? PAIS_STAGE_AFTER2_SAME : PAIS_STAGE_AFTER2_KEEP)
+                                                   : PAIS_STAGE_AFTER2);
             }
             __syncthreads();
             if (lead && again) atomicAdd(&counters[1], 1);
         } else {
-            remove_invisible_camera(sc, st, hp, table, Hn, flag, rat, lane, wave); // mvs.cpp:215 / :574
+            // mvs.cpp:215 / :574.  PAIS_STAGE_AFTER2_SAME: the first call removed nothing and the setters left the reference
+            // camera and the LOD alone, so this call would warp the same patches of the same cameras with the same
+            // homographies, build the same table and again remove nothing -- only its call count is carried
+            if (stg == PAIS_STAGE_AFTER2_SAME) {
+                if (lead) st->ncc_tables += 1;
+            } else {
+                remove_invisible_camera(sc, st, hp, table, Hn, flag, rat, lane, wave);
+            }
             __syncthreads();
             // the scene half of MVS::runtimeFiltering (mvs.cpp:851-863) for the caller's insertPatch: one thread per camera
             int finalStage = PAIS_DONE;
