@@ -248,6 +248,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     dt = job.max_over_ranks(dt)
+    # the cloud of the LAST TIMED step, hashed (outside the timed region): pais_mvs_amd.mvs.patches_sha1 over every
+    # accepted patch in id order.  tests/golden/bench_cloud_<scene>.json holds what the ORACLE produces for the default
+    # workload (tests/golden/make_bench_golden.py) -- the line checks itself against it.
+    cloud_sha1 = m.cloud_sha1() if rank == 0 else None
+    accepted = int(m.num_patches())
     # Roofline leg (not part of `value`): ONE more step of the same workload with every cost-evaluation launch
     # bracketed by HIP events on the stream it is launched on (two overlapping sub-streams by default).
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 1)
@@ -258,6 +263,15 @@ def main():
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
 
     if rank == 0:
+        gold_sha, gold_ok = None, None
+        try:
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_cloud_%s.json" % args.scene)))
+            if (g["seeds"], g["parents_per_round"], g["max_rounds"], g["pso_seed"]) == (len(scene.seeds), B, args.max_rounds, 42):
+                gold_sha = g["cloud_sha1"]
+                gold_ok = bool(cloud_sha1 == gold_sha and accepted == g["accepted_patches"]
+                               and units // max(args.steps, 1) == g["patches_per_step"])
+        except Exception:
+            pass
         k_ms = ks.eval_ms                      # sum of the launch durations of the dominant kernel
         k_launches = max(int(ks.eval_launches), 1)
         pso_gbs = (ks.pso_algorithmic_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
@@ -284,7 +298,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": wname, "parents_per_round": B, "seeds": len(scene.seeds),
                        "patches_per_step": units // max(args.steps, 1),
-                       "accepted_patches": int(m.num_patches()),
+                       "accepted_patches": accepted,
+                       "cloud_sha1": cloud_sha1, "cloud_sha1_expected": gold_sha, "cloud_matches_oracle_golden": gold_ok,
                        "speculative_extra_refines_per_step": spec // max(args.steps, 1),
                        "rounds_per_step": int(last.rounds) if last else 0,
                        "pso_evals_per_patch": evals_eff / max(units, 1),

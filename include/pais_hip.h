@@ -223,6 +223,12 @@ typedef struct pais_kernel_stats {
     int64_t  ncc_tables;
     double   eval_ms;
     int64_t  eval_launches;
+    /* the large-batch evaluation kernel k_pso_eval2 ALONE (a subset of eval_ms / eval_launches / pso_evals /
+     * pso_algorithmic_bytes): its launches are throughput bound, the k_pso_iter launches of small batches latency bound */
+    double   eval2_ms;
+    int64_t  eval2_launches;
+    int64_t  eval2_evals;
+    double   eval2_algorithmic_bytes;
 } pais_kernel_stats;
 int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
 /* on != 0: bracket every cost-evaluation launch (k_pso_iter / k_fitness) with HIP events on the stream it is

@@ -682,9 +682,10 @@ static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const
     s2n(s, sph, normal);
     if (dot3(normal, refCam->optN) > 0) return DBL_MAX; /* :939 */
 
-    /* the window of the run (:952-962) */
+    /* the window of the run (:952-962); windowPerParticle (diagnosis only, tests/test_oracle_modes.py): from the
+     * particle's own centre as the reference does -- the same point up to rounding */
     double c1[3], pt[2];
-    for (int i = 0; i < 3; ++i) c1[i] = patch->ray[i] * 1.0 + refCam->C[i];
+    for (int i = 0; i < 3; ++i) c1[i] = patch->ray[i] * (s->windowPerParticle ? pos[2] : 1.0) + refCam->C[i];
     if (!po_project(s, patch->refCamIdx, c1, pt, LOD)) return DBL_MAX;
     if (pt[0] - r < 2 || pt[0] + r >= refCols - 3 || pt[1] - r < 2 || pt[1] + r >= refRows - 3) return DBL_MAX;
     if (!(fabs(pos[2]) > 0)) return DBL_MAX; /* centre == C_ref: the reference's own projection is 0/0 */
@@ -916,7 +917,9 @@ void po_pso_run(int dim, const double *rangeL_, const double *rangeU_,
             gBestFitness = P[j].pBestFitness;                              \
             gIdx = j;                                                      \
         }                                                                  \
-    }
+    }                                                                      \
+    gSig = (gSig ^ (uint64_t)(gIdx + 1)) * 1099511628211ULL; /* which particle owns gBest, iteration by iteration */
+    uint64_t gSig = 1469598103934665603ULL;
     UPDATE_GBEST();
 
     int iteration;
@@ -1033,6 +1036,7 @@ void po_pso_run(int dim, const double *rangeL_, const double *rangeU_,
     res->gBestFitness = gBestFitness;
     res->iterations = iteration;
     res->evals = evals;
+    res->gbestSig = (gSig ^ (uint64_t)(iteration + 1)) * 1099511628211ULL;
     free(P);
 #undef RANDOM
 #undef UPDATE_GBEST
@@ -1351,6 +1355,7 @@ void po_pso_optimization(const po_scene *s, po_patch *p)
     p->psoRuns++;
     p->psoIters += res.iterations;
     p->psoEvals += res.evals;
+    p->psoSig = (p->psoSig ^ res.gbestSig) * 1099511628211ULL;
 
     p->fitness = res.gBestFitness;
     double ns[2] = {res.gBest[0], res.gBest[1]};
@@ -1611,7 +1616,7 @@ void po_refine_seed(const po_scene *s, po_patch *p)
 /* ------------------------------------------------------------------------ */
 /* MVS: mvs/mvs.cpp, mvs/cellmap.cpp                                         */
 /* ------------------------------------------------------------------------ */
-typedef struct { int n, cap; int *ids; } po_cell;
+typedef struct { int n, cap; int *ids; int claimRound; } po_cell;
 typedef struct { int width, height; po_cell *cells; } po_cellmap;
 
 struct po_mvs {
@@ -1628,6 +1633,10 @@ struct po_mvs {
     int bornCap;
     int curRound;
     int thinFront; /* R(B): rounds whose active set has <= thinFront parents take ALL remaining camera slots of every parent */
+    long speculative; /* parallel mode: records evaluated ahead that the sequential replay did not consume */
+    int parallel;  /* po_mvs_set_parallel: refine() of the units a round is going to look at is evaluated ahead of the sequential
+                    * replay, one candidate per OpenMP thread.  refine() is a pure function of (scene, candidate), so the replay
+                    * consumes the very same records it would compute itself (tests/test_oracle_parallel.py) */
 };
 
 po_mvs *po_mvs_create(po_scene *s)
@@ -1874,15 +1883,27 @@ void po_mvs_refine_seed_patches(po_mvs *m)
 {
     if (m->nalive == 0) return;
     po_mvs_set_neighbor_radius(m);
+    char *ahead = NULL; /* parallel mode: seeds whose refine() was evaluated ahead of the sequential loop */
+    if (m->parallel) {  /* (nothing a seed's refine() reads changes in that loop) */
+        po_scene local = *m->s;
+        local.ompParticles = 0;
+        ahead = (char *)calloc((size_t)m->nslots + 1, 1);
+        for (int id = 0; id < m->nslots; ++id)
+            ahead[id] = m->patches[id] && m->patches[id]->numCam >= local.cfg.minCamNum;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int id = 0; id < m->nslots; ++id)
+            if (ahead[id]) po_refine_seed(&local, m->patches[id]);
+    }
     for (int id = 0; id < m->nslots; ++id) {
         po_patch *pth = m->patches[id];
         if (!pth) continue;
-        if (pth->numCam < m->s->cfg.minCamNum) { mvs_delete_patch(m, id); continue; }
-        po_refine_seed(m->s, pth);
+        if (ahead ? !ahead[id] : (pth->numCam < m->s->cfg.minCamNum)) { mvs_delete_patch(m, id); continue; }
+        if (!ahead) po_refine_seed(m->s, pth);
         m->refineCalls++;
         m->fitnessEvals += pth->psoEvals;
         if (!po_runtime_filtering(m, pth)) { mvs_delete_patch(m, id); continue; }
     }
+    free(ahead);
     po_mvs_set_neighbor_radius(m);
 }
 
@@ -2045,6 +2066,18 @@ static void mvs_insert_patch(po_mvs *m, po_patch *pth)
     }
 }
 
+/* expandCell (mvs.cpp:566-577) for neighbour j of camera slot i of a parent, without the insert */
+static void mvs_make_child(const po_scene *s, const po_patch *pth, int i, int j, po_patch *child)
+{
+    const int camI = pth->camIdx[i];
+    int cx = (int)(pth->imgPoint[i][0] / s->cfg.cellSize);
+    int cy = (int)(pth->imgPoint[i][1] / s->cfg.cellSize);
+    const int nx[] = {cx - 1, cx, cx + 1, cx};
+    const int ny[] = {cy, cy - 1, cy, cy + 1};
+    double center[3];
+    po_expansion_center(s, camI, pth, nx[j], ny[j], center);
+    po_expand_candidate(s, child, center, pth->normal, pth->numCam, pth->camIdx, po_child_key(pth->key, camI, nx[j], ny[j]));
+}
 /* expandCell (mvs.cpp:566-577) for neighbour j of camera slot i of a parent */
 static void mvs_expand_one(po_mvs *m, int parentId, int i, int j)
 {
@@ -2131,7 +2164,62 @@ long po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail)
         if (nW > capClaims) { capClaims = nW * 2; claims = (uint64_t *)realloc(claims, sizeof(uint64_t) * (size_t)capClaims); }
         int nClaims = 0;
         nNext = 0;
-        for (int u = 0; u < nW; ++u) {
+        /* po_mvs_set_parallel: the same walk in three phases.  (A) what a unit does -- dropped, deferred or claimed -- depends on
+         * the state before the round alone (skip test with beforeRound, claims in work-list order); (B) refine() of the
+         * claimed units, one per thread; (C) the sequential replay of the loop below with the records of (B). */
+        if (m->parallel) {
+            int *cl = (int *)malloc(sizeof(int) * (size_t)(nW > 0 ? nW : 1));
+            int nCl = 0;
+            for (int u = 0; u < nW; ++u) {
+                const po_patch *pth = m->patches[work[u].id];
+                const int i = work[u].slot, j = work[u].j;
+                const int camI = pth->camIdx[i];
+                po_cellmap *map = &m->cellMaps[camI];
+                int cx = (int)(pth->imgPoint[i][0] / s->cfg.cellSize);
+                int cy = (int)(pth->imgPoint[i][1] / s->cfg.cellSize);
+                const int nx[] = {cx - 1, cx, cx + 1, cx};
+                const int ny[] = {cy, cy - 1, cy, cy + 1};
+                if (!cm_in_map(map, nx[j], ny[j])) continue;
+                po_cell *cell = &map->cells[(long)ny[j] * map->width + nx[j]];
+                if (skip_neighbor_cell(m, cell, pth, m->curRound)) continue;
+                if (cell->claimRound == m->curRound + 1) { /* (stamp = round + 1: calloc'ed cells start unclaimed) */
+                    if (nNext == capNext) { capNext = capNext ? capNext * 2 : 256; nextDef = (po_unit *)realloc(nextDef, sizeof(po_unit) * (size_t)capNext); }
+                    nextDef[nNext++] = work[u];
+                    continue;
+                }
+                cell->claimRound = m->curRound + 1;
+                cl[nCl++] = u;
+            }
+            po_patch *pre = (po_patch *)malloc(sizeof(po_patch) * (size_t)(nCl > 0 ? nCl : 1));
+            {
+                po_scene local = *s;
+                local.ompParticles = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+                for (int q = 0; q < nCl; ++q)
+                    mvs_make_child(&local, m->patches[work[cl[q]].id], work[cl[q]].slot, work[cl[q]].j, &pre[q]);
+            }
+            for (int q = 0; q < nCl; ++q) {
+                const int u = cl[q];
+                const po_patch *pth = m->patches[work[u].id];
+                const int i = work[u].slot, j = work[u].j;
+                const int camI = pth->camIdx[i];
+                po_cellmap *map = &m->cellMaps[camI];
+                int cx = (int)(pth->imgPoint[i][0] / s->cfg.cellSize);
+                int cy = (int)(pth->imgPoint[i][1] / s->cfg.cellSize);
+                const int nx[] = {cx - 1, cx, cx + 1, cx};
+                const int ny[] = {cy, cy - 1, cy, cy + 1};
+                const po_cell *cell = &map->cells[(long)ny[j] * map->width + nx[j]];
+                if (skip_neighbor_cell(m, cell, pth, -1)) continue; /* mvs.cpp:558 on the live state */
+                m->refineCalls++;
+                m->fitnessEvals += pre[q].psoEvals;
+                m->speculative--; /* (counted below: claimed units whose record the replay did not consume) */
+                mvs_insert_patch(m, &pre[q]);
+            }
+            m->speculative += nCl;
+            free(pre);
+            free(cl);
+        }
+        for (int u = 0; u < nW && !m->parallel; ++u) {
             const po_patch *pth = m->patches[work[u].id];
             const int i = work[u].slot, j = work[u].j;
             const int camI = pth->camIdx[i];
@@ -2363,6 +2451,8 @@ void po_mvs_neighbor_patch_filtering(po_mvs *m, double neighborRatio, int *count
 }
 
 void po_mvs_set_thin_front(po_mvs *m, int thinFront) { m->thinFront = thinFront < 0 ? 0 : thinFront; }
+void po_mvs_set_parallel(po_mvs *m, int on) { m->parallel = on ? 1 : 0; }
+long po_mvs_speculative(const po_mvs *m) { return m->speculative; }
 
 size_t po_sizeof_patch(void) { return sizeof(po_patch); }
 size_t po_sizeof_config(void) { return sizeof(po_config); }

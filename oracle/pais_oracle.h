@@ -104,6 +104,9 @@ typedef struct po_scene {
      * measures (on the CPU) how far the two modes drift apart. */
     int        detMath;
     int        treeSum;
+    int        windowPerParticle;        /* kernel arithmetic, but the window origin from every particle's own centre
+                                          * (patch.cpp:944-952) instead of once per run: separates the two differences
+                                          * between the modes in tests/test_oracle_modes.py; the HIP path has no such mode */
 } po_scene;
 
 /* mvs/abstractpatch.h:22-53 + patch.h:19-20 */
@@ -132,6 +135,8 @@ typedef struct po_patch {
     int      psoRuns;    /* number of psoOptimization() calls so far  */
     int      psoIters;   /* sum of PsoSolver::getIteration()          */
     int      psoEvals;   /* number of getFitness calls                */
+    int      pad0;
+    uint64_t psoSig;     /* fold of po_pso_result::gbestSig over the patch's PSO runs */
 } po_patch;
 
 /* ---- deterministic uniform stream (replaces rand()/srand(time)) */
@@ -172,6 +177,8 @@ typedef struct po_pso_result {
     double gBestFitness;
     int    iterations;
     int    evals;
+    uint64_t gbestSig;   /* FNV fold of the index of the particle that owns gBest after every updateGbest, and of the
+                          * iteration count: two runs with equal signatures took the same discrete trajectory */
 } po_pso_result;
 /* trace (optional): per iteration, per particle: pos[3] vec[3] pBest[3] fitness pBestFitness, then gIdx, iw */
 void po_pso_run(int dim, const double *rangeL, const double *rangeU,
@@ -222,6 +229,10 @@ long    po_mvs_expansion_patches(po_mvs *m, int B, int maxRounds, int strictTail
  * parent instead of one (0 = never).  Same rule and default as pais_mvs_set_thin_front (include/pais_mvs.h). */
 #define PO_DEFAULT_THIN_FRONT 64
 void    po_mvs_set_thin_front(po_mvs *m, int thinFront);
+/* refine() of the seeds / of the units a round claims is evaluated ahead of the sequential replay, one candidate per OpenMP
+ * thread (refine() is a pure function of scene and candidate: same records, same cloud -- tests/test_oracle_parallel.py) */
+void    po_mvs_set_parallel(po_mvs *m, int on);
+long    po_mvs_speculative(const po_mvs *m);
 /* Patch::reCentering (patch.cpp:67-112): imgPoints numCam x 2 pixels -> center */
 void    po_recenter(const po_scene *s, int numCam, const int *camIdx, const double *imgPoints, double center[3]);
 /* post filters (`-f` verb, TMVS.cpp:124-172; mvs.cpp:278-524) and the .mvs loader constructor (patch.cpp:45-59) */

@@ -46,7 +46,7 @@ class SceneS(C.Structure):
     _fields_ = [
         ("cfg", Config), ("numCams", C.c_int), ("cams", C.POINTER(CameraS)), ("gauss", C.POINTER(C.c_double)),
         ("lodScale", C.c_double * MAX_LEVELS), ("seed", C.c_uint64), ("ompParticles", C.c_int),
-        ("detMath", C.c_int), ("treeSum", C.c_int),
+        ("detMath", C.c_int), ("treeSum", C.c_int), ("windowPerParticle", C.c_int),
     ]
 
 
@@ -58,7 +58,8 @@ class Patch(C.Structure):
         ("depthRange", C.c_double * 2), ("LOD", C.c_int), ("imgPoint", (C.c_double * 2) * MAX_VIS),
         ("fitness", C.c_double), ("priority", C.c_double), ("correlation", C.c_double),
         ("corrTable", C.c_double * (MAX_VIS * MAX_VIS)),
-        ("key", C.c_uint64), ("psoRuns", C.c_int), ("psoIters", C.c_int), ("psoEvals", C.c_int),
+        ("key", C.c_uint64), ("psoRuns", C.c_int), ("psoIters", C.c_int), ("psoEvals", C.c_int), ("pad0", C.c_int),
+        ("psoSig", C.c_uint64),
     ]
 
     def cams(self) -> List[int]:
@@ -66,7 +67,8 @@ class Patch(C.Structure):
 
 
 class PsoResult(C.Structure):
-    _fields_ = [("gBest", C.c_double * 3), ("gBestFitness", C.c_double), ("iterations", C.c_int), ("evals", C.c_int)]
+    _fields_ = [("gBest", C.c_double * 3), ("gBestFitness", C.c_double), ("iterations", C.c_int), ("evals", C.c_int),
+                ("gbestSig", C.c_uint64)]
 
 
 class FitCtx(C.Structure):
@@ -155,6 +157,9 @@ def lib():
     L.po_mvs_set_neighbor_radius.argtypes = [C.c_void_p]
     L.po_mvs_refine_seed_patches.argtypes = [C.c_void_p]
     L.po_mvs_set_thin_front.argtypes = [C.c_void_p, C.c_int]
+    L.po_mvs_set_parallel.argtypes = [C.c_void_p, C.c_int]
+    L.po_mvs_speculative.restype = C.c_long
+    L.po_mvs_speculative.argtypes = [C.c_void_p]
     L.po_recenter.argtypes = [C.POINTER(SceneS), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     # po_seed.c: FeatureManager::setSeedPatches after the SIFT call
     fpp = C.POINTER(C.c_float)

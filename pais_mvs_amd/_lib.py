@@ -71,7 +71,9 @@ class KernelStats(C.Structure):
     _fields_ = [("pso_ms", C.c_double), ("begin_ms", C.c_double), ("after_ms", C.c_double),
                 ("pso_launches", C.c_int64), ("pso_evals", C.c_int64), ("pso_patches", C.c_int64),
                 ("pso_algorithmic_bytes", C.c_double), ("ncc_algorithmic_bytes", C.c_double),
-                ("ncc_tables", C.c_int64), ("eval_ms", C.c_double), ("eval_launches", C.c_int64)]
+                ("ncc_tables", C.c_int64), ("eval_ms", C.c_double), ("eval_launches", C.c_int64),
+                ("eval2_ms", C.c_double), ("eval2_launches", C.c_int64), ("eval2_evals", C.c_int64),
+                ("eval2_algorithmic_bytes", C.c_double)]
 
 
 _lib = None

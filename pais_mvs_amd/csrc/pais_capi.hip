@@ -98,10 +98,10 @@ struct pais_ctx {
     // timing: HIP events are recorded only while profiling is on (pais_ctx_set_fine_timing); every pair is returned to
     // evFree by pais_get_kernel_stats, so the number of live events is bounded by one instrumented batch
     bool fineTiming = false;
-    std::vector<EventPair> evPso, evBegin, evAfter, evEval;
+    std::vector<EventPair> evPso, evBegin, evAfter, evEval, evEval2;
     std::vector<EventPair> evFree;
-    double psoMs = 0, beginMs = 0, afterMs = 0, evalMs = 0;
-    int64_t psoLaunches = 0, evalLaunches = 0;
+    double psoMs = 0, beginMs = 0, afterMs = 0, evalMs = 0, eval2Ms = 0;
+    int64_t psoLaunches = 0, evalLaunches = 0, eval2Launches = 0;
 };
 
 // MVS::initPatchDistanceWeighting, mvs.cpp:97-114 (host; same arithmetic as the reference)
@@ -320,7 +320,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         v.clear();
     };
-    freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evEval); freeEv(ctx->evFree);
+    freeEv(ctx->evPso); freeEv(ctx->evBegin); freeEv(ctx->evAfter); freeEv(ctx->evEval); freeEv(ctx->evEval2); freeEv(ctx->evFree);
     (void)hipFree(ctx->d_psoStates);
     (void)hipFree(ctx->d_win);
     (void)hipFree(ctx->d_ratios);
@@ -612,7 +612,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 const Slice &q = sl[k];
                 unsigned char *stp = ctx->d_psoStates + SB * (size_t)q.lo;
                 Timed te; // events on the stream the kernel is launched on
-                if (te.begin(ctx, q.st, &ctx->evEval)) return -2;
+                if (te.begin(ctx, q.st, useIter ? &ctx->evEval : &ctx->evEval2)) return -2;
                 if (useIter)
                     HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, cnt + 2, q.lo, q.hi, Nmax, Kmax, d_out,
                                                  ctx->d_stat, it, 0, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
@@ -621,6 +621,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                                                  ctx->d_win + WB * (size_t)q.lo, q.st));
                 if (te.end()) return -2;
                 ctx->evalLaunches++;
+                if (!useIter) ctx->eval2Launches++;
                 if (!useIter) HIPCHK(pais_launch::pso_step(sc, d_out + q.lo, stp, q.hi - q.lo, Nmax, ctx->d_stat, q.st));
             }
         }
@@ -715,6 +716,12 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
     if (drain_events(ctx, ctx->evBegin, ctx->beginMs)) return -2;
     if (drain_events(ctx, ctx->evAfter, ctx->afterMs)) return -2;
     if (drain_events(ctx, ctx->evEval, ctx->evalMs)) return -2;
+    {
+        double ms2 = 0;
+        if (drain_events(ctx, ctx->evEval2, ms2)) return -2;
+        ctx->eval2Ms += ms2;
+        ctx->evalMs += ms2;
+    }
     unsigned long long st[8];
     HIPCHK(hipMemcpy(st, ctx->d_stat, sizeof(st), hipMemcpyDeviceToHost));
     const double S2 = (double)ctx->sc.cfg.patchSize * ctx->sc.cfg.patchSize;
@@ -729,11 +736,16 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
     out->ncc_algorithmic_bytes = (double)st[4] * S2 * 4.0;
     out->eval_ms = ctx->evalMs;
     out->eval_launches = ctx->evalLaunches;
+    out->eval2_ms = ctx->eval2Ms;
+    out->eval2_launches = ctx->eval2Launches;
+    out->eval2_evals = (int64_t)st[5];
+    out->eval2_algorithmic_bytes = (double)st[6] * S2;
     if (reset) {
         HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
-        ctx->psoMs = ctx->beginMs = ctx->afterMs = ctx->evalMs = 0;
+        ctx->psoMs = ctx->beginMs = ctx->afterMs = ctx->evalMs = ctx->eval2Ms = 0;
         ctx->psoLaunches = 0;
         ctx->evalLaunches = 0;
+        ctx->eval2Launches = 0;
     }
     return 0;
 }

@@ -1205,6 +1205,8 @@ __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c,
         atomicAdd(&stat[0], (unsigned long long)evals);
         atomicAdd(&stat[1], (unsigned long long)evals * perEval);
         atomicAdd(&stat[2], 1ULL);
+        atomicAdd(&stat[5], (unsigned long long)evals); // ... of which by the large-batch pipeline (k_pso_eval2)
+        atomicAdd(&stat[6], (unsigned long long)evals * perEval);
     }
     return 0;
 }

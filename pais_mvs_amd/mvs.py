@@ -78,6 +78,18 @@ def _bind(L):
     L._mvs_bound = True
 
 
+def patches_sha1(rows) -> str:
+    """rows: (center[3], normalS[2], camIdx list, fitness, correlation) per patch in id order -> hex SHA-1 of the bytes
+    FileWriter::writeMVS stores for them (io/filewriter.cpp:97-99)."""
+    import hashlib
+    import struct
+    h = hashlib.sha1()
+    for cen, ns, cams, fit, corr in rows:
+        k = len(cams)
+        h.update(struct.pack("<5di%di2d" % k, *cen, *ns, k, *cams, fit, corr))
+    return h.hexdigest()
+
+
 def get_unique_id() -> bytes:
     """ncclGetUniqueId through the C ABI: call on ONE rank and hand the 128 bytes to the others."""
     L = _lib.load()
@@ -271,6 +283,12 @@ class MVS:
         """(N, 6) array of patch centres and normals in id order."""
         ps = self.patches()
         return np.array([[*p.center[:], *p.normal[:]] for p in ps], dtype=np.float64).reshape(-1, 6)
+
+    def cloud_sha1(self) -> str:
+        """SHA-1 over the PATCHES payload of an MVS_V3 file (io/filewriter.cpp:97-99: per patch in id order centre[3],
+        normalS[2], int K, int camIdx[K], fitness, correlation -- raw little-endian bytes): one string that pins every
+        accepted patch, its order and its camera set."""
+        return patches_sha1((p.center[:], p.normalS[:], p.cams(), p.fitness, p.correlation) for p in self.patches())
 
     # ---- writers (MVS::writeMVS / writePLY / writePSR, mvs.cpp:174-184 -> io/filewriter.cpp)
     def _io_cameras(self):

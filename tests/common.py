@@ -53,3 +53,29 @@ def same_value(a: float, b: float, rtol: float) -> bool:
     if a == b:
         return True
     return abs(a - b) <= rtol * max(abs(a), abs(b))
+
+
+def oracle_reconstruct(cfg, scene, B, max_rounds=0, parallel=True, kernel_arithmetic=True, thin_front=None, seed=42):
+    """Seeds + expansion through the oracle's drivers (po_mvs_refine_seed_patches / po_mvs_expansion_patches).
+    Returns (rows for patches_sha1, refine calls, accepted patches, speculative records of the parallel mode)."""
+    S = oracle_scene(cfg, scene, seed=seed)
+    S.set_kernel_arithmetic(kernel_arithmetic)
+    L = po.lib()
+    mo = L.po_mvs_create(S.ptr)
+    L.po_mvs_set_parallel(mo, 1 if parallel else 0)
+    if thin_front is not None:
+        L.po_mvs_set_thin_front(mo, thin_front)
+    for X, vis in scene.seeds:
+        L.po_mvs_add_seed(mo, po.darr(X), len(vis), po.iarr(vis))
+    L.po_mvs_refine_seed_patches(mo)
+    L.po_mvs_expansion_patches(mo, B, max_rounds, 1)
+    rows = []
+    for i in range(L.po_mvs_num_slots(mo)):
+        pp = L.po_mvs_get_patch(mo, i)
+        if pp:
+            p = pp.contents
+            rows.append((list(p.center[:]), list(p.normalS[:]), p.cams(), p.fitness, p.correlation))
+    calls, acc, spec = L.po_mvs_refine_calls(mo), L.po_mvs_num_patches(mo), L.po_mvs_speculative(mo)
+    L.po_mvs_destroy(mo)
+    S.close()
+    return rows, calls, acc, spec

@@ -1,0 +1,20 @@
+"""The oracle's candidate-parallel mode (po_mvs_set_parallel) against its sequential statement: refine() is a pure
+function of (scene, candidate), so evaluating the units a round claims ahead of the sequential replay must give the
+same cloud, patch for patch and bit for bit, for every schedule R(B) -- the mode exists so that the FULL-SIZE bench
+workload can be checked against the oracle in a minute instead of an hour (tests/test_bench_parity.py)."""
+import pytest
+
+from pais_mvs_amd.config import readme_config
+from pais_mvs_amd.mvs import patches_sha1
+from tests import common
+
+
+@pytest.mark.parametrize("B,max_rounds,strategy", [(1, 10, 0), (16, 5, 1), (4096, 3, 0)])
+def test_parallel_mode_is_the_sequential_oracle(pawn_small, B, max_rounds, strategy):
+    cfg = readme_config(expansionStrategy=strategy)
+    a = common.oracle_reconstruct(cfg, pawn_small, B, max_rounds, parallel=False)
+    b = common.oracle_reconstruct(cfg, pawn_small, B, max_rounds, parallel=True)
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], (a[1:], b[1:])
+    assert a[2] >= len(pawn_small.seeds) // 2
+    assert patches_sha1(a[0]) == patches_sha1(b[0])
+    assert a[3] == 0 and b[3] >= 0
