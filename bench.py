@@ -147,7 +147,7 @@ def cpu_baseline(cfg, scene, budget_s: float, n_seed_units: int, n_expand_units:
     L.po_mvs_destroy(mo)
     total_s = n_seed_units * t_seed + n_expand_units * t_exp
     return {"value": (n_seed_units + n_expand_units) / total_s if total_s > 0 else 0.0, "unit": "patches/s", "cores": nthr,
-            "kind": "port",
+            "kind": "port, extrapolated from sample",
             "sample": "%d seeds (%.3f s each) + %d first-ring expansion candidates (%.4f s each) of the same scene, "
                       "oracle/pais_oracle.c with OpenMP over particles (the reference's structure), %.1f s of CPU work; "
                       "value = workload units / (seeds x t_seed + expansion candidates x t_expand) for the workload's "
@@ -156,6 +156,50 @@ def cpu_baseline(cfg, scene, budget_s: float, n_seed_units: int, n_expand_units:
             "patch_parallel": {"value": pp_value, "unit": "expansion candidates/s", "cores": ncores,
                                "sample": "%d first-ring candidates, one candidate per OpenMP thread (NOT the reference's "
                                          "structure; the stronger CPU arrangement)" % m_par}}
+
+
+def predicted_speedup(log, particle_num, worlds=(2, 4, 8)):
+    """Strong-scaling model from the per-batch log of the last reconstruction (include/pais_mvs.h pais_round_log), printed
+    so that the first measured SCALE run can be compared with a prediction made from one GPU:
+      T(N) = sum over batches of  host enumerate + host commit                      (replicated on every rank)
+                                + t(ceil(n / N)) + exchange(n, N)   if the batch is sharded (>= 1024 evaluation waves per iteration)
+                                  t(n)                               otherwise (thin batch: every rank refines all of it)
+    t(n) = the measured refine time of this run's batches, interpolated over n (expansion batches; the seed batch scales
+    as half latency floor + half throughput); exchange = 30 us + gathered wire slots over 50 GB/s (device-to-host of what
+    the all-gather delivered) + 0.2 us of host unpacking per record."""
+    import bisect
+    ex = sorted((l.n, l.refine_ms) for l in log if not l.has_seeds and l.n > 0)
+    if not ex:
+        return None
+    xs, ys = [e[0] for e in ex], [e[1] for e in ex]
+
+    def t_exp(n):
+        if n <= xs[0]:
+            return ys[0]
+        if n >= xs[-1]:
+            return ys[-1] * n / xs[-1]
+        i = bisect.bisect_left(xs, n)
+        x0, x1, y0, y1 = xs[i - 1], xs[i], ys[i - 1], ys[i]
+        return y0 if x1 == x0 else y0 + (y1 - y0) * (n - x0) / (x1 - x0)
+
+    def total(N):
+        T = 0.0
+        for l in log:
+            T += l.enumerate_ms + l.commit_ms
+            waves = l.n * particle_num * (2 if l.has_seeds else 1)
+            if N == 1 or waves < 1024:
+                T += l.refine_ms
+                continue
+            per = -(-l.n // N)
+            slot = 208 + 20 * ((l.max_num_cam + 1) // 2 * 2)
+            xchg = 0.030 + (64 + per * slot) * N / 50e6 + 0.0002 * l.n
+            T += (0.5 * l.refine_ms + 0.5 * l.refine_ms * per / l.n if l.has_seeds else min(t_exp(per), l.refine_ms)) + xchg
+        return T
+    t1 = total(1)
+    return {"model_ms_at_1": t1, **{str(N): t1 / total(N) for N in worlds},
+            "shardable_ms": sum(l.refine_ms for l in log if l.n * particle_num * (2 if l.has_seeds else 1) >= 1024),
+            "replicated_ms": sum(l.refine_ms for l in log if l.n * particle_num * (2 if l.has_seeds else 1) < 1024),
+            "host_ms": sum(l.enumerate_ms + l.commit_ms for l in log)}
 
 
 def spawn_ranks(args):
@@ -263,6 +307,7 @@ def main():
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
 
     if rank == 0:
+        scaling_model = predicted_speedup(m.round_log(), cfg.particleNum)
         gold_sha, gold_ok = None, None
         try:
             g = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_cloud_%s.json" % args.scene)))
@@ -275,12 +320,27 @@ def main():
         k_ms = ks.eval_ms                      # sum of the launch durations of the dominant kernel
         k_launches = max(int(ks.eval_launches), 1)
         pso_gbs = (ks.pso_algorithmic_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
-        traffic = None
-        tnote = "no PMC summary found under profiles/"
-        try:   # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same command
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            traffic = pj["eval_hbm_read_bytes_per_launch"]
-            tnote = pj.get("note", "")
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE pass of THIS scene at
+        # THIS workload (profiles/pmc_traffic_by_scene.json, written by scripts/make_profiles.sh); a figure taken on another
+        # scene or workload is never printed
+        traffic, traffic_all = None, None
+        tnote = "no PMC pass of this scene / workload under profiles/"
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_by_scene.json"))).get(args.scene)
+            if pj and (pj["seeds"], pj["parents_per_round"], pj["max_rounds"]) == (len(scene.seeds), B, args.max_rounds):
+                traffic = pj.get("eval2_hbm_read_bytes_per_launch")
+                traffic_all = pj.get("eval_hbm_read_bytes_per_launch")
+                tnote = pj.get("note", "")
+        except Exception:
+            pass
+        # the dominant kernel ALONE: k_pso_eval2 (the throughput-bound launches of the large batches); the k_pso_iter launches
+        # of small batches are latency bound and reported next to it, never mixed into `achieved`
+        e2_ms, e2_n = ks.eval2_ms, max(int(ks.eval2_launches), 1)
+        e2_gbs = (ks.eval2_algorithmic_bytes / 1e9) / (e2_ms / 1e3) if e2_ms > 0 else 0.0
+        evals_per_s = evals_eff / dt if dt > 0 else 0.0
+        mb = None
+        try:   # saturated rate of the same evaluation code (scripts/microbench_eval.py under profiles/)
+            mb = json.load(open(os.path.join(ROOT, "profiles", "microbench_eval.json")))["evals_per_s"]
         except Exception:
             pass
         out = {
@@ -306,22 +366,29 @@ def main():
                        "batches_sharded_per_step": int(last.batches_sharded) if last else 0,
                        "batches_replicated_per_step": int(last.batches_replicated) if last else 0,
                        "exchange_ms_per_step": float(last.exchange_ms) if last else 0.0,
+                       "exchange_bytes_per_step": int(last.exchange_bytes) if last else 0,
+                       "predicted_speedup_at": scaling_model,
                        "parallelism": "1 process per GPU, candidates of a round sharded over %d GPU(s), one ncclAllGather of the "
                                       "records per sharded round (thin rounds replicated)" % world},
-            "roofline": {"bound": "hbm", "kernel": "cost evaluation (k_pso_eval in large batches, k_pso_iter in small ones)", "achieved": pso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": pso_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": k_launches, "avg_launch_ms": k_ms / k_launches,
-                         "algorithmic_bytes_per_launch": ks.pso_algorithmic_bytes / k_launches,
-                         "evals": int(ks.pso_evals),
-                         "algorithmic_bytes_per_eval": (ks.pso_algorithmic_bytes / ks.pso_evals) if ks.pso_evals else 0,
-                         # the two sub-streams' launches overlap, so the sum of their durations counts shared time twice:
-                         # the same bytes over the wall time of the PSO passes they belong to (k_pso_init and the step
-                         # launches included) -- informative only, `achieved` / `frac` stay the per-launch figures
-                         "achieved_over_pso_pass_wall": (ks.pso_algorithmic_bytes / 1e9) / (ks.pso_ms / 1e3) if ks.pso_ms > 0 else 0.0,
+            "roofline": {"bound": "hbm", "kernel": "k_pso_eval2 (PAIS::getFitness, one wave per candidate x particle; the launches of the large batches)",
+                         "achieved": e2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e2_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches": e2_n, "avg_launch_ms": e2_ms / e2_n,
+                         "algorithmic_bytes_per_launch": ks.eval2_algorithmic_bytes / e2_n,
+                         "evals": int(ks.eval2_evals),
+                         "algorithmic_bytes_per_eval": (ks.eval2_algorithmic_bytes / ks.eval2_evals) if ks.eval2_evals else 0,
+                         # every cost-evaluation launch of the step (k_pso_eval2 + the latency-bound k_pso_iter launches of
+                         # seeds and thin rounds): the figure rounds 1 and 2 printed as `frac`
+                         "all_evaluation_launches": {"achieved": pso_gbs, "frac": pso_gbs / HBM_PEAK_GBS, "launches": k_launches,
+                                                     "avg_launch_ms": k_ms / k_launches, "evals": int(ks.pso_evals), "traffic": traffic_all,
+                                                     "achieved_over_pso_pass_wall": (ks.pso_algorithmic_bytes / 1e9) / (ks.pso_ms / 1e3) if ks.pso_ms > 0 else 0.0},
+                         # whole reconstruction against the saturated kernel: cost evaluations the sequential order consumed
+                         # per second of the timed region / the microbenchmark's rate (profiles/microbench_eval.json)
+                         "evals_per_s": evals_per_s, "microbench_evals_per_s": mb,
+                         "evals_per_s_over_microbench": (evals_per_s / mb) if mb else None,
                          "note": "rank-0, one extra instrumented step; bytes = S^2*(4K+1+8[dist]+8[grad]) per cost evaluation "
-                                 "(SURVEY 8d) x evaluations of the launch; durations from HIP events on the launching sub-stream "
-                                 "(launches of the two sub-streams overlap).  The kernel is FP64-VALU bound, not HBM bound "
-                                 "(DESIGN.md 4): the window taps hit L1/L2.  traffic: " + tnote},
+                                 "(SURVEY 8d) x evaluations; durations from HIP events on the launching sub-stream (the two "
+                                 "sub-streams' launches overlap, which stretches each).  The kernel is FP64-VALU bound, not HBM "
+                                 "bound (DESIGN.md 4): the window taps hit L1/L2.  traffic: " + tnote},
             "kernel_ms_per_step": {"pso_pass": ks.pso_ms, "cost_evaluation_sum_of_launches": ks.eval_ms, "k_begin": ks.begin_ms,
                                    "k_after": ks.after_ms,
                                    "host_enumerate": last.host_enumerate_ms if last else 0,

@@ -201,6 +201,21 @@ int  pais_refine_batch_view(pais_ctx *ctx, int n, const pais_candidate *cands, c
  * pure expansion batches are enqueued asynchronously). */
 int  pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candidate *d_cands,
                               pais_patch_result *d_out, int max_num_cam, int has_seeds);
+/* ---- wire format of a record (the per-round exchange of the multi-GPU drivers, include/pais_mvs.h) ----
+ * A pais_patch_result is 1488 bytes, 1280 of them the two PAIS_MAX_VIS-long arrays.  What a driver's commit reads of a
+ * record of a batch whose candidates see at most `max_num_cam` cameras fits in
+ *     pais_record_wire_bytes(max_num_cam) = 208 + 20 * roundup2(max_num_cam)       (308 bytes at 5 cameras)
+ * [17 doubles center .. correlation][key][type .. pso_evals][stage .. ncc_tables][imgPoint[Kw][2]][cam_idx[Kw]],
+ * every slot of a batch the same size (an all-gather needs that).  Unpacking zero-fills the array tails beyond Kw -- the
+ * batch calls never write an array element at or beyond the candidate's own camera count, so for records of such a
+ * batch pack -> unpack reproduces every byte.
+ * pack / unpack are plain host loops; _device is the same packing by a kernel on the context's stream (d_* device
+ * pointers). */
+size_t pais_record_wire_bytes(int max_num_cam);
+int  pais_pack_records(int n, const pais_patch_result *recs, int max_num_cam, void *wire);
+int  pais_unpack_records(int n, const void *wire, int max_num_cam, pais_patch_result *recs);
+int  pais_pack_records_device(pais_ctx *ctx, int n, const pais_patch_result *d_recs, int max_num_cam, void *d_wire);
+
 /* The HIP stream (hipStream_t) all work of this context is enqueued on. */
 void *pais_ctx_stream(pais_ctx *ctx);
 int  pais_ctx_synchronize(pais_ctx *ctx);

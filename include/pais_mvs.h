@@ -48,7 +48,22 @@ typedef struct pais_mvs_stats {
     int64_t batches_sharded;      /* batches whose candidates were split across the ranks (one all-gather each) */
     int64_t batches_replicated;   /* multi-rank batches too small to split: every rank refined all of them      */
     double  exchange_ms;          /* host time spent in the all-gathers (incl. waiting for the slowest rank)    */
+    int64_t exchange_bytes;       /* bytes a rank received in them: world x (64-byte header + shard x wire slot) per batch */
 } pais_mvs_stats;
+
+/* One entry per GPU batch of the last reconstruction (the seed batch first, then one per expansion round with
+ * candidates): what a scaling model needs -- how many candidates, whether the batch was sharded, and the host / GPU
+ * times around it (milliseconds).  bench.py prints a predicted speed-up at 2 / 4 / 8 GPUs from it. */
+typedef struct pais_round_log {
+    int32_t n;                    /* candidates of the batch                                     */
+    int32_t has_seeds;
+    int32_t sharded;              /* 1: split across the ranks, 0: one rank / replicated         */
+    int32_t max_num_cam;
+    double  refine_ms;            /* pais_refine_batch (or shard + exchange) as the host saw it  */
+    double  enumerate_ms, commit_ms; /* host work before / after it (0 for the seed batch's enumerate) */
+} pais_round_log;
+/* copies up to `cap` entries into out (may be NULL); returns the number of entries recorded */
+int  pais_mvs_get_round_log(const pais_mvs *m, pais_round_log *out, int cap);
 
 /* Creates the driver and its own pais_ctx on `device` (MVS::getInstance(config),
  * mvs.cpp:22-34 + loading the cameras).  device < 0 creates the scheduler without

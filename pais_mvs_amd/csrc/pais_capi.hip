@@ -3,6 +3,7 @@
 // either runs the gfx950 kernels or returns an error.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -81,7 +82,7 @@ struct pais_ctx {
     long splitAbove = 0;
     int psoMinPer = 64;
     int evalParts = 0;                  // waves per cost evaluation in k_pso_iter (1, 2, 4); 0 = chosen per slice
-    double partFill = 1.0;              // ... such that parts * waves <= partFill * resident wave slots
+    double partFill = 0.75;             // ... such that parts * waves <= partFill * numCUs * 16 (= the 3 waves per SIMD the kernels' registers allow)
     int psoStreams = 2;
     std::vector<hipStream_t> sub;       // sub-streams
     std::vector<hipEvent_t> subDone;
@@ -704,6 +705,60 @@ extern "C" int pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *can
     int rc = pais_refine_batch_view(ctx, n, cands, &view);
     if (rc || n <= 0) return rc;
     memcpy(out, view, sizeof(pais_patch_result) * (size_t)n);
+    return 0;
+}
+
+// ------------------------------------------------------------- record wire --
+// include/pais_hip.h "wire format of a record".  Word offsets of the record are asserted against the struct.
+static_assert(offsetof(pais_patch_result, imgPoint) == 136 && offsetof(pais_patch_result, key) == 1160 &&
+              offsetof(pais_patch_result, type) == 1168 && offsetof(pais_patch_result, cam_idx) == 1200 &&
+              offsetof(pais_patch_result, stage) == 1456 && sizeof(pais_patch_result) == 1488, "pais_patch_result layout");
+static inline int wire_kw(int max_num_cam)
+{
+    int k = max_num_cam < 1 ? 1 : (max_num_cam > PAIS_MAX_VIS ? PAIS_MAX_VIS : max_num_cam);
+    return (k + 1) & ~1;
+}
+extern "C" size_t pais_record_wire_bytes(int max_num_cam) { return 208 + 20 * (size_t)wire_kw(max_num_cam); }
+extern "C" int pais_pack_records(int n, const pais_patch_result *recs, int max_num_cam, void *wire)
+{
+    if (n < 0 || (n && (!recs || !wire))) return fail_msg("pais_pack_records: bad argument");
+    const int Kw = wire_kw(max_num_cam);
+    const size_t WB = pais_record_wire_bytes(max_num_cam);
+    for (int i = 0; i < n; ++i) {
+        const unsigned char *r = (const unsigned char *)&recs[i];
+        unsigned char *w = (unsigned char *)wire + WB * (size_t)i;
+        memcpy(w, r, 136);                  // center .. correlation
+        memcpy(w + 136, r + 1160, 8);       // key
+        memcpy(w + 144, r + 1168, 32);      // type .. pso_evals
+        memcpy(w + 176, r + 1456, 32);      // stage .. ncc_tables
+        memcpy(w + 208, r + 136, 16 * (size_t)Kw);
+        memcpy(w + 208 + 16 * (size_t)Kw, r + 1200, 4 * (size_t)Kw);
+    }
+    return 0;
+}
+extern "C" int pais_unpack_records(int n, const void *wire, int max_num_cam, pais_patch_result *recs)
+{
+    if (n < 0 || (n && (!recs || !wire))) return fail_msg("pais_unpack_records: bad argument");
+    const int Kw = wire_kw(max_num_cam);
+    const size_t WB = pais_record_wire_bytes(max_num_cam);
+    for (int i = 0; i < n; ++i) {
+        unsigned char *r = (unsigned char *)&recs[i];
+        const unsigned char *w = (const unsigned char *)wire + WB * (size_t)i;
+        memset(r, 0, sizeof(pais_patch_result));
+        memcpy(r, w, 136);
+        memcpy(r + 1160, w + 136, 8);
+        memcpy(r + 1168, w + 144, 32);
+        memcpy(r + 1456, w + 176, 32);
+        memcpy(r + 136, w + 208, 16 * (size_t)Kw);
+        memcpy(r + 1200, w + 208 + 16 * (size_t)Kw, 4 * (size_t)Kw);
+    }
+    return 0;
+}
+extern "C" int pais_pack_records_device(pais_ctx *ctx, int n, const pais_patch_result *d_recs, int max_num_cam, void *d_wire)
+{
+    if (!ctx || n < 0 || (n && (!d_recs || !d_wire))) return fail_msg("pais_pack_records_device: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(pais_launch::pack_records(d_recs, n, wire_kw(max_num_cam), d_wire, ctx->stream));
     return 0;
 }
 

@@ -390,6 +390,27 @@ __device__ __forceinline__ bool corners_inside(const EvalPatch *ep, const EvalCa
     return __all(ok);
 }
 
+// spherical2normal (utility.h:25-29) by one wave: sin(theta), cos(theta), sin(phi), cos(phi) are four evaluations of the same
+// fdlibm routine -- shared argument reduction, then k_sin or k_cos by quadrant -- so lanes 0..3 (every lane by its low two
+// bits) evaluate one of them each in ONE pass and the four values are broadcast with v_readlane: a quarter of the
+// instructions of four wave-uniform calls (a tenth of a cost evaluation at five cameras), the bits of det_sin / det_cos
+// (the same functions on the same arguments; cos(x) is sin's quadrant table shifted by one).
+__device__ __forceinline__ void wave_spherical2normal(double theta, double phi, double *n, int lane)
+{
+    const double arg = (lane & 2) ? phi : theta;
+    const int wantCos = lane & 1;
+    double y0, y1;
+    const int q = (det_rem_pio2(arg, &y0, &y1) + wantCos) & 3;
+    const double ks = det_ksin(y0, y1, 1), kc = det_kcos(y0, y1);
+    double r = (q & 1) ? kc : ks;
+    r = (q & 2) ? -r : r;
+    if (arg != arg || arg - arg != 0.0) r = arg - arg; // NaN / inf, as det_sin / det_cos
+    const double st = lane_get(r, 0), ct = lane_get(r, 1), sp = lane_get(r, 2), cp = lane_get(r, 3);
+    n[0] = st * cp;
+    n[1] = st * sp;
+    n[2] = ct;
+}
+
 template <int NS, bool BYTES, bool ACCR>
 __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                                   const WinPix *win, double theta, double phi, double depth, int lane, int part, int nparts,
@@ -398,7 +419,7 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     f4[0] = f4[1] = f4[2] = f4[3] = 0;
     w4[0] = w4[1] = w4[2] = w4[3] = 0;
     double n[3];
-    spherical2normal(theta, phi, n);
+    wave_spherical2normal(theta, phi, n, lane);
     {
         double on[3] = {ep->optNref[0], ep->optNref[1], ep->optNref[2]};
         if (dot3(n, on) > 0) return 1; // patch.cpp:939

@@ -1395,6 +1395,28 @@ __global__ __launch_bounds__(64 * AFTER_WAVES) void k_after(DevScene sc, pais_pa
     }
 }
 
+// ------------------------------------------------------------ record wire ---
+// include/pais_hip.h "wire format of a record": one thread per 4-byte word of a slot; the layout below is the one
+// pais_pack_records / pais_unpack_records (pais_capi.hip) state on the host
+__global__ __launch_bounds__(256) void k_pack_records(const pais_patch_result *recs, int n, int Kw, uint32_t *wire)
+{
+    const int wordsPerSlot = 52 + 5 * Kw; // 208 / 4 + Kw * (16 + 4) / 4
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < (size_t)n * wordsPerSlot; t += (size_t)gridDim.x * 256) {
+        const int r = (int)(t / wordsPerSlot), w = (int)(t - (size_t)r * wordsPerSlot);
+        const uint32_t *src = (const uint32_t *)&recs[r];
+        // record words: [0,34) the 17 doubles; [34,290) imgPoint; [290,292) key; [292,300) type..pso_evals; [300,364) cam_idx;
+        // [364,372) stage..ncc_tables
+        int sw;
+        if (w < 34) sw = w;
+        else if (w < 36) sw = 290 + (w - 34);
+        else if (w < 44) sw = 292 + (w - 36);
+        else if (w < 52) sw = 364 + (w - 44);
+        else if (w < 52 + 4 * Kw) sw = 34 + (w - 52);
+        else sw = 300 + (w - 52 - 4 * Kw);
+        wire[t] = src[sw];
+    }
+}
+
 // ------------------------------------------------------- scene preparation ---
 // float2 tap copy of the byte blob (pais_internal.h PaisImgT): one thread per pixel, coalesced
 __global__ __launch_bounds__(256) void k_expand_image(const uint8_t *img, PaisImgT *out, size_t n)
@@ -1594,6 +1616,15 @@ hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_neighbor_count, dim3((n + 255) / 256), dim3(256), 0, stream, centers, n, radius, counts);
+    return hipGetLastError();
+}
+
+hipError_t pack_records(const pais_patch_result *recs, int n, int Kw, void *wire, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t words = (size_t)n * (52 + 5 * Kw);
+    const size_t blocks = (words + 255) / 256;
+    hipLaunchKernelGGL(k_pack_records, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, recs, n, Kw, (uint32_t *)wire);
     return hipGetLastError();
 }
 

@@ -199,9 +199,13 @@ struct pais_mvs {
     pais_record_source_fn recordSource = nullptr;
     void *recordUser = nullptr;
     pais_candidate *d_shardC = nullptr, *h_shardC = nullptr;       // this rank's shard of a batch (device / pinned)
-    pais_patch_result *d_shardR = nullptr, *d_allR = nullptr, *h_allR = nullptr;
-    size_t shardCap = 0, allCap = 0;
+    pais_patch_result *d_shardR = nullptr;
+    size_t shardCap = 0;
+    void *d_wireS = nullptr, *d_wireAll = nullptr;                 // wire slots: this rank's (header + shard), all ranks'
+    unsigned char *h_wireAll = nullptr, *h_hdr = nullptr;          // pinned
+    size_t wireCap = 0;
     std::vector<pais_patch_result> sendBuf;
+    std::vector<unsigned char> wireSend, wireAll;
     std::vector<HostCamera> cams;
     std::vector<HostPatch *> patches; // index == id; nullptr once deleted  (map<int,Patch>, mvs.h:86)
     int alive = 0;
@@ -230,6 +234,8 @@ struct pais_mvs {
     bool strictTail = true;
     long truncatedVisible = 0;         // cameras dropped because a visibility cone held more than PAIS_MAX_VIS of them
     pais_mvs_stats st;
+    std::vector<pais_round_log> roundLog;
+    double lastEnumerateMs = 0;
     std::string err;
 
     ~pais_mvs()
@@ -241,8 +247,8 @@ struct pais_mvs {
                 std::string e;
                 if (rccl::Api *a = rccl::api(e)) a->commDestroy(nccl);
             }
-            (void)hipFree(d_shardC); (void)hipFree(d_shardR); (void)hipFree(d_allR);
-            (void)hipHostFree(h_shardC); (void)hipHostFree(h_allR);
+            (void)hipFree(d_shardC); (void)hipFree(d_shardR); (void)hipFree(d_wireS); (void)hipFree(d_wireAll);
+            (void)hipHostFree(h_shardC); (void)hipHostFree(h_wireAll); (void)hipHostFree(h_hdr);
         }
         if (ctx) pais_ctx_destroy(ctx);
     }
@@ -689,6 +695,7 @@ extern "C" int pais_mvs_reset(pais_mvs *m)
     m->candRecs.clear();
     m->seedIds.clear();
     memset(&m->st, 0, sizeof(m->st));
+    m->roundLog.clear();
     return 0;
 }
 extern "C" pais_ctx *pais_mvs_ctx(pais_mvs *m) { return m ? m->ctx : nullptr; }
@@ -822,6 +829,7 @@ static int refine_local(pais_mvs *m, int n, const pais_candidate *c, pais_patch_
     return mfail("this driver has neither a GPU context nor a record source");
 }
 
+static constexpr size_t kWireHeader = 64; // per-rank header of a sharded batch's exchange (status of the rank's refinement)
 static int all_gather_host(pais_mvs *m, const void *send, void *recv, size_t bytes)
 {
     if (!m->gatherCb) return mfail("no host all-gather installed");
@@ -848,63 +856,99 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
     m->st.batches_sharded++;
     const int per = (n + world - 1) / world;
     const int lo = std::min(m->rank * per, n), hi = std::min(lo + per, n), cnt = hi - lo;
-    const size_t SZ_R = sizeof(pais_patch_result);
+    // What travels: wire slots (include/pais_hip.h "wire format of a record") sized for the batch's largest camera count --
+    // the same on every rank, the candidate list is replicated -- behind a 64-byte header per rank that carries the rank's
+    // status: a rank whose refinement failed still takes part in the collective and every rank returns the error together
+    // (no rank is left waiting in an all-gather the failed one never entered).
+    int Kb = 1;
+    for (int i = 0; i < n; ++i) Kb = std::max(Kb, c[i].num_cam);
+    const size_t WB = pais_record_wire_bytes(Kb), slot = kWireHeader + WB * (size_t)per;
+    struct WireHeader { uint32_t magic; int32_t rc; int32_t count; int32_t rank; };
+    const uint32_t kMagic = 0x50414953u; // "PAIS"
+    m->wireAll.resize(slot * (size_t)world);
+    m->results.resize((size_t)n);
+    int localRc = 0;
     if (!m->ctx || !m->nccl) {
         // records through host memory: GPU-less driver, or a caller-supplied transport
         m->sendBuf.assign((size_t)per, pais_patch_result());
-        if (cnt > 0) {
-            int rc = refine_local(m, cnt, c + lo, m->sendBuf.data(), has_seeds);
-            if (rc) return rc;
-        }
-        std::vector<pais_patch_result> all((size_t)per * world);
+        if (cnt > 0) localRc = refine_local(m, cnt, c + lo, m->sendBuf.data(), has_seeds);
+        m->wireSend.assign(slot, 0);
+        WireHeader hd = {kMagic, localRc, cnt, m->rank};
+        memcpy(m->wireSend.data(), &hd, sizeof(hd));
+        if (!localRc && pais_pack_records(cnt, m->sendBuf.data(), Kb, m->wireSend.data() + kWireHeader)) localRc = -1;
         const double t0 = now_ms();
-        int rc = all_gather_host(m, m->sendBuf.data(), all.data(), SZ_R * (size_t)per);
+        int rc = all_gather_host(m, m->wireSend.data(), m->wireAll.data(), slot);
         m->st.exchange_ms += now_ms() - t0;
+        m->st.exchange_bytes += (int64_t)(slot * (size_t)world);
         if (rc) return rc;
-        memcpy(out, all.data(), SZ_R * (size_t)n); // shards are contiguous and in rank order
-        return 0;
-    }
-    // RCCL: candidates up, records stay in HBM, one ncclAllGather on the context's stream, gathered records down
-    MHIP(hipSetDevice(m->device));
-    hipStream_t st = (hipStream_t)pais_ctx_stream(m->ctx);
-    if ((size_t)per > m->shardCap) {
+    } else {
+        // RCCL: candidates up, records stay in HBM, packed by a kernel, ONE ncclAllGather on the context's stream, slots down
+        MHIP(hipSetDevice(m->device));
+        hipStream_t st = (hipStream_t)pais_ctx_stream(m->ctx);
+        if ((size_t)per > m->shardCap) {
+            MHIP(hipStreamSynchronize(st));
+            (void)hipFree(m->d_shardC); (void)hipFree(m->d_shardR); (void)hipHostFree(m->h_shardC);
+            m->d_shardC = nullptr; m->d_shardR = nullptr; m->h_shardC = nullptr;
+            const size_t cap = (size_t)per + (size_t)per / 2 + 64;
+            MHIP(hipMalloc((void **)&m->d_shardC, sizeof(pais_candidate) * cap));
+            MHIP(hipMalloc((void **)&m->d_shardR, sizeof(pais_patch_result) * cap));
+            MHIP(hipHostMalloc((void **)&m->h_shardC, sizeof(pais_candidate) * cap, hipHostMallocDefault));
+            m->shardCap = cap;
+        }
+        if (slot * (size_t)world > m->wireCap) {
+            MHIP(hipStreamSynchronize(st));
+            (void)hipFree(m->d_wireS); (void)hipFree(m->d_wireAll); (void)hipHostFree(m->h_wireAll); (void)hipHostFree(m->h_hdr);
+            m->d_wireS = nullptr; m->d_wireAll = nullptr; m->h_wireAll = nullptr; m->h_hdr = nullptr;
+            const size_t cap = slot * (size_t)world * 3 / 2 + 4096;
+            MHIP(hipMalloc((void **)&m->d_wireS, cap / world + 4096));
+            MHIP(hipMalloc((void **)&m->d_wireAll, cap));
+            MHIP(hipHostMalloc((void **)&m->h_wireAll, cap, hipHostMallocDefault));
+            MHIP(hipHostMalloc((void **)&m->h_hdr, kWireHeader, hipHostMallocDefault));
+            m->wireCap = cap;
+        }
+        if (cnt > 0) {
+            int Kmax = 1;
+            for (int i = lo; i < hi; ++i) Kmax = std::max(Kmax, c[i].num_cam);
+            memcpy(m->h_shardC, c + lo, sizeof(pais_candidate) * (size_t)cnt);
+            MHIP(hipMemcpyAsync(m->d_shardC, m->h_shardC, sizeof(pais_candidate) * (size_t)cnt, hipMemcpyHostToDevice, st));
+            localRc = pais_refine_batch_device(m->ctx, cnt, m->d_shardC, m->d_shardR, Kmax, has_seeds);
+            if (localRc) g_mvs_err = pais_last_error();
+            else if (pais_pack_records_device(m->ctx, cnt, m->d_shardR, Kb, (unsigned char *)m->d_wireS + kWireHeader)) { localRc = -2; g_mvs_err = pais_last_error(); }
+        }
+        MHIP(hipStreamSynchronize(st)); // (h_hdr of the previous batch has been consumed; the seed loop is synchronous anyway)
+        WireHeader hd = {kMagic, localRc, cnt, m->rank};
+        memset(m->h_hdr, 0, kWireHeader);
+        memcpy(m->h_hdr, &hd, sizeof(hd));
+        MHIP(hipMemcpyAsync(m->d_wireS, m->h_hdr, kWireHeader, hipMemcpyHostToDevice, st));
+        std::string err;
+        rccl::Api *a = rccl::api(err);
+        if (!a) return mfail(err.c_str());
+        const double t0 = now_ms();
+        int nr = a->allGather(m->d_wireS, m->d_wireAll, slot, rccl::kInt8, m->nccl, st);
+        if (nr != 0) { g_mvs_err = std::string("ncclAllGather: ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
+        MHIP(hipMemcpyAsync(m->h_wireAll, m->d_wireAll, slot * (size_t)world, hipMemcpyDeviceToHost, st));
         MHIP(hipStreamSynchronize(st));
-        (void)hipFree(m->d_shardC); (void)hipFree(m->d_shardR); (void)hipHostFree(m->h_shardC);
-        m->d_shardC = nullptr; m->d_shardR = nullptr; m->h_shardC = nullptr;
-        const size_t cap = (size_t)per + (size_t)per / 2 + 64;
-        MHIP(hipMalloc((void **)&m->d_shardC, sizeof(pais_candidate) * cap));
-        MHIP(hipMalloc((void **)&m->d_shardR, SZ_R * cap));
-        MHIP(hipHostMalloc((void **)&m->h_shardC, sizeof(pais_candidate) * cap, hipHostMallocDefault));
-        m->shardCap = cap;
+        m->st.exchange_ms += now_ms() - t0;
+        m->st.exchange_bytes += (int64_t)(slot * (size_t)world);
+        memcpy(m->wireAll.data(), m->h_wireAll, slot * (size_t)world);
     }
-    if ((size_t)per * world > m->allCap) {
-        MHIP(hipStreamSynchronize(st));
-        (void)hipFree(m->d_allR); (void)hipHostFree(m->h_allR);
-        m->d_allR = nullptr; m->h_allR = nullptr;
-        const size_t cap = (size_t)per * world + (size_t)per * world / 2 + 64;
-        MHIP(hipMalloc((void **)&m->d_allR, SZ_R * cap));
-        MHIP(hipHostMalloc((void **)&m->h_allR, SZ_R * cap, hipHostMallocDefault));
-        m->allCap = cap;
+    // every rank reads every rank's status, then the shards in rank order (contiguous, count balanced)
+    for (int r = 0; r < world; ++r) {
+        WireHeader hd;
+        memcpy(&hd, m->wireAll.data() + slot * (size_t)r, sizeof(hd));
+        const int rlo = std::min(r * per, n), rcnt = std::min(rlo + per, n) - rlo;
+        if (hd.magic != kMagic || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
+        if (hd.rc != 0) {
+            if (r != m->rank || g_mvs_err.empty()) g_mvs_err = "sharded batch: rank " + std::to_string(r) + " failed to refine its shard (rc " + std::to_string(hd.rc) + ")";
+            return hd.rc < 0 ? hd.rc : -1;
+        }
     }
-    if (cnt > 0) {
-        int Kmax = 1;
-        for (int i = lo; i < hi; ++i) Kmax = std::max(Kmax, c[i].num_cam);
-        memcpy(m->h_shardC, c + lo, sizeof(pais_candidate) * (size_t)cnt);
-        MHIP(hipMemcpyAsync(m->d_shardC, m->h_shardC, sizeof(pais_candidate) * (size_t)cnt, hipMemcpyHostToDevice, st));
-        int rc = pais_refine_batch_device(m->ctx, cnt, m->d_shardC, m->d_shardR, Kmax, has_seeds);
-        if (rc) { g_mvs_err = pais_last_error(); return rc; }
+    for (int r = 0; r < world; ++r) {
+        const int rlo = std::min(r * per, n), rcnt = std::min(rlo + per, n) - rlo;
+        if (rcnt > 0 && pais_unpack_records(rcnt, m->wireAll.data() + slot * (size_t)r + kWireHeader, Kb, m->results.data() + rlo))
+            return mfail(pais_last_error());
     }
-    std::string err;
-    rccl::Api *a = rccl::api(err);
-    if (!a) return mfail(err.c_str());
-    const double t0 = now_ms();
-    // the tail of the last rank's shard is padding: never read back
-    int nr = a->allGather(m->d_shardR, m->d_allR, SZ_R * (size_t)per, rccl::kInt8, m->nccl, st);
-    if (nr != 0) { g_mvs_err = std::string("ncclAllGather: ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
-    MHIP(hipMemcpyAsync(m->h_allR, m->d_allR, SZ_R * (size_t)n, hipMemcpyDeviceToHost, st));
-    MHIP(hipStreamSynchronize(st));
-    m->st.exchange_ms += now_ms() - t0;
-    *view = m->h_allR;
+    *view = m->results.data();
     return 0;
 }
 
@@ -1040,10 +1084,17 @@ extern "C" int pais_mvs_refine_seed_patches(pais_mvs *m)
     m->results.resize((size_t)n);
     double t0 = now_ms();
     const pais_patch_result *recs = nullptr;
+    const int64_t shardedBefore = m->st.batches_sharded;
     rc = refine_any(m, n, c, m->results.data(), 1, &recs);
-    m->st.gpu_refine_ms += now_ms() - t0;
+    const double tRef = now_ms() - t0;
+    m->st.gpu_refine_ms += tRef;
     if (rc) return rc;
-    return pais_mvs_seed_commit(m, recs, n);
+    int kmax = 1;
+    for (int i = 0; i < n; ++i) kmax = std::max(kmax, c[i].num_cam);
+    const double t1 = now_ms();
+    rc = pais_mvs_seed_commit(m, recs, n);
+    m->roundLog.push_back(pais_round_log{n, 1, m->st.batches_sharded > shardedBefore ? 1 : 0, kmax, tRef, 0.0, now_ms() - t1});
+    return rc;
 }
 
 extern "C" int pais_mvs_expansion_begin(pais_mvs *m)
@@ -1188,7 +1239,8 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
     }
     *cands = m->candRecs.data();
     *n = (int)m->candRecs.size();
-    m->st.host_enumerate_ms += now_ms() - t0;
+    m->lastEnumerateMs = now_ms() - t0;
+    m->st.host_enumerate_ms += m->lastEnumerateMs;
     return 0;
 }
 
@@ -1443,14 +1495,22 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         if (rc < 0) return rc;
         if (rc == 1) break;
         m->results.resize((size_t)(n > 0 ? n : 1));
+        const double enumMs = m->lastEnumerateMs;
+        double tRef = 0;
+        const int64_t shardedBefore = m->st.batches_sharded;
+        int kmax = 1;
         if (n > 0) {
+            for (int i = 0; i < n; ++i) kmax = std::max(kmax, c[i].num_cam);
             double t0 = now_ms();
             rc = refine_any(m, n, c, m->results.data(), 0, &recs);
-            m->st.gpu_refine_ms += now_ms() - t0;
+            tRef = now_ms() - t0;
+            m->st.gpu_refine_ms += tRef;
             if (rc) return rc;
         }
+        const double t1 = now_ms();
         rc = pais_mvs_round_commit(m, n > 0 ? recs : m->results.data(), n);
         if (rc) return rc;
+        if (n > 0) m->roundLog.push_back(pais_round_log{n, 0, m->st.batches_sharded > shardedBefore ? 1 : 0, kmax, tRef, enumMs, now_ms() - t1});
         if (max_rounds > 0 && ++rounds >= max_rounds) break;
     }
     return pais_mvs_expansion_end(m);
@@ -1632,6 +1692,13 @@ extern "C" int pais_mvs_get_stats(const pais_mvs *m, pais_mvs_stats *out)
     if (!m || !out) return -1;
     *out = m->st;
     return 0;
+}
+extern "C" int pais_mvs_get_round_log(const pais_mvs *m, pais_round_log *out, int cap)
+{
+    if (!m) return 0;
+    const int n = (int)m->roundLog.size();
+    for (int i = 0; out && i < n && i < cap; ++i) out[i] = m->roundLog[i];
+    return n;
 }
 extern "C" const char *pais_mvs_last_error(void) { return g_mvs_err.c_str(); }
 

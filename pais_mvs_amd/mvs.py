@@ -18,7 +18,13 @@ class MvsStats(C.Structure):
                 ("patches_inserted", C.c_int64), ("patches_deleted", C.c_int64), ("rounds", C.c_int64),
                 ("parents_popped", C.c_int64), ("pso_evals_effective", C.c_int64),
                 ("host_enumerate_ms", C.c_double), ("host_commit_ms", C.c_double), ("gpu_refine_ms", C.c_double),
-                ("batches_sharded", C.c_int64), ("batches_replicated", C.c_int64), ("exchange_ms", C.c_double)]
+                ("batches_sharded", C.c_int64), ("batches_replicated", C.c_int64), ("exchange_ms", C.c_double),
+                ("exchange_bytes", C.c_int64)]
+
+
+class RoundLog(C.Structure):
+    _fields_ = [("n", C.c_int32), ("has_seeds", C.c_int32), ("sharded", C.c_int32), ("max_num_cam", C.c_int32),
+                ("refine_ms", C.c_double), ("enumerate_ms", C.c_double), ("commit_ms", C.c_double)]
 
 
 UNIQUE_ID_BYTES = 128
@@ -67,6 +73,7 @@ def _bind(L):
     L.pais_mvs_neighbor_radius.restype = C.c_double
     L.pais_mvs_neighbor_radius.argtypes = [vp]
     L.pais_mvs_get_stats.argtypes = [vp, C.POINTER(MvsStats)]
+    L.pais_mvs_get_round_log.argtypes = [vp, C.POINTER(RoundLog), C.c_int]
     L.pais_mvs_last_error.restype = C.c_char_p
     L.pais_comm_get_unique_id.argtypes = [C.POINTER(UniqueId)]
     L.pais_mvs_comm_init_rccl.argtypes = [vp, C.c_int, C.c_int, C.POINTER(UniqueId)]
@@ -278,6 +285,13 @@ class MVS:
         s = MvsStats()
         self.L.pais_mvs_get_stats(self.h, C.byref(s))
         return s
+
+    def round_log(self):
+        """One RoundLog per GPU batch of the last reconstruction (seed batch first)."""
+        n = self.L.pais_mvs_get_round_log(self.h, None, 0)
+        buf = (RoundLog * max(n, 1))()
+        n = self.L.pais_mvs_get_round_log(self.h, buf, n)
+        return [buf[i] for i in range(n)]
 
     def cloud(self) -> np.ndarray:
         """(N, 6) array of patch centres and normals in id order."""

@@ -4,11 +4,14 @@
 # 1. kernel-trace + stats of the default bench command   -> gpurun_out/<tag>_kernel_stats.txt, <tag>_bench_under_rocprof.json
 # 2. PMC passes (kernel-trace only, one rocprofv3 run per counter set) of `bench.py --steps 1 --warmup 0`
 #                                                          -> gpurun_out/<tag>_pmc.txt, <tag>_pmc_traffic.json
-tag=${1:-r01x}
+tag=${1:-r01x}; shift
+# further arguments go to bench.py (e.g. --scene dome --max-rounds 3 --parents-per-round 1024); SCENE / SEEDS / PPR / MAXR
+# describe that workload in the traffic record (defaults = bench.py's defaults)
+SCENE=${SCENE:-pawn}; SEEDS=${SEEDS:-200}; PPR=${PPR:-4096}; MAXR=${MAXR:-0}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 2 --warmup 1 --cpu-seconds 4 > $out/bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 2 --warmup 1 --cpu-seconds 4 "$@" > $out/bench.log 2>&1
 grep '^{"metric"' $out/bench.log | tail -1 > gpurun_out/${tag}_bench_under_rocprof.json
 python scripts/rocprof_summary.py $(ls $out/kt/*.db | head -1) gpurun_out/${tag}_kernel_stats.txt gpurun_out/${tag}_bench_under_rocprof.json "python bench.py --steps 2 --warmup 1 ($tag)" > /dev/null
 i=0
@@ -21,7 +24,7 @@ for set in \
  "FETCH_SIZE" \
  "WRITE_SIZE" ; do
   i=$((i+1))
-  timeout 900 rocprofv3 --kernel-trace --pmc $set -d $out/p$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/p$i.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $set -d $out/p$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/p$i.log 2>&1
   python - >> gpurun_out/${tag}_pmc.txt << PY
 import sqlite3,glob,json
 f=glob.glob("$out/p$i/*.db")
@@ -36,13 +39,17 @@ if f:
     for n_,c_,t_ in cur.execute("select name,count(*),sum(duration)/1e6 from kernels group by name"):
         print("   dur_ms %-22s calls %6d total %.3f"%(n_.split("(")[0].replace("void ","")[:22],c_,t_))
     if "$set"=="FETCH_SIZE":
-        ev=lambda k: k.startswith("k_pso_iter") or k.startswith("k_pso_eval")
-        tot=sum(v for (k,c),(v,n) in sums.items() if ev(k)); nl=sum(n for (k,c),(v,n) in sums.items() if ev(k))
-        if nl:
-            raw=tot*1024.0/nl
-            json.dump({"eval_hbm_read_bytes_per_launch": 2.0*raw, "raw_fetch_size_bytes_per_launch": raw, "launches": nl,
-                       "note": "rocprofv3 --pmc FETCH_SIZE (KiB) summed over the k_pso_eval / k_pso_iter dispatches of 'bench.py --steps 1 --warmup 0' / launches, x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated for wide coalesced reads only, so an upper bound for these 8-byte gathers)"},
-                      open("gpurun_out/${tag}_pmc_traffic.json","w"))
+        def per_launch(pred):
+            tot=sum(v for (k,c),(v,n) in sums.items() if pred(k)); nl=sum(n for (k,c),(v,n) in sums.items() if pred(k))
+            return (tot*1024.0/nl if nl else None), nl
+        raw_all,nl_all=per_launch(lambda k: k.startswith("k_pso_iter") or k.startswith("k_pso_eval"))
+        raw_e2,nl_e2=per_launch(lambda k: k.startswith("k_pso_eval"))
+        if nl_all:
+            json.dump({"$SCENE": {"seeds": $SEEDS, "parents_per_round": $PPR, "max_rounds": $MAXR,
+                       "eval2_hbm_read_bytes_per_launch": (2.0*raw_e2 if raw_e2 else None), "eval2_launches": nl_e2,
+                       "eval_hbm_read_bytes_per_launch": 2.0*raw_all, "launches": nl_all, "tag": "$tag",
+                       "note": "rocprofv3 --pmc FETCH_SIZE (KiB) summed over the dispatches of the kernel in 'bench.py --steps 1 --warmup 0 $*' / its launches, x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated for wide coalesced reads only, so an upper bound for these 2- / 8-byte gathers)"}},
+                      open("gpurun_out/${tag}_pmc_traffic.json","w"), indent=1)
 else:
     print("no db (see log)")
 PY

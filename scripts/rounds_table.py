@@ -1,7 +1,7 @@
 """Per-round table (candidates, duration, kernel counts) of the second reconstruction in a rocprofv3 kernel-trace db."""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
-rows = [(r[0].split('(')[0], r[1], r[2], r[3], r[4]) for r in cur.execute("select name,start,end,grid_x,queue_id from kernels order by start")]
+rows = [(r[0].split('(')[0].replace('void ', ''), r[1], r[2], r[3], r[4]) for r in cur.execute("select name,start,end,grid_x,queue_id from kernels order by start")]
 begins = [i for i, r in enumerate(rows) if r[0].startswith('k_begin')]
 # the second half of the k_begin launches belongs to the timed step (warmup 1, steps 1)
 half = (len(begins) // 3) if len(begins) % 3 == 0 else len(begins) // 2   # warm-up, timed, roofline step
@@ -13,7 +13,7 @@ for k, (a, b) in enumerate(zip(begins[half:end], (begins[half + 1:] + [len(rows)
     n = seg[0][3] // 64
     dur = ((rows[b][1] if b < len(rows) else seg[-1][2]) - seg[0][1]) / 1e3
     it = [r for r in seg if 'k_pso_iter' in r[0] or 'k_pso_eval' in r[0]]
-    af = sum((r[2] - r[1]) for r in seg if r[0] == 'k_after') / 1e3
+    af = sum((r[2] - r[1]) for r in seg if r[0].startswith('k_after') or r[0].startswith('k_region_ratio')) / 1e3
     itus = sum((r[2] - r[1]) for r in it) / 1e3
     kinds = sorted(set(r[0].replace('void ', '') for r in it))
     tot += dur

@@ -18,7 +18,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q, replicate_below):
+def _worker(rank, world, port, q, replicate_below, fail_rank=-1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"] = str(rank); os.environ["WORLD_SIZE"] = str(world)
@@ -38,6 +38,8 @@ def _worker(rank, world, port, q, replicate_below):
     calls = {"n": 0, "cands": 0}
 
     def source(n, cands, out, has_seeds):
+        if rank == fail_rank and not has_seeds:
+            raise RuntimeError("injected failure of this rank's refinement")
         S.ptr.contents.cfg.neighborRadius = m.neighbor_radius()
         recs = _oracle_records(S, cands, n, has_seeds)
         C.memmove(out, recs, n * C.sizeof(_lib.PatchResult))
@@ -46,20 +48,25 @@ def _worker(rank, world, port, q, replicate_below):
     m.set_record_source(source)
     D.attach(m, job, transport="host")
     m.set_replicate_below(replicate_below)
-    D.reconstruct(m, 8, max_rounds=10)
+    try:
+        D.reconstruct(m, 8, max_rounds=10)
+    except RuntimeError as e:
+        q.put((rank, "error", str(e)))
+        job.close()
+        return
     cloud = m.cloud()
     st = m.stats()
     q.put((rank, cloud.tobytes(), cloud.shape, int(st.candidates_effective), int(st.batches_sharded), int(st.batches_replicated),
-           calls["cands"]))
+           calls["cands"], int(st.exchange_bytes), [l.n for l in m.round_log()]))
     job.close()
 
 
-def _run(world, replicate_below):
+def _run(world, replicate_below, fail_rank=-1):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     port = _free_port()
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q, replicate_below)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, replicate_below, fail_rank)) for r in range(world)]
     for p in ps:
         p.start()
     got = [q.get(timeout=600) for _ in range(world)]
@@ -75,14 +82,70 @@ def test_two_rank_sharded_reconstruction_is_rank_count_invariant():
     # replicate_below = 72 evaluation waves (6 particles: 12 expansion candidates): thinner batches are replicated, the
     # others sharded -- both kinds of batch must occur so that both code paths run
     two = _run(2, 72)
-    for rank, blob, shape, eff, sharded, replicated, cands in two:
+    for rank, blob, shape, eff, sharded, replicated, cands, xbytes, nmin in two:
         assert shape == ref[2] and blob == ref[1] and eff == ref[3], rank
         assert sharded > 0 and replicated > 0, (sharded, replicated)
+        # what travelled: wire slots (include/pais_hip.h), a fraction of the 1488-byte records
+        assert 0 < xbytes < sharded * 2 * 64 + 0.3 * 1488 * (two[0][6] + two[1][6]), xbytes
     # the shards really were disjoint: together the two ranks refined fewer candidates than two full replicas would
     assert two[0][6] + two[1][6] < 2 * ref[6]
     # always shard (0): ragged shards incl. a last rank with padding; same cloud
-    for rank, blob, shape, eff, sharded, replicated, cands in _run(2, 0):
+    for rank, blob, shape, eff, sharded, replicated, cands, xbytes, nmin in _run(2, 0):
         assert blob == ref[1] and replicated == 0 and sharded > 0
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_many_ranks_with_ragged_and_empty_shards(world):
+    """4 and 8 ranks, always sharded: batches whose size is not a multiple of the world (a padded last shard) and batches
+    with fewer candidates than ranks (ranks with NO candidate still take part in the exchange) -- same cloud as one rank."""
+    ref = _run(1, 1024)[0]
+    got = _run(world, 0)
+    assert len(got) == world
+    for rank, blob, shape, eff, sharded, replicated, cands, xbytes, nmin in got:
+        assert shape == ref[2] and blob == ref[1] and eff == ref[3], rank
+        assert replicated == 0 and sharded > 0
+    ns = got[0][8]
+    per = [(n + world - 1) // world for n in ns]
+    assert any(n % world for n in ns)                          # ragged: a padded last shard
+    if world == 8:
+        assert any(p * (world - 1) >= n for n, p in zip(ns, per)), ns   # some batch left a rank without a candidate
+    assert sum(g[6] for g in got) == ref[6]                   # disjoint shards: together exactly one replica's work
+
+
+def test_a_failing_rank_fails_every_rank_together():
+    """a rank whose refinement fails must not leave the others waiting in the all-gather -- its status travels
+    in the exchange header and every rank returns the error."""
+    got = _run(2, 0, fail_rank=1)
+    assert all(g[1] == "error" for g in got), got
+    assert "rank 1" in got[0][2] or "record source" in got[0][2], got[0][2]
+
+
+def test_record_wire_format_roundtrip():
+    """pack -> unpack reproduces every byte of records whose arrays are empty beyond the batch's camera count; a slot is
+    208 + 20 x roundup2(K) bytes."""
+    from pais_mvs_amd import _lib
+    L = _lib.load()
+    L.pais_record_wire_bytes.restype = C.c_size_t
+    L.pais_record_wire_bytes.argtypes = [C.c_int]
+    L.pais_pack_records.argtypes = [C.c_int, C.POINTER(_lib.PatchResult), C.c_int, C.c_void_p]
+    L.pais_unpack_records.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(_lib.PatchResult)]
+    assert L.pais_record_wire_bytes(5) == 208 + 20 * 6 and L.pais_record_wire_bytes(64) == 208 + 20 * 64 == 1488
+    rng = np.random.default_rng(1)
+    for K in (1, 5, 6, 31, 64):
+        n = 7
+        recs = (_lib.PatchResult * n)()
+        raw = np.frombuffer(recs, dtype=np.uint8).reshape(n, C.sizeof(_lib.PatchResult))
+        raw[:] = rng.integers(0, 256, raw.shape, dtype=np.uint8)
+        for r in recs:                                           # arrays empty beyond K, as the batch calls leave them
+            for i in range(K, 64):
+                r.cam_idx[i] = 0; r.imgPoint[i][0] = 0.0; r.imgPoint[i][1] = 0.0
+        want = bytes(raw.tobytes())
+        wb = L.pais_record_wire_bytes(K)
+        wire = (C.c_uint8 * (wb * n))()
+        assert L.pais_pack_records(n, recs, K, wire) == 0
+        back = (_lib.PatchResult * n)()
+        assert L.pais_unpack_records(n, wire, K, back) == 0
+        assert bytes(back) == want, K
 
 
 def test_shard_bounds_cover_everything():
