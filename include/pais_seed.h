@@ -31,6 +31,13 @@ int  pais_seed_fundamental(const pais_camera_desc *from, const pais_camera_desc 
 int  pais_seed_match(int device, int nq, const float *query_desc, int nt, const float *train_desc, int dim,
                      int32_t *train_of_query, float *dist);
 
+/* The nearest searches of a whole rig in one call: every camera's descriptors are uploaded ONCE and nearest(i -> j) is
+ * evaluated once per ORDERED camera pair (pais_seed_match per pair would upload both sets and search both directions for
+ * (i, j) and again for (j, i)).  nearest: sum over i of kp[i].n * (num_cams - 1) entries, pair major -- for i ascending,
+ * for j ascending without i, the kp[i].n indices into camera j's descriptors (-1 when camera j has none); first minimum
+ * of the float L2 distance as in pais_seed_match.  The cross-check of a pair is `nearest(j -> i)[nearest(i -> j)[q]] == q`. */
+int  pais_seed_nearest_all(int device, int num_cams, const pais_keypoints *kp, int dim, int32_t *nearest);
+
 /* One pairwise match as the reference's match table holds it: matchTable[cam_q][cam_t] gets DMatch(q, t). */
 typedef struct pais_pair_match { int32_t cam_q, cam_t, q, t; } pais_pair_match;
 
@@ -38,12 +45,14 @@ typedef struct pais_pair_match { int32_t cam_q, cam_t, q, t; } pais_pair_match;
  * the reference's order: cam_q outer, cam_t inner, q ascending): epipolarLineFiltering (:158-196) with distance bound
  * `max_dist`, filteroutNonMatches (:198-243), the union of :56-82 / setNVMatch (:118-156), and one seed per n-view
  * feature with >= minCamNum views: Patch(0, grey, camIdx, imgPoint) + reCentering (:84-99), appended to `m` as by
- * pais_mvs_add_seed_measured(..., recenter = 1).  *num_seeds: seeds added.  Host only (m may be a GPU-less driver). */
+ * pais_mvs_add_seed_measured(..., recenter = 1).  *num_seeds: seeds added.  Host only (m may be a GPU-less driver).
+ * A (cam_q, cam_t, q, t) tuple given twice is an error: the reference's matcher yields each query at most once per
+ * pair, and its erase-while-scanning lists treat duplicates in a way no caller should rely on. */
 int  pais_mvs_seeds_from_matches(pais_mvs *m, int num_cams, const pais_keypoints *kp, int num_matches,
                                  const pais_pair_match *matches, double max_dist, int *num_seeds);
 
-/* FeatureManager::setSeedPatches(cameras, maxDist, mvs) from the keypoints on: pais_seed_match for every ordered pair
- * on the driver's GPU, then pais_mvs_seeds_from_matches. */
+/* FeatureManager::setSeedPatches(cameras, maxDist, mvs) from the keypoints on: pais_seed_nearest_all on the driver's GPU,
+ * the cross-check of every ordered pair (BFMatcher's crossCheck), then pais_mvs_seeds_from_matches. */
 int  pais_mvs_set_seed_patches(pais_mvs *m, int num_cams, const pais_keypoints *kp, int dim, double max_dist, int *num_seeds);
 
 const char *pais_seed_last_error(void);

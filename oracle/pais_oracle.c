@@ -704,7 +704,7 @@ static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const
     const int hasRef = firstRef >= 0;
     const double invK = 1.0 / (double)K, invDiffW = 1.0 / s->cfg.diffWeighting;
     const double a0 = pt[0] - r, b0 = pt[1] - r;
-    /* corners_inside (pais_eval.hpp): if every other camera maps the four window corners into [2, w-3) x [2, h-3) with a
+    /* corners_inside (pais_eval.hpp): if every other camera maps the four window corners into [3, w-4) x [3, h-4) with a
      * denominator of one sign, no tap of the (convex) window can leave the image: the per-tap test of :999 is skipped
      * for this evaluation; otherwise it is applied tap by tap as the reference does */
     int fast = 1;
@@ -718,8 +718,9 @@ static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const
             const double rw = 1.0 / w;
             const double ix = fma(Hi[1], y, fma(Hi[0], x, Hi[2])) * rw, iy = fma(Hi[4], y, fma(Hi[3], x, Hi[5])) * rw;
             /* (int) of a NaN / out-of-range double is 0 / saturated on the GPU: rejected either way */
-            const int okx = ix >= 2 && ix < (double)(cam->width[LOD] - 3), oky = iy >= 2 && iy < (double)(cam->height[LOD] - 3);
-            if (!(okx && oky)) fast = 0;
+            /* (the box shrunk by one pixel and a denominator of ordinary size: pais_eval.hpp corners_inside) */
+            const int okx = ix >= 3 && ix < (double)(cam->width[LOD] - 4), oky = iy >= 3 && iy < (double)(cam->height[LOD] - 4);
+            if (!(okx && oky) || !(fabs(w) > 1e-90 && fabs(w) < 1e90)) fast = 0;
             npos += w > 0.0;
             nneg += w < 0.0;
         }

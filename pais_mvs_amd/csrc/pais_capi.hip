@@ -154,6 +154,7 @@ extern "C" size_t pais_sizeof_patch_result(void) { return sizeof(pais_patch_resu
 extern "C" uint32_t pais_rand31(uint64_t seed, uint64_t key, uint32_t run, uint32_t k) { return pais::rand31(seed, key, run, k); }
 extern "C" uint64_t pais_child_key(uint64_t parent_key, int cam, int cx, int cy) { return pais::child_key(parent_key, cam, cx, cy); }
 
+static int ctx_init(pais_ctx *ctx, const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device, uint64_t pso_seed);
 extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device,
                                uint64_t pso_seed, pais_ctx **out)
 {
@@ -164,6 +165,16 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     if (device < 0 || device >= ndev) return fail_msg("pais_ctx_create: bad device index");
     HIPCHK(hipSetDevice(device));
     pais_ctx *ctx = new pais_ctx();
+    // every failure below -- a validation message or a HIP error, e.g. hipMalloc of a multi-GB blob -- leaves through
+    // ctx_init's return value; what had been created by then is released here
+    const int rc = ctx_init(ctx, cfg, num_cams, cams, device, pso_seed);
+    if (rc) { pais_ctx_destroy(ctx); return rc; }
+    *out = ctx;
+    return 0;
+}
+
+static int ctx_init(pais_ctx *ctx, const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device, uint64_t pso_seed)
+{
     ctx->device = device;
     memset(&ctx->sc, 0, sizeof(ctx->sc));
     hipDeviceProp_t prop;
@@ -174,7 +185,7 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     ctx->sc.seed = pso_seed;
     ctx->sc.numCams = num_cams;
     int rc = apply_config(ctx, cfg);
-    if (rc) { pais_ctx_destroy(ctx); return rc; }
+    if (rc) return rc;
     const bool wantEdge = cfg->adaptiveGradientEnable != 0;
     // edge pyramids: as the caller built them (Camera::pyramidEdge, camera.cpp:72-77,87-91), or -- level_edge == NULL --
     // evaluated on the fly from the gray levels with the same statements (no double-precision copy of every pyramid)
@@ -186,17 +197,17 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     size_t imgBytes = 0, edgeBytes = 0;
     for (int c = 0; c < num_cams; ++c) {
         const pais_camera_desc &d = cams[c];
-        if (d.max_lod < 0 || d.max_lod >= PAIS_MAX_LEVELS) { pais_ctx_destroy(ctx); return fail_msg("camera max_lod out of range"); }
+        if (d.max_lod < 0 || d.max_lod >= PAIS_MAX_LEVELS) return fail_msg("camera max_lod out of range");
         for (int l = 0; l <= d.max_lod; ++l) {
-            if (!d.level_image[l] || d.level_width[l] <= 0 || d.level_height[l] <= 0) { pais_ctx_destroy(ctx); return fail_msg("camera level missing"); }
+            if (!d.level_image[l] || d.level_width[l] <= 0 || d.level_height[l] <= 0) return fail_msg("camera level missing");
             // the evaluation packs a level's tap bounds (w - 4, h - 4) into 16 bits each and its row offsets into 24 (pais_eval.hpp)
-            if (d.level_width[l] > 65535 || d.level_height[l] > 65535) { pais_ctx_destroy(ctx); return fail_msg("camera level larger than 65535 pixels in one dimension"); }
+            if (d.level_width[l] > 65535 || d.level_height[l] > 65535) return fail_msg("camera level larger than 65535 pixels in one dimension");
             size_t px = (size_t)d.level_width[l] * d.level_height[l];
-            if (px >= ((size_t)1 << 29)) { pais_ctx_destroy(ctx); return fail_msg("camera level of 2^29 pixels or more (32-bit tap offsets inside a level)"); }
+            if (px >= ((size_t)1 << 29)) return fail_msg("camera level of 2^29 pixels or more (32-bit tap offsets inside a level)");
             imgOff[(size_t)c * PAIS_MAX_LEVELS + l] = imgBytes;
             imgBytes = (imgBytes + px + 16 + 255) & ~(size_t)255; // +16: taps read (px+1, py+1)
             if (wantEdge && edgesGiven) {
-                if (!d.level_edge[l]) { pais_ctx_destroy(ctx); return fail_msg("level_edge given for some levels only"); }
+                if (!d.level_edge[l]) return fail_msg("level_edge given for some levels only");
                 edgeOff[(size_t)c * PAIS_MAX_LEVELS + l] = edgeBytes;
                 edgeBytes = (edgeBytes + px * sizeof(double) + 255) & ~(size_t)255;
             }
@@ -243,8 +254,9 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
     if (wantEdge && !edgesGiven) {
         mm.assign((size_t)num_cams * PAIS_MAX_LEVELS * 2, 0ULL);
         for (size_t i = 0; i < mm.size(); i += 2) mm[i] = ~0ULL;
-        unsigned long long *d_mm = nullptr;
-        HIPCHK(hipMalloc(&d_mm, mm.size() * sizeof(unsigned long long)));
+        struct DevBuf { unsigned long long *p = nullptr; ~DevBuf() { (void)hipFree(p); } } mmBuf; // released on every path
+        HIPCHK(hipMalloc(&mmBuf.p, mm.size() * sizeof(unsigned long long)));
+        unsigned long long *d_mm = mmBuf.p;
         HIPCHK(hipMemcpyAsync(d_mm, mm.data(), mm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
         for (int c = 0; c < num_cams; ++c)
             for (int l = 0; l <= cams[c].max_lod; ++l)
@@ -252,7 +264,6 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
                                                       cams[c].level_height[l], d_mm + ((size_t)c * PAIS_MAX_LEVELS + l) * 2, ctx->stream));
         HIPCHK(hipMemcpyAsync(mm.data(), d_mm, mm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_mm);
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->edgesOnTheFly = wantEdge && !edgesGiven;
@@ -308,7 +319,6 @@ extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_
         ctx->subDone.push_back(ev);
     }
     if (const char *e = getenv("PAIS_FINE_TIMING")) ctx->fineTiming = atoi(e) != 0;
-    *out = ctx;
     return 0;
 }
 

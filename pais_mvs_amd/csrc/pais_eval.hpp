@@ -362,7 +362,7 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
 // The taps of a window are the images of its pixels under maps (h0 x + h1 y + h2) / (h6 x + h7 y + h8): where the
 // denominator keeps one sign over the window -- it is affine, so: at the four corners -- the image of the (convex) window
 // is convex and lies inside the bounding box of the four corner images.  If every camera maps all four corners into
-// [2, w-3) x [2, h-3) no tap can leave it, the whole-call DBL_MAX of patch.cpp:999-1002 cannot trigger and the per-tap
+// [3, w-4) x [3, h-4) -- the reference's box shrunk by a pixel, see below -- no tap can leave [2, w-3) x [2, h-3), the whole-call DBL_MAX of patch.cpp:999-1002 cannot trigger and the per-tap
 // clamp / flag logic (5 of 39 instructions per tap) is dropped for this evaluation.  Otherwise (a particle that grazes an
 // image border, or a degenerate plane) the evaluation runs the checked loop: the reference's rule tap by tap.
 // One (corner, camera) pair per lane; the corner taps use a plain quotient n * (1 / w).
@@ -380,7 +380,11 @@ __device__ __forceinline__ bool corners_inside(const EvalPatch *ep, const EvalCa
         const double ix = fma(H[1], y, fma(H[0], x, H[2])) * rw, iy = fma(H[4], y, fma(H[3], x, H[5])) * rw;
         const int qx = (int)ix, qy = (int)iy;
         const uint32_t qp = cams[c].qpack;
-        bool in = qx >= 2 && qx <= (int)(qp & 0xffffu) && qy >= 2 && qy <= (int)(qp >> 16);
+        // one pixel inside the reference's bound [2, w-3) x [2, h-3): the window's taps come out of the batch inversion
+        // r * w_other, which rounds differently from this corner's n * (1 / w) -- a corner within an ulp of the bound must not
+        // be able to put a tap on the other side of it.  And a denominator of ordinary size: the products of two or three of
+        // them that the batch inversion forms can then neither overflow nor underflow.
+        bool in = qx >= 3 && qx < (int)(qp & 0xffffu) && qy >= 3 && qy < (int)(qp >> 16) && fabs(w) > 1e-90 && fabs(w) < 1e90;
         // one sign of w over the four corners of a camera: lanes 4c .. 4c+3
         const unsigned long long neg = __ballot(w < 0.0), pos = __ballot(w > 0.0);
         const unsigned long long grp = 0xFull << (lane & ~3);

@@ -1550,6 +1550,18 @@ extern "C" int pais_mvs_seeds_from_matches(pais_mvs *m, int num_cams, const pais
     // the match table after epipolarLineFiltering (:158-196)
     typedef std::pair<int, int> QT;
     std::vector<std::vector<QT>> table((size_t)C * C);
+    {   // a tuple given twice is refused (the statement below over hashed pair sets equals the reference's
+        // erase-while-scanning lists only while the matches of a pair are unique)
+        std::unordered_set<uint64_t> seen;
+        seen.reserve((size_t)num_matches * 2);
+        for (int k = 0; k < num_matches; ++k) {
+            const pais_pair_match &mm = matches[k];
+            if (mm.cam_q < 0 || mm.cam_q >= C || mm.cam_t < 0 || mm.cam_t >= C || mm.q < 0 || mm.t < 0 || mm.q >= (1 << 24) || mm.t >= (1 << 24) || C > 256)
+                continue; // (validated below / rigs beyond the key's range: checked per pair list instead)
+            const uint64_t kk = ((uint64_t)mm.cam_q << 56) | ((uint64_t)mm.cam_t << 48) | ((uint64_t)mm.q << 24) | (uint64_t)mm.t;
+            if (!seen.insert(kk).second) return mfail("pais_mvs_seeds_from_matches: the same (cam_q, cam_t, q, t) match is given twice");
+        }
+    }
     for (int k = 0; k < num_matches; ++k) {
         const pais_pair_match &mm = matches[k];
         if (mm.cam_q < 0 || mm.cam_q >= C || mm.cam_t < 0 || mm.cam_t >= C || mm.cam_q == mm.cam_t || mm.q < 0 || mm.q >= kp[mm.cam_q].n ||
@@ -1661,18 +1673,27 @@ extern "C" int pais_mvs_set_seed_patches(pais_mvs *m, int num_cams, const pais_k
 {
     if (!m || !kp || num_cams != (int)m->cams.size() || dim <= 0) return mfail("pais_mvs_set_seed_patches: bad argument");
     if (!m->ctx) return mfail("pais_mvs_set_seed_patches: this driver owns no GPU (the descriptor matching runs on it)");
-    std::vector<pais_pair_match> all;
-    std::vector<int32_t> tq;
-    std::vector<float> dd;
+    // nearest(i -> j) once per ordered pair, every camera's descriptors uploaded once; the cross-check of (i, j) reads the
+    // two directions (BFMatcher crossCheck: q keeps its nearest t only if t's nearest is q)
+    size_t total = 0;
+    std::vector<size_t> pairOff((size_t)num_cams * num_cams, 0);
     for (int i = 0; i < num_cams; ++i)
         for (int j = 0; j < num_cams; ++j) {
             if (i == j) continue;
-            tq.assign((size_t)std::max(kp[i].n, 1), -1);
-            dd.assign((size_t)std::max(kp[i].n, 1), 0.f);
-            if (pais_seed_match(m->device, kp[i].n, kp[i].desc, kp[j].n, kp[j].desc, dim, tq.data(), dd.data()))
-                return mfail(pais_seed_last_error());
-            for (int q = 0; q < kp[i].n; ++q)
-                if (tq[(size_t)q] >= 0) all.push_back(pais_pair_match{i, j, q, tq[(size_t)q]});
+            pairOff[(size_t)i * num_cams + j] = total;
+            total += (size_t)std::max(kp[i].n, 0);
+        }
+    std::vector<int32_t> nn(total ? total : 1, -1);
+    if (pais_seed_nearest_all(m->device, num_cams, kp, dim, nn.data())) return mfail(pais_seed_last_error());
+    std::vector<pais_pair_match> all;
+    for (int i = 0; i < num_cams; ++i)
+        for (int j = 0; j < num_cams; ++j) {
+            if (i == j) continue;
+            const int32_t *ij = nn.data() + pairOff[(size_t)i * num_cams + j], *ji = nn.data() + pairOff[(size_t)j * num_cams + i];
+            for (int q = 0; q < kp[i].n; ++q) {
+                const int32_t t = ij[q];
+                if (t >= 0 && t < kp[j].n && ji[t] == q) all.push_back(pais_pair_match{i, j, q, t});
+            }
         }
     return pais_mvs_seeds_from_matches(m, num_cams, kp, (int)all.size(), all.data(), max_dist, num_seeds);
 }

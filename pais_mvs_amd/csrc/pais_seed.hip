@@ -99,6 +99,48 @@ extern "C" int pais_seed_match(int device, int nq, const float *query_desc, int 
     return 0;
 }
 
+extern "C" int pais_seed_nearest_all(int device, int num_cams, const pais_keypoints *kp, int dim, int32_t *nearest)
+{
+    if (num_cams < 0 || dim <= 0 || (num_cams && (!kp || !nearest))) return sfail("pais_seed_nearest_all: bad argument");
+    if (device < 0) return sfail("pais_seed_nearest_all: needs a GPU");
+    if (dim % 4 != 0) return sfail("pais_seed_nearest_all: descriptor dimension must be a multiple of 4 (cv::SIFT: 128): rows are read 16 bytes at a time");
+    for (int c = 0; c < num_cams; ++c)
+        if (kp[c].n < 0 || (kp[c].n && !kp[c].desc)) return sfail("pais_seed_nearest_all: bad keypoints");
+    SHIP(hipSetDevice(device));
+    struct Bufs { // freed on every return path
+        std::vector<float *> desc;
+        int32_t *best = nullptr;
+        float *dist = nullptr;
+        ~Bufs() { for (float *p : desc) (void)hipFree(p); (void)hipFree(best); (void)hipFree(dist); }
+    } b;
+    b.desc.assign((size_t)num_cams, nullptr);
+    size_t total = 0;
+    int nmax = 0;
+    for (int c = 0; c < num_cams; ++c) { // every camera's descriptors go up ONCE
+        if (kp[c].n == 0) continue;
+        SHIP(hipMalloc(&b.desc[c], sizeof(float) * (size_t)kp[c].n * dim));
+        SHIP(hipMemcpy(b.desc[c], kp[c].desc, sizeof(float) * (size_t)kp[c].n * dim, hipMemcpyHostToDevice));
+        total += (size_t)kp[c].n * (size_t)(num_cams - 1);
+        nmax = kp[c].n > nmax ? kp[c].n : nmax;
+    }
+    if (total == 0) return 0;
+    SHIP(hipMalloc(&b.best, sizeof(int32_t) * total));
+    SHIP(hipMalloc(&b.dist, sizeof(float) * (size_t)nmax));
+    const size_t lds = sizeof(float) * (size_t)dim;
+    size_t off = 0;
+    for (int i = 0; i < num_cams; ++i)
+        for (int j = 0; j < num_cams; ++j) { // nearest(i -> j) once per ORDERED pair
+            if (i == j || kp[i].n == 0) continue;
+            if (kp[j].n == 0) SHIP(hipMemsetAsync(b.best + off, 0xff, sizeof(int32_t) * (size_t)kp[i].n, 0)); // -1: nothing to match
+            else hipLaunchKernelGGL(k_nearest_descriptor, dim3(kp[i].n < 65536 ? kp[i].n : 65536), dim3(64), lds, 0, b.desc[i], kp[i].n,
+                                    b.desc[j], kp[j].n, dim, b.best + off, b.dist);
+            off += (size_t)kp[i].n;
+        }
+    SHIP(hipGetLastError());
+    SHIP(hipMemcpy(nearest, b.best, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int pais_seed_fundamental(const pais_camera_desc *from, const pais_camera_desc *to, double F[9])
 {
     if (!from || !to || !F) return sfail("pais_seed_fundamental: bad argument");

@@ -38,7 +38,8 @@ def keypoint_array(xy: Sequence[np.ndarray], desc: Sequence[np.ndarray]):
     arr = (Keypoints * len(xy))()
     for c, (p, d) in enumerate(zip(xy, desc)):
         p = np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 2)
-        d = np.ascontiguousarray(d, dtype=np.float32).reshape(len(p), -1)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        d = d.reshape(len(p), d.size // len(p)) if len(p) else d.reshape(0, 0)   # (a camera without keypoints is fine)
         keep += [p, d]
         arr[c].n = len(p)
         arr[c].xy = p.ctypes.data_as(C.POINTER(C.c_float))
@@ -85,7 +86,14 @@ def set_seed_patches(m: MVS, xy, desc, max_dist: float) -> int:
     """FeatureManager::setSeedPatches(cameras, maxDist, mvs) from the keypoints / descriptors on; returns the seeds added."""
     L = _bind(m.L)
     arr, keep = keypoint_array(xy, desc)
-    dim = int(np.asarray(desc[0]).reshape(len(np.asarray(xy[0]).reshape(-1, 2)), -1).shape[1])
+    dim = 0
+    for p, d in zip(xy, desc):                  # the first camera that has keypoints defines the descriptor length
+        npts = len(np.asarray(p).reshape(-1, 2))
+        if npts:
+            dim = int(np.asarray(d).size // npts)
+            break
+    if dim <= 0:
+        return 0
     n = C.c_int(0)
     m._check(L.pais_mvs_set_seed_patches(m.h, len(xy), arr, dim, float(max_dist), C.byref(n)), "pais_mvs_set_seed_patches")
     return n.value
