@@ -84,6 +84,8 @@ struct pais_ctx {
     int evalParts = 0;                  // waves per cost evaluation in k_pso_iter (1, 2, 4); 0 = chosen per slice
     double partFill = 0.75;             // ... such that parts * waves <= partFill * numCUs * 16 (= the 3 waves per SIMD the kernels' registers allow)
     int psoStreams = 2;
+    int tileMode = 1;                   // PAIS_TILE=0: many-camera batches keep the one-wave-per-evaluation kernels
+    long tileAbove = 512;               // PAIS_TILE_ABOVE: waves per iteration from which a tile-eligible batch runs the tile kernel
     std::vector<hipStream_t> sub;       // sub-streams
     std::vector<hipEvent_t> subDone;
     hipEvent_t forkEv = nullptr;
@@ -310,6 +312,8 @@ static int ctx_init(pais_ctx *ctx, const pais_config *cfg, int num_cams, const p
     if (const char *e = getenv("PAIS_SPLIT_ABOVE")) { long v = atol(e); if (v > 0) ctx->splitAbove = v; }
     if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
+    if (const char *e = getenv("PAIS_TILE")) ctx->tileMode = atoi(e);
+    if (const char *e = getenv("PAIS_TILE_ABOVE")) { long v = atol(e); if (v > 0) ctx->tileAbove = v; }
     HIPCHK(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming));
     for (int i = 0; i + 1 < ctx->psoStreams; ++i) { // slice 0 runs on ctx->stream itself
         hipStream_t st; hipEvent_t ev;
@@ -586,7 +590,11 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         // (>= 3 x 12 waves per CU) is throughput bound: there the step replay in every evaluation wave (~13 % of a wave's
         // time) costs more than a separate one-wave-per-candidate k_pso_step launch per iteration, whose latency the other
         // sub-stream hides
-        const bool useIter = Nmax <= 64 && (long)n * Nmax < ctx->splitAbove;
+        const bool tileOk = ctx->tileMode != 0 && pais_launch::tile_eligible(Kmax);
+        // (the tile kernel is an evaluation launch of the large-batch pipeline: batches that are eligible for it take that
+        // pipeline from PAIS_TILE_ABOVE waves per iteration on)
+        const bool useIter = Nmax <= 64 && (long)n * Nmax < (tileOk ? ctx->tileAbove : ctx->splitAbove);
+        const bool useTile = tileOk && !useIter;
         // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
         // its length is n at most in the first pass and exactly the "again" count afterwards
         const int nRun = useIter ? (pass == 0 ? n : againCount) : n;
@@ -627,9 +635,15 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 if (useIter)
                     HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, cnt + 2, q.lo, q.hi, Nmax, Kmax, d_out,
                                                  ctx->d_stat, it, 0, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
-                else
+                else if (useTile) {
+                    // many cameras: footprints staged in LDS (pais_tile.hpp); the particles it flags take the checked walk
+                    HIPCHK(pais_launch::pso_tile(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
+                                                 ctx->d_win + WB * (size_t)q.lo, ctx->numCUs, q.st));
                     HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
-                                                 ctx->d_win + WB * (size_t)q.lo, q.st));
+                                                 ctx->d_win + WB * (size_t)q.lo, 1, q.st));
+                } else
+                    HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
+                                                 ctx->d_win + WB * (size_t)q.lo, 0, q.st));
                 if (te.end()) return -2;
                 ctx->evalLaunches++;
                 if (!useIter) ctx->eval2Launches++;

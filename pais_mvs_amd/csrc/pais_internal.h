@@ -72,7 +72,10 @@ size_t pso_state_bytes_host(int Nmax);
 hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
                     int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    hipStream_t stream);
+                    int pendingOnly, hipStream_t stream);
+bool tile_eligible(int Kmax);
+hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
+                    int numCUs, hipStream_t stream);
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                     int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream);

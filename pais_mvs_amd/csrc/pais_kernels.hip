@@ -731,7 +731,8 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 // The candidate's constants come from the block k_pso_init prepared; positions from swarm buffer 0 (k_pso_step).
 template <int NS, bool BYTES, bool ACCR>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
-                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
+                                                                    const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
+                                                                    int pendingOnly)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
     unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, ACCR); // wave-private scratch
@@ -755,7 +756,9 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
         const int active = hd->active, Nrun = hd->N;
         const double p0 = A.pos[iLoad][0], p1 = A.pos[iLoad][1], p2 = A.pos[iLoad][2];
         const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0;
-        if (!active || i >= Nrun) continue;
+        // pendingOnly: the launch behind k_pso_tile (pais_tile.hpp) -- only the particles it flagged for the checked walk
+        const double pend = pendingOnly ? A.part[iLoad][0] : 1.0;
+        if (!active || i >= Nrun || pend != 1.0) continue;
         wave_sync();
         stage_eval_block(smem, src, nwMax, lane, v0, v1);
         wave_sync();
@@ -764,6 +767,8 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
         if (lane == 0) A.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
     }
 }
+
+#include "pais_tile.hpp"
 
 // ------------------------------------------------------------- k_pso_iter ---
 // Default PSO pipeline: ONE launch per PSO iteration.  The wave of (candidate c, particle i) first replays
@@ -1639,7 +1644,7 @@ hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, un
 }
 template <int NS, bool BYTES, bool ACCR>
 static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
-                                   const void *win, hipStream_t stream)
+                                   const void *win, int pendingOnly, hipStream_t stream)
 {
     static LdsAttr attr;
     const size_t lds = eval_lds_bytes(NS, Kmax, ACCR) * PAIS_WG_WAVES;
@@ -1647,14 +1652,31 @@ static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, in
     if (e != hipSuccess) return e;
     const int grid = eval_grid((long)n * Nmax);
     hipLaunchKernelGGL((k_pso_eval2<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win);
+                       eval_block_bytes(Kmax), (const WinPix *)win, pendingOnly);
     return hipGetLastError();
 }
 // the evaluation launch of large batches: `states`, `evalBlocks`, `win` point at the slice's first candidate
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    hipStream_t stream)
+                    int pendingOnly, hipStream_t stream)
 {
-    PAIS_SHAPE_DISPATCH(pso_eval2_launch, sc, states, n, Nmax, Kmax, evalBlocks, win, stream);
+    PAIS_SHAPE_DISPATCH(pso_eval2_launch, sc, states, n, Nmax, Kmax, evalBlocks, win, pendingOnly, stream);
+}
+// many-camera batches: the tile kernel (pais_tile.hpp) can take the evaluation launch of the large-batch pipeline
+bool tile_eligible(int Kmax) { return eval_shape(Kmax) == 2 && Kmax <= TILE_MAX_CAMS; }
+hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
+                    int numCUs, hipStream_t stream)
+{
+    static LdsAttr attr;
+    const size_t lds = 160 * 1024, fixed = tile_fixed_lds_bytes(Kmax);
+    hipError_t e = attr.ensure((const void *)k_pso_tile, lds);
+    if (e != hipSuccess) return e;
+    const int groups = (Nmax + TILE_WAVES - 1) / TILE_WAVES;
+    long grid = (long)n * groups;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(k_pso_tile, dim3((unsigned)grid), dim3(64 * TILE_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win, (int)(lds - fixed), groups);
+    (void)numCUs;
+    return hipGetLastError();
 }
 template <int P, int NS, bool BYTES, bool ACCR>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,

@@ -447,10 +447,17 @@ def test_bench_refuses_a_rank_count_it_cannot_run():
     assert r.returncode != 0 and "n_gpus" not in r.stdout
 
 
-def test_dome_radius25_many_cameras(dome_small):
+@pytest.mark.parametrize("tile", ["tile kernel for every batch", "one wave per evaluation"])
+def test_dome_radius25_many_cameras(dome_small, monkeypatch, tile):
     """Config-4-like parameters: patchRadius 25 (S^2 = 2601), reduceNormalRange 4, all weights, many visible
-    cameras per patch (large per-wave LDS carve).  Cost + seeds + a few expansion rounds, bit for bit."""
+    cameras per patch.  Cost + seeds + a few expansion rounds against the oracle, bit for bit -- through the LDS-tile
+    kernel of many-camera batches (pais_tile.hpp: footprints staged in LDS, colours in registers; forced for every
+    batch incl. the seeds' 2N particles) and through the one-wave-per-evaluation kernels."""
     from oracle import po
+    if tile.startswith("tile"):
+        monkeypatch.setenv("PAIS_TILE_ABOVE", "1")
+    else:
+        monkeypatch.setenv("PAIS_TILE", "0")
     from pais_mvs_amd.config import readme_config
     from pais_mvs_amd.mvs import MVS
     cfg = readme_config(patchRadius=25, distWeighting=25 / 3.0, reduceNormalRange=4.0, adaptiveGradientEnable=True,
