@@ -84,6 +84,10 @@ struct pais_ctx {
     int evalParts = 0;                  // waves per cost evaluation in k_pso_iter (1, 2, 4); 0 = chosen per slice
     double partFill = 0.75;             // ... such that parts * waves <= partFill * numCUs * 16 (= the 3 waves per SIMD the kernels' registers allow)
     int psoStreams = 2;
+    int tileStrip2 = 14, tileStrip1 = 20; // 64-pixel steps per strip of the two instantiations (PAIS_TILE_STRIP2 / PAIS_TILE_STRIP1)
+    int tileForceNs1 = 0;               // PAIS_TILE_FORCE_NS1 (tests): the one-pixel instantiation also for batches of <= 32 cameras
+    bool tileVerify = false;            // PAIS_TILE_VERIFY=1: every particle is ALSO walked by k_pso_eval2 and the two values compared (diagnosis)
+    bool tileDebug = false;             // PAIS_TILE_DEBUG=1: counters of the tile kernel (printed by pais_get_kernel_stats)
     int tileMode = 1;                   // PAIS_TILE=0: many-camera batches keep the one-wave-per-evaluation kernels
     long tileAbove = 512;               // PAIS_TILE_ABOVE: waves per iteration from which a tile-eligible batch runs the tile kernel
     std::vector<hipStream_t> sub;       // sub-streams
@@ -303,8 +307,8 @@ static int ctx_init(pais_ctx *ctx, const pais_config *cfg, int num_cams, const p
 
     HIPCHK(hipMalloc(&ctx->d_counters, sizeof(int) * 8));
     HIPCHK(hipMemset(ctx->d_counters, 0, sizeof(int) * 8));
-    HIPCHK(hipMalloc(&ctx->d_stat, sizeof(unsigned long long) * 8));
-    HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
+    HIPCHK(hipMalloc(&ctx->d_stat, sizeof(unsigned long long) * 24));
+    HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 24));
     HIPCHK(hipHostMalloc((void **)&ctx->h_counters, sizeof(int) * 4, hipHostMallocDefault));
     if (const char *e = getenv("PAIS_EVAL_PARTS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) ctx->evalParts = v; }
     if (const char *e = getenv("PAIS_PART_FILL")) { double v = atof(e); if (v > 0) ctx->partFill = v; }
@@ -313,6 +317,11 @@ static int ctx_init(pais_ctx *ctx, const pais_config *cfg, int num_cams, const p
     if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     if (const char *e = getenv("PAIS_TILE")) ctx->tileMode = atoi(e);
+    if (const char *e = getenv("PAIS_TILE_DEBUG")) ctx->tileDebug = atoi(e) != 0;
+    if (const char *e = getenv("PAIS_TILE_VERIFY")) ctx->tileVerify = atoi(e) != 0;
+    if (const char *e = getenv("PAIS_TILE_STRIP2")) { int v = atoi(e); if (v >= 2) ctx->tileStrip2 = v; }
+    if (const char *e = getenv("PAIS_TILE_STRIP1")) { int v = atoi(e); if (v >= 1) ctx->tileStrip1 = v; }
+    if (const char *e = getenv("PAIS_TILE_FORCE_NS1")) ctx->tileForceNs1 = atoi(e) != 0;
     if (const char *e = getenv("PAIS_TILE_ABOVE")) { long v = atol(e); if (v > 0) ctx->tileAbove = v; }
     HIPCHK(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming));
     for (int i = 0; i + 1 < ctx->psoStreams; ++i) { // slice 0 runs on ctx->stream itself
@@ -638,9 +647,10 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                 else if (useTile) {
                     // many cameras: footprints staged in LDS (pais_tile.hpp); the particles it flags take the checked walk
                     HIPCHK(pais_launch::pso_tile(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
-                                                 ctx->d_win + WB * (size_t)q.lo, ctx->numCUs, q.st));
+                                                 ctx->d_win + WB * (size_t)q.lo, ctx->tileStrip2, ctx->tileStrip1, ctx->tileForceNs1,
+                                                 ctx->tileDebug ? ctx->d_stat + 8 : nullptr, q.st));
                     HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
-                                                 ctx->d_win + WB * (size_t)q.lo, 1, q.st));
+                                                 ctx->d_win + WB * (size_t)q.lo, ctx->tileVerify ? 2 : 1, q.st));
                 } else
                     HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
                                                  ctx->d_win + WB * (size_t)q.lo, 0, q.st));
@@ -801,8 +811,13 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
         ctx->eval2Ms += ms2;
         ctx->evalMs += ms2;
     }
-    unsigned long long st[8];
+    unsigned long long st[24];
     HIPCHK(hipMemcpy(st, ctx->d_stat, sizeof(st), hipMemcpyDeviceToHost));
+    if (ctx->tileDebug)
+        fprintf(stderr, "[pais tile] particles through the tiles %llu, DBL_MAX %llu, pending (checked walk) %llu; tiles staged %llu (%.1f KB each), cameras left in global memory %llu\n",
+                st[8], st[9], st[10], st[11], st[11] ? (double)st[13] / (double)st[11] / 1024.0 : 0.0, st[12]);
+    if (ctx->tileDebug)
+        fprintf(stderr, "[pais tile] cycles of wave 0 per phase: boxes %.3g, layout %.3g, copy %.3g, walk %.3g\n", (double)st[14], (double)st[15], (double)st[16], (double)st[17]);
     const double S2 = (double)ctx->sc.cfg.patchSize * ctx->sc.cfg.patchSize;
     out->pso_ms = ctx->psoMs;
     out->begin_ms = ctx->beginMs;
@@ -820,7 +835,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
     out->eval2_evals = (int64_t)st[5];
     out->eval2_algorithmic_bytes = (double)st[6] * S2;
     if (reset) {
-        HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 8));
+        HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 24));
         ctx->psoMs = ctx->beginMs = ctx->afterMs = ctx->evalMs = ctx->eval2Ms = 0;
         ctx->psoLaunches = 0;
         ctx->evalLaunches = 0;

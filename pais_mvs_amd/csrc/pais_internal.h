@@ -75,7 +75,7 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
                     int pendingOnly, hipStream_t stream);
 bool tile_eligible(int Kmax);
 hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int numCUs, hipStream_t stream);
+                    int strip2, int strip1, int forceNs1, unsigned long long *dbg, hipStream_t stream);
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                     int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream);

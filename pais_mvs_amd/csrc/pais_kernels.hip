@@ -18,6 +18,7 @@
 // (SURVEY 8d).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/pais_hip.h"
 #include "pais_dev.hpp"
@@ -758,13 +759,18 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
         const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0;
         // pendingOnly: the launch behind k_pso_tile (pais_tile.hpp) -- only the particles it flagged for the checked walk
         const double pend = pendingOnly ? A.part[iLoad][0] : 1.0;
-        if (!active || i >= Nrun || pend != 1.0) continue;
+        if (!active || i >= Nrun || (pend != 1.0 && pendingOnly != 2)) continue;
         wave_sync();
         stage_eval_block(smem, src, nwMax, lane, v0, v1);
         wave_sync();
         double f4[4], w4[4];
         const int st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
-        if (lane == 0) A.fit[i] = st ? DBL_MAX : combine_parts(f4, w4);
+        if (lane == 0) {
+            const double v = st ? DBL_MAX : combine_parts(f4, w4);
+            if (pendingOnly == 2 && pend != 1.0 && A.fit[i] != v) // PAIS_TILE_VERIFY: the tile kernel's value against this walk's
+                printf("[pais tile verify] candidate %d particle %d K %d: tile %.17g one-wave %.17g\n", c, i, ep->K, A.fit[i], v);
+            A.fit[i] = v;
+        }
     }
 }
 
@@ -1650,7 +1656,10 @@ static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, in
     const size_t lds = eval_lds_bytes(NS, Kmax, ACCR) * PAIS_WG_WAVES;
     hipError_t e = attr.ensure((const void *)k_pso_eval2<NS, BYTES, ACCR>, lds);
     if (e != hipSuccess) return e;
-    const int grid = eval_grid((long)n * Nmax);
+    // pending-only (behind k_pso_tile): a handful of particles at most -- a few waves scan the flags (grid-stride loop);
+    // one workgroup per particle would queue tens of thousands of workgroups, each asking for LDS, behind the tile
+    // kernel of the other sub-stream, which holds every CU's LDS (measured: 2.2 ms per launch spent waiting)
+    const int grid = pendingOnly == 1 ? (int)(((long)n * Nmax < 256) ? (long)n * Nmax : 256) : eval_grid((long)n * Nmax);
     hipLaunchKernelGGL((k_pso_eval2<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
                        eval_block_bytes(Kmax), (const WinPix *)win, pendingOnly);
     return hipGetLastError();
@@ -1663,20 +1672,29 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
 }
 // many-camera batches: the tile kernel (pais_tile.hpp) can take the evaluation launch of the large-batch pipeline
 bool tile_eligible(int Kmax) { return eval_shape(Kmax) == 2 && Kmax <= TILE_MAX_CAMS; }
-hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int numCUs, hipStream_t stream)
+template <int NS, int NP>
+static hipError_t pso_tile_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
+                                  const void *win, int stripSteps, unsigned long long *dbg, hipStream_t stream)
 {
     static LdsAttr attr;
     const size_t lds = 160 * 1024, fixed = tile_fixed_lds_bytes(Kmax);
-    hipError_t e = attr.ensure((const void *)k_pso_tile, lds);
+    hipError_t e = attr.ensure((const void *)k_pso_tile<NS, NP>, lds);
     if (e != hipSuccess) return e;
     const int groups = (Nmax + TILE_WAVES - 1) / TILE_WAVES;
     long grid = (long)n * groups;
     if (grid > 65536) grid = 65536;
-    hipLaunchKernelGGL(k_pso_tile, dim3((unsigned)grid), dim3(64 * TILE_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win, (int)(lds - fixed), groups);
-    (void)numCUs;
+    hipLaunchKernelGGL((k_pso_tile<NS, NP>), dim3((unsigned)grid), dim3(64 * TILE_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win, getenv("PAIS_TILE_NOTILES") ? 0 : (int)(lds - fixed), groups, stripSteps, dbg);
     return hipGetLastError();
+}
+hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
+                    int strip2, int strip1, int forceNs1, unsigned long long *dbg, hipStream_t stream)
+{
+    // two pixels per lane while the colours of 2 x 32 cameras fit the registers; one pixel per lane beyond.  Strip lengths
+    // swept on the full-size dome (profiles/r03_dome_tile_sweep.txt): 14 / 20 steps; longer strips = fewer barriers, until the
+    // tiles of a strip stop fitting the tile area (cameras then tap global memory)
+    if (Kmax <= 32 && !forceNs1) return pso_tile_launch<2, 16>(sc, states, n, Nmax, Kmax, evalBlocks, win, (strip2 + 1) & ~1, dbg, stream);
+    return pso_tile_launch<1, 32>(sc, states, n, Nmax, Kmax, evalBlocks, win, strip1, dbg, stream);
 }
 template <int P, int NS, bool BYTES, bool ACCR>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,

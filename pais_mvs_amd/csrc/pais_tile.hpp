@@ -13,13 +13,20 @@
 // particle.  The window is cut into strips of whole 64-pixel steps; per strip
 //   1. every wave maps the strip's bounding rectangle through its particle's homographies (one camera per lane) and
 //      merges the image-space bounding boxes per camera with LDS atomics;
-//   2. wave 0 lays the per-camera tiles out in the tile area (exclusive scan of their sizes);
-//   3. all waves copy the tiles' rows global -> LDS with coalesced dword loads (the only global image traffic);
-//   4. every wave walks the strip's steps for its particle: the taps are 2-byte LDS reads at (py - y0) * tw + (px - x0).
-// The colours of a pixel stay in REGISTERS (camera pairs statically unrolled; the odd tail's colours in three small LDS
-// rows), so the workgroup's LDS is the tiles + 2.5 KB of homographies per wave: 8 waves per CU at <= 256 VGPRs.
+//   2. wave 0 lays the per-camera tiles out in one HALF of the tile area (exclusive scan of their sizes);
+//   3. all waves issue the copy of the tiles global -> LDS as LDS-DMA (global_load_lds_dword: no registers, nothing to
+//      wait for) -- the only global image traffic -- and
+//   4. walk the steps of the PREVIOUS strip, whose tiles landed in the other half meanwhile: the taps are byte reads at
+//      (py - y0) * tw + (px - x0).
+// The colours of a pixel stay in REGISTERS (camera pairs statically unrolled, the odd tail's group behind them), so the
+// workgroup's LDS is the tiles + 2.5 KB of homographies per wave: 8 waves per CU at <= 256 VGPRs.  A lane carries TWO
+// window pixels (consecutive steps) through every camera group: the wave-uniform operands of a camera -- its homography
+// and its tile -- are LDS reads (ds_read_b128, 4 LDS cycles each whatever the lanes read), the LDS pipe is shared by the
+// CU's four SIMDs, and with one pixel per lane those reads alone keep it as busy as the VALUs (measured: the first,
+// one-pixel version of this kernel was SLOWER than the global-memory kernels).  The tile of a camera rides in the padding
+// of its homography record, so a camera costs five 16-byte reads per two pixels.
 // Same arithmetic, same operation order and same reduction shape as eval_window<1, false, true, true>: identical bits
-// (tests/test_gpu_parity.py: test_tile_kernel_*).
+// (tests/test_gpu_parity.py: test_dome_radius25_many_cameras).
 //
 // What does NOT go through the tiles, exactly as before:
 //   * a particle whose window corners do not map inside every image with one sign of the denominator (corners_inside):
@@ -28,91 +35,126 @@
 #pragma once
 
 #define TILE_WAVES 8
-#define TILE_MAX_CAMS 32          // cameras tapped per pixel (M <= 32): colours in registers, 16 pairs (or fewer + a tail of <= 3)
-#define TILE_STRIP_STEPS 11       // 64-pixel steps per strip (r = 25: 41 steps -> 4 strips of ~14 window rows)
+#define TILE_MAX_CAMS PAIS_MAX_VIS // cameras of a candidate.  Two instantiations: NS = 2 pixels per lane, 16 camera pairs in registers
+                                  // (M <= 32 tapped cameras); NS = 1, 32 pairs (M <= 64)
+#ifndef TILE_STRIP_STEPS
+#define TILE_STRIP_STEPS 12       // 64-pixel steps per strip, even (r = 25: 41 steps -> strips of 12, 12, 12, 5: ~15 window rows)
+#endif
+#ifndef TILE_DOUBLE_BUFFER
+#define TILE_DOUBLE_BUFFER 0      // 1: two half-size tile areas, the next strip's tiles are staged while this one is walked
+#endif
 
-struct TileCam {                  // one camera's tile of the current strip (LDS, 16 bytes: one ds_read_b128)
-    int32_t base;                 // byte index in the tile area of image pixel (0, 0): off - y0 * tw - x0
-    int32_t tw;                   // row stride of the tile in bytes (multiple of 4); 0: not staged, tap global memory
-    int32_t x0, y0;
-};
+// tile of a camera in a strip, as the taps read it (one ds_read_b64; two sets: the strip being walked / being staged)
+//   base : byte index in the tile area of image pixel (0, 0): off - y0 * tw - x0
+//   tw   : row stride of the tile in bytes (multiple of 4); 0: not staged, the camera is tapped in global memory
+struct TileWord { int32_t base, tw; };
 struct TileBox { int32_t xmin, ymin, xmax, ymax; };
+struct TileLay { int32_t off, tw, x0, y0, th, pad0, pad1, pad2; }; // layout of one camera's tile for the copy (LDS)
 
 __host__ __device__ inline size_t tile_fixed_lds_bytes(int Kmax)
 {
     size_t b = eval_block_bytes(Kmax);                                   // EvalPatch + EvalCam[Kmax], shared by the waves
     b += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE_WAVES;     // homographies, per wave
-    b += sizeof(double) * 64 * 3 * TILE_WAVES;                           // colours of the odd tail (<= 3 cameras), per wave
-    b += (sizeof(TileCam) + sizeof(TileBox)) * (size_t)Kmax + 64;        // tile table, boxes, flags
+    b += (sizeof(TileLay) + sizeof(TileBox) + 2 * sizeof(TileWord)) * (size_t)Kmax + 64; // tile layout, boxes, tile words, flags
     return (b + 15) & ~(size_t)15;
 }
 
-// one camera group of one window pixel from the tiles: the statements of tap_group<G, 1, false, true> with LDS rows
-template <int G>
-__device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam *cams, const TileCam *tcam, const unsigned char *tiles,
-                                               const double *Hbuf, int c0, double x, double y, double *col, double &sum)
+// one camera group of the lane's two window pixels from the tiles: the statements of tap_group<G, 1, false, true> per
+// pixel, with LDS rows
+template <int G, int NS>
+__device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam *cams, const unsigned char *tiles, const TileWord *tword,
+                                               const double *Hbuf, int c0, double *x, double *y, double (*col)[NS], double *sum)
 {
-    asm volatile("" : "+v"(x), "+v"(y));
-    double nx[G], ny[G], w[G], rw[G];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
+    double nx[NS][G], ny[NS][G], w[NS][G], rw[NS][G];
+    int tbase[G], ttw[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
         const double2 ha = H2[0], hb = H2[1], hc = H2[2], hd = H2[3], he = H2[4];
-        w[u] = fma(hd.y, y, fma(hd.x, x, he.x));
-        nx[u] = fma(ha.y, y, fma(ha.x, x, hb.x));
-        ny[u] = fma(hc.x, y, fma(hb.y, x, hc.y));
-    }
-    if (G == 3) {
-        const double p01 = w[0] * w[G > 1 ? 1 : 0];
-        const double r = rcp_cr(p01 * w[G - 1]);
-        rw[G - 1] = r * p01;
-        const double r01 = r * w[G - 1];
-        rw[0] = r01 * w[G > 1 ? 1 : 0];
-        rw[G > 1 ? 1 : 0] = r01 * w[0];
-    } else if (G == 2) {
-        const double r = rcp_cr(w[0] * w[G - 1]);
-        rw[0] = r * w[G - 1];
-        rw[G - 1] = r * w[0];
-    } else {
-        rw[0] = rcp_cr(w[0]);
-    }
-    uint16_t r0[G], r1[G];
-    double bx[G], by[G];
+        TileWord tv;
+        __builtin_memcpy(&tv, __builtin_assume_aligned(&tword[c0 + u], 8), sizeof(tv));
+        tbase[u] = tv.base;
+        ttw[u] = __builtin_amdgcn_readfirstlane(tv.tw);
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-        const int c = c0 + u;
-        TileCam tc;
-        __builtin_memcpy(&tc, __builtin_assume_aligned(&tcam[c], 16), sizeof(tc));
-        const double ix = nx[u] * rw[u], iy = ny[u] * rw[u];
-        const int px = (int)ix, py = (int)iy;
-        bx[u] = __builtin_amdgcn_fract(ix);
-        by[u] = __builtin_amdgcn_fract(iy);
-        const int tw = __builtin_amdgcn_readfirstlane(tc.tw);
-        if (tw != 0) { // wave-uniform: the camera's tile is staged
-            const uint32_t a = (uint32_t)(tc.base + py * tw + px);
-            __builtin_memcpy(&r0[u], tiles + a, 2);
-            __builtin_memcpy(&r1[u], tiles + a + (uint32_t)tw, 2);
-        } else {
-            TapInfo ti;
-            __builtin_memcpy(&ti, __builtin_assume_aligned(&cams[c].imgOff, 16), sizeof(ti));
-            const unsigned char *lvl = sc.imgBlob + ti.imgOff;
-            const uint32_t off = (uint32_t)py * (uint32_t)ti.w + (uint32_t)px;
-            r0[u] = load_row_at<uint16_t>(lvl, off);
-            r1[u] = load_row_at<uint16_t>(lvl, off + (uint32_t)ti.w);
+        for (int q = 0; q < NS; ++q) {
+            w[q][u] = fma(hd.y, y[q], fma(hd.x, x[q], he.x));
+            nx[q][u] = fma(ha.y, y[q], fma(ha.x, x[q], hb.x));
+            ny[q][u] = fma(hc.x, y[q], fma(hb.y, x[q], hc.y));
         }
     }
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-        col[u] = lerp3(r0[u], r1[u], bx[u], by[u]);
-        sum += col[u];
+    for (int q = 0; q < NS; ++q) {
+        if (G == 3) {
+            const double p01 = w[q][0] * w[q][G > 1 ? 1 : 0];
+            const double r = rcp_cr(p01 * w[q][G - 1]);
+            rw[q][G - 1] = r * p01;
+            const double r01 = r * w[q][G - 1];
+            rw[q][0] = r01 * w[q][G > 1 ? 1 : 0];
+            rw[q][G > 1 ? 1 : 0] = r01 * w[q][0];
+        } else if (G == 2) {
+            const double r = rcp_cr(w[q][0] * w[q][G - 1]);
+            rw[q][0] = r * w[q][G - 1];
+            rw[q][G - 1] = r * w[q][0];
+        } else {
+            rw[q][0] = rcp_cr(w[q][0]);
+        }
     }
+    // a row of a tap = two adjacent bytes; from the tiles they are read as BYTES: an unaligned 2-byte LDS read stalls the LDS
+    // pipe (SQ_LDS_UNALIGNED_STALL: 87 % of the LDS cycles of the first version of this kernel)
+    int a0[NS][G], b0[NS][G], a1[NS][G], b1[NS][G];
+    double bx[NS][G], by[NS][G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        int px[NS], py[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const double ix = nx[q][u] * rw[q][u], iy = ny[q][u] * rw[q][u];
+            px[q] = (int)ix;
+            py[q] = (int)iy;
+            bx[q][u] = __builtin_amdgcn_fract(ix);
+            by[q][u] = __builtin_amdgcn_fract(iy);
+        }
+        if (ttw[u] != 0) { // wave-uniform: the camera's tile is staged
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                // (four BYTE reads: the right-hand neighbours go through an opaque copy of the address, or the compiler fuses
+                // each pair into one 2-byte read again)
+                const uint32_t a = (uint32_t)(tbase[u] + py[q] * ttw[u] + px[q]);
+                uint32_t ar = a + 1;
+                asm volatile("" : "+v"(ar));
+                a0[q][u] = tiles[a]; b0[q][u] = tiles[ar];
+                a1[q][u] = tiles[a + (uint32_t)ttw[u]]; b1[q][u] = tiles[ar + (uint32_t)ttw[u]];
+            }
+        } else {
+            TapInfo ti;
+            __builtin_memcpy(&ti, __builtin_assume_aligned(&cams[c0 + u].imgOff, 16), sizeof(ti));
+            const unsigned char *lvl = sc.imgBlob + ti.imgOff;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const uint32_t off = (uint32_t)py[q] * (uint32_t)ti.w + (uint32_t)px[q];
+                const uint16_t r0 = load_row_at<uint16_t>(lvl, off), r1 = load_row_at<uint16_t>(lvl, off + (uint32_t)ti.w);
+                a0[q][u] = r0 & 0xff; b0[q][u] = r0 >> 8;
+                a1[q][u] = r1 & 0xff; b1[q][u] = r1 >> 8;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            col[u][q] = lerp3((double)a0[q][u], (double)(b0[q][u] - a0[q][u]), (double)a1[q][u], (double)(b1[q][u] - a1[q][u]), bx[q][u], by[q][u]);
+            sum[q] += col[u][q];
+        }
 }
 
 // The evaluation launch of many-camera batches.  Grid: candidates x particle groups of TILE_WAVES; workgroup of TILE_WAVES
-// waves.  Writes A.fit[i], or flags the particle pending (A.part[i][0] = 1) for the k_pso_eval2<.., PENDING> launch behind it.
+// waves.  Writes A.fit[i], or flags the particle pending (A.part[i][0] = 1) for the pending-only k_pso_eval2 launch behind it.
+template <int NS, int NP>
 __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                                                 const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
-                                                                int tileBytes, int groups)
+                                                                int tileBytes, int groups, int stripSteps, unsigned long long *dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,11 +162,12 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     size_t o = eval_block_bytes(Kmax);
     double *Hbuf = (double *)(smem + o) + (size_t)wave * Kmax * PAIS_H_STRIDE; o += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE_WAVES;
-    double *tailc = (double *)(smem + o) + (size_t)wave * 3 * 64 + lane;      o += sizeof(double) * 64 * 3 * TILE_WAVES;
-    TileCam *tcam = (TileCam *)(smem + o);                                      o += sizeof(TileCam) * (size_t)Kmax;
+    TileLay *lay = (TileLay *)(smem + o);                                       o += sizeof(TileLay) * (size_t)Kmax;
     TileBox *box = (TileBox *)(smem + o);                                       o += sizeof(TileBox) * (size_t)Kmax;
+    TileWord *twordAll = (TileWord *)(smem + o);                                o += 2 * sizeof(TileWord) * (size_t)Kmax; // [2][Kmax]
     int *flags = (int *)(smem + o);                                             // [0]: some particle of the group walks the tiles
     unsigned char *tiles = smem + tile_fixed_lds_bytes(Kmax);
+    const int halfBytes = TILE_DOUBLE_BUFFER ? ((tileBytes / 2) & ~15) : tileBytes; // (two halves: the strip being walked, the strip being staged)
     const size_t SB = pso_state_bytes(Nmax);
     const int WS = win_stride(sc);
     const int S = sc.cfg.patchSize, S2 = S * S;
@@ -189,6 +232,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                 if (state == 1) A.fit[i] = DBL_MAX;
                 A.part[i][0] = (state == 2) ? 1.0 : 0.0;
                 if (state == 0) flags[0] = 1;
+                if (dbg) atomicAdd(&dbg[state], 1ULL); // [0] particles through the tiles, [1] DBL_MAX, [2] pending
             }
         }
         __syncthreads();
@@ -203,11 +247,13 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
         const int nPairs = (M >= 2) ? ((M & 1) ? (M - 3) / 2 : M / 2) : 0; // cameras 0 .. 2 nPairs - 1 in pairs, then a tail of 3, 1 or 0
         const int tail0 = 2 * nPairs, nTail = M - tail0;
 
-        for (int s0 = 0; s0 < nSteps; s0 += TILE_STRIP_STEPS) {
-            const int s1 = min(s0 + TILE_STRIP_STEPS, nSteps);
+        // stage(strip, half): boxes -> layout -> LDS-DMA of the strip's tiles into `half`.  Two workgroup barriers inside;
+        // every wave calls it with the same arguments.
+        auto stage = [&](int s0, int half) {
+            const int s1 = min(s0 + stripSteps, nSteps);
             // ---- 1. bounding boxes of the strip's rectangle (full window rows ya .. yb) in every camera
             for (int q = threadIdx.x; q < M; q += 64 * TILE_WAVES) box[q] = TileBox{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
-            __syncthreads();
+            __syncthreads(); // (also: every wave has finished walking the strip that used `half` before)
             if (state == 0) {
                 const int ya = (64 * s0) / S, yb = (min(64 * s1, S2) - 1) / S;
                 for (int cc = lane; cc < M; cc += 64) {
@@ -236,7 +282,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                         const int lw = cams[cc].w, lh = cams[cc].h;
                         x0 = max(box[cc].xmin - 1, 0); y0 = max(box[cc].ymin - 1, 0);
                         const int x1 = min(box[cc].xmax + 2, lw - 1), y1 = min(box[cc].ymax + 2, lh - 1);
-                        tw = ((x1 - x0 + 1) + 3) & ~3;
+                        tw = max(((x1 - x0 + 1) + 3) & ~3, 8); // (>= 2 dwords: the copy's division by tw / 4 is a multiplication by
+                                                                //  2^32 / (tw / 4), which a one-dword row would overflow -- a single
+                                                                //  window row CAN map onto one image column)
                         th = y1 - y0 + 1;
                     }
                     int sz = tw * th, incl = sz;
@@ -245,90 +293,152 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                         const int up = __shfl_up(incl, m, 64);
                         incl += (lane >= m) ? up : 0;
                     }
-                    const int off = carry + incl - sz;
-                    const bool fits = sz > 0 && off + sz <= tileBytes;
+                    const int off = half * halfBytes + carry + incl - sz;
+                    const bool fits = sz > 0 && carry + incl <= halfBytes;
                     if (cc < M) {
-                        TileCam tc;
-                        tc.tw = fits ? tw : 0;
-                        tc.base = fits ? (off - y0 * tw - x0) : 0;
-                        tc.x0 = fits ? x0 : 0;
-                        tc.y0 = fits ? (y0 | (th << 16)) : 0; // rows of the tile in the upper half (levels are < 65536 high)
-                        tcam[cc] = tc;
+                        if (dbg && sz > 0) atomicAdd(&dbg[fits ? 3 : 4], 1ULL); // [3] tiles staged, [4] cameras left in global memory
+                        if (dbg && fits) atomicAdd(&dbg[5], (unsigned long long)sz); // [5] bytes staged
+                        TileLay tl;
+                        tl.off = off; tl.tw = fits ? tw : 0; tl.x0 = x0; tl.y0 = y0; tl.th = fits ? th : 0; tl.pad0 = tl.pad1 = tl.pad2 = 0;
+                        lay[cc] = tl;
+                        twordAll[half * Kmax + cc] = TileWord{fits ? (off - y0 * tw - x0) : 0, fits ? tw : 0};
                     }
                     carry += __shfl(incl, 63, 64);
                 }
             }
+            // the tiles that are about to be walked (staged by the PREVIOUS call) have landed in LDS: this wave's part once
+            // its own LDS-DMA count is down to zero, everybody's after the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            // ---- 3. copy: rows dealt to half waves, dwords of a row to their lanes
-            for (int cc = 0; cc < M; ++cc) {
-                const TileCam tc = tcam[cc];
-                if (tc.tw == 0) continue;
-                const int th = tc.y0 >> 16, y0 = tc.y0 & 0xffff, twd = tc.tw >> 2;
-                const unsigned char *lvl = sc.imgBlob + cams[cc].imgOff;
+            // ---- 3. copy as LDS-DMA: cameras dealt to the waves; a tile is th * tw / 4 consecutive dwords of LDS, dword j of it
+            // is image byte (y0 + j / twd) * w + x0 + 4 (j % twd); one instruction moves 64 of them
+            int inFlight = 0; // LDS-DMA instructions of this wave not waited for yet: the counter behind s_waitcnt vmcnt has 6 bits
+            for (int cc = wave; cc < M; cc += TILE_WAVES) {
+                const TileLay tl = lay[cc];
+                if (tl.tw == 0) continue;
+                const uint32_t twd = (uint32_t)tl.tw >> 2, J = twd * (uint32_t)tl.th;
+                const int need = (int)((J + 63) >> 6);
+                if (inFlight + need > 48) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    inFlight = 0;
+                }
+                inFlight += need;
+                const uint32_t magic = 0xFFFFFFFFu / twd + 1; // j / twd == umulhi(j, magic) for j * twd < 2^32
+                const unsigned char *lvl = sc.imgBlob + cams[cc].imgOff + (size_t)(uint32_t)tl.y0 * (uint32_t)cams[cc].w + (uint32_t)tl.x0;
                 const uint32_t lw = (uint32_t)cams[cc].w;
-                unsigned char *dst = tiles + (tc.base + y0 * tc.tw + tc.x0);
-                for (int r = 2 * wave + (lane >> 5); r < th; r += 2 * TILE_WAVES) {
-                    const unsigned char *srow = lvl + (size_t)(uint32_t)(y0 + r) * lw + (uint32_t)tc.x0;
-                    for (int dw = lane & 31; dw < twd; dw += 32) {
-                        uint32_t v;
-                        __builtin_memcpy(&v, srow + 4 * dw, 4);
-                        *(uint32_t *)(dst + r * tc.tw + 4 * dw) = v;
+                const unsigned ldsTile = (unsigned)(uintptr_t)(tiles + tl.off);
+                for (uint32_t j0 = 0; j0 < J; j0 += 64) {
+                    const uint32_t j = j0 + lane;
+                    if (j < J) {
+                        const uint32_t row = __umulhi(j, magic), d = j - row * twd;
+                        const unsigned char *gsrc = lvl + (size_t)row * lw + 4 * d;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ldsTile + 4 * j0);
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
                     }
                 }
             }
-            __syncthreads();
-            // ---- 4. the strip's steps for this wave's particle
+        };
+
+        const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0;
+        if (TILE_DOUBLE_BUFFER) stage(0, 0);
+        unsigned long long tWalk = 0;
+        int sIdx = 0;
+        for (int s0 = 0; s0 < nSteps; s0 += stripSteps, ++sIdx) {
+            const int s1 = min(s0 + stripSteps, nSteps);
+            const int half = TILE_DOUBLE_BUFFER ? (sIdx & 1) : 0;
+            if (TILE_DOUBLE_BUFFER && s1 < nSteps) {
+                stage(s1, half ^ 1); // (its second barrier is also the one behind which this strip's tiles are complete)
+            } else {
+                if (!TILE_DOUBLE_BUFFER) stage(s0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            const TileWord *tword = twordAll + half * Kmax;
+            const unsigned long long tc3 = dbg ? __builtin_readcyclecounter() : 0;
+            // ---- 4. the strip's steps for this wave's particle, NS steps (NS pixels per lane) per trip
             if (state == 0) {
-                int kpix = 64 * s0 + lane;
+                const int kpix = 64 * s0 + lane;
                 int yw = kpix / S, xw = kpix - yw * S;
                 const int qA = 64 / S, rA = 64 - qA * S;
-                for (int st = s0; st < s1; ++st) {
-                    const WinPix wp = wbase[64 * st + lane]; // (the padding lanes of the last step are masked entries)
-                    const double x = a0 + (double)xw, y = b0 + (double)yw;
-                    xw += rA; yw += qA;
-                    yw += (xw >= S) ? 1 : 0;
-                    xw -= (xw >= S) ? S : 0;
-                    double sum = hasRef ? wp.refCol : 0.0;
-                    double col[TILE_MAX_CAMS];
+                for (int st = s0; st < s1; st += NS) {
+                    double x[NS], y[NS], sum[NS];
+                    WinPix wp[NS];
 #pragma unroll
-                    for (int u = 0; u < TILE_MAX_CAMS / 2; ++u) {
-                        if (u < nPairs) tile_tap_group<2>(sc, cams, tcam, tiles, Hbuf, 2 * u, x, y, &col[2 * u], sum);
-                        else { col[2 * u] = 0; col[2 * u + 1] = 0; }
+                    for (int q = 0; q < NS; ++q) {
+                        const int stq = st + q;
+                        // (a step past the window -- uniform, skipped below -- re-reads the last entry; the padding lanes of
+                        // the last step are masked entries)
+                        wp[q] = wbase[stq < nSteps ? (64 * stq + lane) : (S2 - 1)];
+                        x[q] = a0 + (double)xw;
+                        y[q] = b0 + (double)yw;
+                        xw += rA; yw += qA;
+                        yw += (xw >= S) ? 1 : 0;
+                        xw -= (xw >= S) ? S : 0;
+                        sum[q] = hasRef ? wp[q].refCol : 0.0;
                     }
-                    if (nTail == 3) {
-                        double t3[3];
-                        tile_tap_group<3>(sc, cams, tcam, tiles, Hbuf, tail0, x, y, t3, sum);
-                        tailc[0] = t3[0]; tailc[64] = t3[1]; tailc[128] = t3[2];
-                    } else if (nTail == 1) {
-                        double t1[1];
-                        tile_tap_group<1>(sc, cams, tcam, tiles, Hbuf, tail0, x, y, t1, sum);
-                        tailc[0] = t1[0];
-                    }
-                    const double mean = sum * invK;
-                    double sad = hasRef ? fabs(wp.refCol - mean) : 0.0;
+                    // lanes without a pixel (padding of the last step, the step past the window) tap the strip's first pixel:
+                    // an address inside the tiles
+                    {
+                        const double xs = a0 + (double)((64 * s0) % S), ys = b0 + (double)((64 * s0) / S);
 #pragma unroll
-                    for (int u = 0; u < TILE_MAX_CAMS / 2; ++u) {
-                        if (u < nPairs) {
-                            sad += fabs(col[2 * u] - mean);
-                            sad += fabs(col[2 * u + 1] - mean);
+                        for (int q = 0; q < NS; ++q) {
+                            const bool nopix = 64 * (st + q) + lane >= S2 || st + q >= s1;
+                            x[q] = nopix ? xs : x[q];
+                            y[q] = nopix ? ys : y[q];
                         }
                     }
-                    for (int q = 0; q < nTail; ++q) sad += fabs(tailc[64 * q] - mean);
-                    const bool act = wp.wStat >= 0.0;
-                    const double sadq = sad * invK;
-                    double weight = wp.wStat;
-                    if (useDiff) weight *= det_exp_poly(-(sadq * sadq) * invDiffW);
-                    const int ga = st & 3; // canonical sub-accumulator of the step (uniform)
+                    double col[2 * NP][NS], t3[3][NS];
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) t3[0][q] = t3[1][q] = t3[2][q] = 0;
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        if (u < nPairs) tile_tap_group<2, NS>(sc, cams, tiles, tword, Hbuf, 2 * u, x, y, &col[2 * u], sum);
+                        else {
+#pragma unroll
+                            for (int q = 0; q < NS; ++q) col[2 * u][q] = col[2 * u + 1][q] = 0;
+                        }
+                    }
+                    if (nTail == 3) tile_tap_group<3, NS>(sc, cams, tiles, tword, Hbuf, tail0, x, y, t3, sum);
+                    else if (nTail == 1) tile_tap_group<1, NS>(sc, cams, tiles, tword, Hbuf, tail0, x, y, t3, sum);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        if (st + q >= s1) break; // uniform: the strip (the window) has no such step
+                        const double mean = sum[q] * invK;
+                        double sad = hasRef ? fabs(wp[q].refCol - mean) : 0.0;
+#pragma unroll
+                        for (int u = 0; u < NP; ++u) {
+                            if (u < nPairs) {
+                                sad += fabs(col[2 * u][q] - mean);
+                                sad += fabs(col[2 * u + 1][q] - mean);
+                            }
+                        }
+                        if (nTail >= 1) sad += fabs(t3[0][q] - mean);
+                        if (nTail == 3) {
+                            sad += fabs(t3[1][q] - mean);
+                            sad += fabs(t3[2][q] - mean);
+                        }
+                        const bool act = wp[q].wStat >= 0.0;
+                        const double sadq = sad * invK;
+                        double weight = wp[q].wStat;
+                        if (useDiff) weight *= det_exp_poly(-(sadq * sadq) * invDiffW);
+                        const int ga = (st + q) & 3; // canonical sub-accumulator of the step (uniform)
 #define PAIS_TACC(a)                                          \
     {                                                         \
         accW[a] = act ? (accW[a] + weight) : accW[a];         \
         accF[a] = act ? fma(weight, sadq, accF[a]) : accF[a]; \
     }
-                    if (ga == 0) PAIS_TACC(0) else if (ga == 1) PAIS_TACC(1) else if (ga == 2) PAIS_TACC(2) else PAIS_TACC(3)
+                        if (ga == 0) PAIS_TACC(0) else if (ga == 1) PAIS_TACC(1) else if (ga == 2) PAIS_TACC(2) else PAIS_TACC(3)
 #undef PAIS_TACC
+                    }
                 }
             }
-            // (the barrier at the head of the next strip / task orders these reads before the tiles are overwritten)
+            if (dbg) tWalk += __builtin_readcyclecounter() - tc3;
+        }
+        if (dbg && threadIdx.x == 0) {
+            atomicAdd(&dbg[6], __builtin_readcyclecounter() - tc0 - tWalk); // staging (boxes, layout, DMA issue, barriers) ...
+            atomicAdd(&dbg[9], tWalk);                                      // ... and the walks of wave 0
         }
         if (state == 0) {
             double f4[4], w4[4];

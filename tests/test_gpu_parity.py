@@ -447,8 +447,8 @@ def test_bench_refuses_a_rank_count_it_cannot_run():
     assert r.returncode != 0 and "n_gpus" not in r.stdout
 
 
-@pytest.mark.parametrize("tile", ["tile kernel for every batch", "one wave per evaluation"])
-def test_dome_radius25_many_cameras(dome_small, monkeypatch, tile):
+@pytest.mark.parametrize("tile", ["tile kernel for every batch", "tile kernel, one pixel per lane, one-row last strip", "one wave per evaluation"])
+def test_dome_radius25_many_cameras(dome_small, monkeypatch, capfd, tile):
     """Config-4-like parameters: patchRadius 25 (S^2 = 2601), reduceNormalRange 4, all weights, many visible
     cameras per patch.  Cost + seeds + a few expansion rounds against the oracle, bit for bit -- through the LDS-tile
     kernel of many-camera batches (pais_tile.hpp: footprints staged in LDS, colours in registers; forced for every
@@ -456,6 +456,12 @@ def test_dome_radius25_many_cameras(dome_small, monkeypatch, tile):
     from oracle import po
     if tile.startswith("tile"):
         monkeypatch.setenv("PAIS_TILE_ABOVE", "1")
+        if "one pixel" in tile:
+            # the instantiation of batches of more than 32 cameras, with strips of 4 steps: the last strip is step 40 alone, a
+            # single window row (whose footprint may be one image column wide)
+            monkeypatch.setenv("PAIS_TILE_FORCE_NS1", "1")
+            monkeypatch.setenv("PAIS_TILE_STRIP1", "4")
+        monkeypatch.setenv("PAIS_TILE_VERIFY", "1")     # every particle ALSO through k_pso_eval2: a mismatch is printed (and fails below)
     else:
         monkeypatch.setenv("PAIS_TILE", "0")
     from pais_mvs_amd.config import readme_config
@@ -501,6 +507,7 @@ def test_dome_radius25_many_cameras(dome_small, monkeypatch, tile):
     for i, (a, b) in enumerate(zip(got, want)):
         assert a == b, (i, a, b)
     m.close()
+    assert "tile verify" not in capfd.readouterr().out   # (PAIS_TILE_VERIFY prints every particle whose two values differ)
 
 
 def test_edge_cases(pawn_small):
