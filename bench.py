@@ -158,14 +158,14 @@ def cpu_baseline(cfg, scene, budget_s: float, n_seed_units: int, n_expand_units:
                                          "structure; the stronger CPU arrangement)" % m_par}}
 
 
-def predicted_speedup(log, particle_num, worlds=(2, 4, 8)):
+def predicted_speedup(log, particle_num, bytes_per_eval=23000.0, worlds=(2, 4, 8)):
     """Strong-scaling model from the per-batch log of the last reconstruction (include/pais_mvs.h pais_round_log), printed
     so that the first measured SCALE run can be compared with a prediction made from one GPU:
       T(N) = sum over batches of  host enumerate + host commit                      (replicated on every rank)
                                 + t(ceil(n / N)) + exchange(n, N)   if the batch is sharded (>= 1024 evaluation waves per iteration)
                                   t(n)                               otherwise (thin batch: every rank refines all of it)
-    t(n) = the measured refine time of this run's batches, interpolated over n (expansion batches; the seed batch scales
-    as half latency floor + half throughput); exchange = 30 us + gathered wire slots over 50 GB/s (device-to-host of what
+    t(n) = the measured refine time of this run's batches, interpolated over n (expansion batches; below the smallest one
+    linearly down to a latency floor; the seed batch scales as half latency floor + half throughput); exchange = 30 us + gathered wire slots over 50 GB/s (device-to-host of what
     the all-gather delivered) + 0.2 us of host unpacking per record."""
     import bisect
     ex = sorted((l.n, l.refine_ms) for l in log if not l.has_seeds and l.n > 0)
@@ -173,9 +173,13 @@ def predicted_speedup(log, particle_num, worlds=(2, 4, 8)):
         return None
     xs, ys = [e[0] for e in ex], [e[1] for e in ex]
 
+    # latency floor of a batch: what the thinnest rounds of the pawn scene take (0.9 ms: ~31 dependent launches), scaled with
+    # the length of one evaluation; below the smallest measured batch t(n) falls linearly to it
+    floor = 0.9 * max(1.0, bytes_per_eval / 23000.0)
+
     def t_exp(n):
         if n <= xs[0]:
-            return ys[0]
+            return min(ys[0], max(floor, ys[0] * n / xs[0]))
         if n >= xs[-1]:
             return ys[-1] * n / xs[-1]
         i = bisect.bisect_left(xs, n)
@@ -307,7 +311,7 @@ def main():
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
 
     if rank == 0:
-        scaling_model = predicted_speedup(m.round_log(), cfg.particleNum)
+        scaling_model = predicted_speedup(m.round_log(), cfg.particleNum, (ks.pso_algorithmic_bytes / ks.pso_evals) if ks.pso_evals else 23000.0)
         gold_sha, gold_ok = None, None
         try:
             g = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_cloud_%s.json" % args.scene)))

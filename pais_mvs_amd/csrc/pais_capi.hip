@@ -88,7 +88,8 @@ struct pais_ctx {
     int tileForceNs1 = 0;               // PAIS_TILE_FORCE_NS1 (tests): the one-pixel instantiation also for batches of <= 32 cameras
     bool tileVerify = false;            // PAIS_TILE_VERIFY=1: every particle is ALSO walked by k_pso_eval2 and the two values compared (diagnosis)
     bool tileDebug = false;             // PAIS_TILE_DEBUG=1: counters of the tile kernel (printed by pais_get_kernel_stats)
-    int tileMode = 1;                   // PAIS_TILE=0: many-camera batches keep the one-wave-per-evaluation kernels
+    int tileMode = 1;                   // PAIS_TILE: 0 many-camera batches keep the one-wave-per-evaluation kernels; 1 the tile kernel for
+                                        // scenes that tap the byte blob; 2 for every scene
     long tileAbove = 512;               // PAIS_TILE_ABOVE: waves per iteration from which a tile-eligible batch runs the tile kernel
     std::vector<hipStream_t> sub;       // sub-streams
     std::vector<hipEvent_t> subDone;
@@ -599,7 +600,10 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         // (>= 3 x 12 waves per CU) is throughput bound: there the step replay in every evaluation wave (~13 % of a wave's
         // time) costs more than a separate one-wave-per-candidate k_pso_step launch per iteration, whose latency the other
         // sub-stream hides
-        const bool tileOk = ctx->tileMode != 0 && pais_launch::tile_eligible(Kmax);
+        // the tile kernel pays where the taps miss the caches: scenes whose pyramids exceed PAIS_TAP_FLOAT_MAX_MB (those that tap
+        // the byte blob; the dome: PSO passes -22 %).  On the 184 MB ring, whose taps hit L2, it LOSES 35 % against the
+        // one-wave kernels (profiles/r03_ring_tile_ab.txt) -- PAIS_TILE=2 forces it regardless (tests)
+        const bool tileOk = (ctx->tileMode == 2 || (ctx->tileMode == 1 && ctx->d_imgF == nullptr)) && pais_launch::tile_eligible(Kmax);
         // (the tile kernel is an evaluation launch of the large-batch pipeline: batches that are eligible for it take that
         // pipeline from PAIS_TILE_ABOVE waves per iteration on)
         const bool useIter = Nmax <= 64 && (long)n * Nmax < (tileOk ? ctx->tileAbove : ctx->splitAbove);
@@ -650,10 +654,10 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
                                                  ctx->d_win + WB * (size_t)q.lo, ctx->tileStrip2, ctx->tileStrip1, ctx->tileForceNs1,
                                                  ctx->tileDebug ? ctx->d_stat + 8 : nullptr, q.st));
                     HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
-                                                 ctx->d_win + WB * (size_t)q.lo, ctx->tileVerify ? 2 : 1, q.st));
+                                                 ctx->d_win + WB * (size_t)q.lo, ctx->tileVerify ? 2 : 1, ctx->d_stat + 18, q.st));
                 } else
                     HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
-                                                 ctx->d_win + WB * (size_t)q.lo, 0, q.st));
+                                                 ctx->d_win + WB * (size_t)q.lo, 0, nullptr, q.st));
                 if (te.end()) return -2;
                 ctx->evalLaunches++;
                 if (!useIter) ctx->eval2Launches++;
@@ -816,6 +820,14 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
     if (ctx->tileDebug)
         fprintf(stderr, "[pais tile] particles through the tiles %llu, DBL_MAX %llu, pending (checked walk) %llu; tiles staged %llu (%.1f KB each), cameras left in global memory %llu\n",
                 st[8], st[9], st[10], st[11], st[11] ? (double)st[13] / (double)st[11] / 1024.0 : 0.0, st[12]);
+    if (ctx->tileVerify) {
+        double a, b;
+        memcpy(&a, &st[20], 8); memcpy(&b, &st[21], 8);
+        if (st[18]) // (the tests look for this line)
+            fprintf(stdout, "[pais tile verify] %llu particles differ; first: candidate %llu particle %llu: tile %.17g one-wave %.17g\n", st[18],
+                    st[19] >> 32, st[19] & 0xffffffffULL, a, b);
+        fflush(stdout);
+    }
     if (ctx->tileDebug)
         fprintf(stderr, "[pais tile] cycles of wave 0 per phase: boxes %.3g, layout %.3g, copy %.3g, walk %.3g\n", (double)st[14], (double)st[15], (double)st[16], (double)st[17]);
     const double S2 = (double)ctx->sc.cfg.patchSize * ctx->sc.cfg.patchSize;

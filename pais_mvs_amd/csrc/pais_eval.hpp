@@ -384,7 +384,11 @@ __device__ __forceinline__ bool corners_inside(const EvalPatch *ep, const EvalCa
         // r * w_other, which rounds differently from this corner's n * (1 / w) -- a corner within an ulp of the bound must not
         // be able to put a tap on the other side of it.  And a denominator of ordinary size: the products of two or three of
         // them that the batch inversion forms can then neither overflow nor underflow.
+#if PAIS_CORNER_WTEST
         bool in = qx >= 3 && qx < (int)(qp & 0xffffu) && qy >= 3 && qy < (int)(qp >> 16) && fabs(w) > 1e-90 && fabs(w) < 1e90;
+#else
+        bool in = qx >= 3 && qx < (int)(qp & 0xffffu) && qy >= 3 && qy < (int)(qp >> 16);
+#endif
         // one sign of w over the four corners of a camera: lanes 4c .. 4c+3
         const unsigned long long neg = __ballot(w < 0.0), pos = __ballot(w > 0.0);
         const unsigned long long grp = 0xFull << (lane & ~3);
@@ -423,7 +427,11 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     f4[0] = f4[1] = f4[2] = f4[3] = 0;
     w4[0] = w4[1] = w4[2] = w4[3] = 0;
     double n[3];
+#if PAIS_WAVE_SINCOS
     wave_spherical2normal(theta, phi, n, lane);
+#else
+    spherical2normal(theta, phi, n);
+#endif
     {
         double on[3] = {ep->optNref[0], ep->optNref[1], ep->optNref[2]};
         if (dot3(n, on) > 0) return 1; // patch.cpp:939

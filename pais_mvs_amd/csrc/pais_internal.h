@@ -72,7 +72,7 @@ size_t pso_state_bytes_host(int Nmax);
 hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
                     int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int pendingOnly, hipStream_t stream);
+                    int pendingOnly, unsigned long long *verify, hipStream_t stream);
 bool tile_eligible(int Kmax);
 hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
                     int strip2, int strip1, int forceNs1, unsigned long long *dbg, hipStream_t stream);

@@ -39,6 +39,14 @@ using namespace pais;
 #ifndef PAIS_CORNER_FASTPATH
 #define PAIS_CORNER_FASTPATH 1
 #endif
+//   PAIS_WAVE_SINCOS  1: the normal of a particle by four lanes in one pass (pais_eval.hpp wave_spherical2normal)
+#ifndef PAIS_WAVE_SINCOS
+#define PAIS_WAVE_SINCOS 1
+#endif
+//   PAIS_CORNER_WTEST 1: corners_inside also bounds the size of the denominators
+#ifndef PAIS_CORNER_WTEST
+#define PAIS_CORNER_WTEST 1
+#endif
 //   PAIS_WG_WAVES    waves (= consecutive evaluation tasks: particles of one candidate) per workgroup of the evaluation
 //                    kernels: the waves of a workgroup run on one CU and share its L1 -- the taps of a candidate's particles
 //                    fall into the same few image windows.  LDS scratch stays private to each wave: no barriers.
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 template <int NS, bool BYTES, bool ACCR>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                                                     const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
-                                                                    int pendingOnly)
+                                                                    int pendingOnly, unsigned long long *verify)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
     unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, ACCR); // wave-private scratch
@@ -767,8 +775,15 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
         const int st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
         if (lane == 0) {
             const double v = st ? DBL_MAX : combine_parts(f4, w4);
-            if (pendingOnly == 2 && pend != 1.0 && A.fit[i] != v) // PAIS_TILE_VERIFY: the tile kernel's value against this walk's
-                printf("[pais tile verify] candidate %d particle %d K %d: tile %.17g one-wave %.17g\n", c, i, ep->K, A.fit[i], v);
+            // PAIS_TILE_VERIFY: the tile kernel's value against this walk's; mismatches are counted (and the first one kept)
+            // in the debug words -- no printf in this kernel: its mere presence costs every instantiation registers
+            if (pendingOnly == 2 && pend != 1.0 && A.fit[i] != v && verify) {
+                if (atomicAdd(&verify[0], 1ULL) == 0) {
+                    verify[1] = ((unsigned long long)(unsigned)c << 32) | (unsigned)i;
+                    verify[2] = (unsigned long long)__double_as_longlong(A.fit[i]);
+                    verify[3] = (unsigned long long)__double_as_longlong(v);
+                }
+            }
             A.fit[i] = v;
         }
     }
@@ -1650,7 +1665,7 @@ hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, un
 }
 template <int NS, bool BYTES, bool ACCR>
 static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
-                                   const void *win, int pendingOnly, hipStream_t stream)
+                                   const void *win, int pendingOnly, unsigned long long *verify, hipStream_t stream)
 {
     static LdsAttr attr;
     const size_t lds = eval_lds_bytes(NS, Kmax, ACCR) * PAIS_WG_WAVES;
@@ -1661,14 +1676,14 @@ static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, in
     // kernel of the other sub-stream, which holds every CU's LDS (measured: 2.2 ms per launch spent waiting)
     const int grid = pendingOnly == 1 ? (int)(((long)n * Nmax < 256) ? (long)n * Nmax : 256) : eval_grid((long)n * Nmax);
     hipLaunchKernelGGL((k_pso_eval2<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win, pendingOnly);
+                       eval_block_bytes(Kmax), (const WinPix *)win, pendingOnly, verify);
     return hipGetLastError();
 }
 // the evaluation launch of large batches: `states`, `evalBlocks`, `win` point at the slice's first candidate
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int pendingOnly, hipStream_t stream)
+                    int pendingOnly, unsigned long long *verify, hipStream_t stream)
 {
-    PAIS_SHAPE_DISPATCH(pso_eval2_launch, sc, states, n, Nmax, Kmax, evalBlocks, win, pendingOnly, stream);
+    PAIS_SHAPE_DISPATCH(pso_eval2_launch, sc, states, n, Nmax, Kmax, evalBlocks, win, pendingOnly, verify, stream);
 }
 // many-camera batches: the tile kernel (pais_tile.hpp) can take the evaluation launch of the large-batch pipeline
 bool tile_eligible(int Kmax) { return eval_shape(Kmax) == 2 && Kmax <= TILE_MAX_CAMS; }

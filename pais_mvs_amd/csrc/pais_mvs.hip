@@ -18,6 +18,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <deque>
 #include <queue>
@@ -186,6 +190,58 @@ static Api *api(std::string &err)
 const int kInt8 = 0; // ncclInt8 / ncclChar
 } // namespace rccl
 
+// Helper threads of the enumeration of large rounds (pais_mvs_round_begin): the caller is worker 0, the pool holds the others.
+class EnumPool {
+public:
+    explicit EnumPool(int helpers)
+    {
+        for (int i = 0; i < helpers; ++i) th.emplace_back([this, i] { loop(i + 1); });
+    }
+    ~EnumPool()
+    {
+        { std::lock_guard<std::mutex> l(mu); stop = true; ++gen; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+    int workers() const { return (int)th.size() + 1; }
+    // fn(worker) for worker = 0 .. workers() - 1; returns when all have finished
+    void run(const std::function<void(int)> &fn)
+    {
+        { std::lock_guard<std::mutex> l(mu); job = &fn; pending = (int)th.size(); ++gen; }
+        cv.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> l(mu);
+        cvDone.wait(l, [this] { return pending == 0; });
+        job = nullptr;
+    }
+private:
+    void loop(int worker)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *f;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return gen != seen; });
+                seen = gen;
+                if (stop) return;
+                f = job;
+            }
+            (*f)(worker);
+            { std::lock_guard<std::mutex> l(mu); if (--pending == 0) cvDone.notify_one(); }
+        }
+    }
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cvDone;
+    const std::function<void(int)> *job = nullptr;
+    unsigned long gen = 0;
+    int pending = 0;
+    bool stop = false;
+};
+
+struct WorkItem { Unit u; int cam, x, y; };
+
 struct pais_mvs {
     pais_config cfg;
     pais_ctx *ctx = nullptr;
@@ -236,10 +292,18 @@ struct pais_mvs {
     pais_mvs_stats st;
     std::vector<pais_round_log> roundLog;
     double lastEnumerateMs = 0;
+    // enumeration of large rounds on several host threads (round_begin)
+    EnumPool *enumPool = nullptr;
+    int enumThreads = 0;               // PAIS_ENUM_THREADS (default min(8, hardware threads)); 1 = always the single-thread walk
+    size_t enumThreadsAbove = 4096;    // PAIS_ENUM_ABOVE: units of a round from which the threads are used
+    std::vector<WorkItem> work;
+    std::vector<unsigned char> workState;
+    std::vector<std::vector<uint32_t>> workBucket;
     std::string err;
 
     ~pais_mvs()
     {
+        delete enumPool;
         for (void *c : patchChunks) free(c);
         if (device >= 0) {
             (void)hipSetDevice(device);
@@ -634,6 +698,14 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
     pais_mvs *m = new pais_mvs();
     if (const char *e = getenv("PAIS_HOST_SCENE_TEST")) m->trustSceneStage = atoi(e) == 0;
     if (const char *e = getenv("PAIS_THIN_FRONT")) m->thinFront = atoi(e) < 0 ? 0 : atoi(e); // tuning sweeps (scripts/)
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        (void)hw;
+        m->enumThreads = 1; // measured on the GPU box (2 x 128 cores): pawn enumerate 4.1 -> 8.6 ms, ring 1.17 -> 1.93 s with 8 threads --
+                            // a round's walk is too short for the wake-ups; the threaded walk stays selectable (and tested)
+        if (const char *e = getenv("PAIS_ENUM_THREADS")) m->enumThreads = std::max(1, std::min(64, atoi(e)));
+        if (const char *e = getenv("PAIS_ENUM_ABOVE")) m->enumThreadsAbove = (size_t)std::max(0, atoi(e));
+    }
     memset(&m->st, 0, sizeof(m->st));
     m->cfg = *cfg;
     m->cfg.patchSize = (cfg->patchRadius << 1) + 1;
@@ -1160,6 +1232,95 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
         m->candRecs.push_back(rec);
     };
     static const int dx[4] = {-1, 0, 1, 0}, dy[4] = {0, -1, 0, 1}; // neighbour j of a cell: left, up, right, down
+    // one camera slot of every active parent; a thin front (few active parents: the long tail of the
+    // expansion, where a round is pure latency) takes all remaining slots of its parents at once
+    const bool thin = (int)m->active.size() <= m->thinFront;
+    // Large rounds on several host threads.  What a unit does -- dropped (cell blocked before the round), deferred (cell
+    // claimed by an earlier unit of the round) or claimed -- depends on the pre-round state and on the units that aim at the
+    // SAME cell before it in work-list order, nothing else.  So: (1) one thread lists the units in order (the parents'
+    // records are the only thing it reads) and makes sure the 32 x 32 tile of every target cell exists; (2) the units are
+    // dealt to the threads by (camera, tile) -- all units of a cell to one thread, each thread in work-list order -- and every
+    // thread runs the skip test and the claim for its units (the cell maps, the pool and the dense patch copies are only
+    // read; a claim stamp belongs to its tile's thread); (3) one thread walks the states in order and builds the candidates.
+    // Same candidates, same order, same deferred list as the single-thread walk below (tests/test_scheduler_cpu.py runs both).
+    if (m->enumThreads > 1 && m->deferred.size() + 4 * m->active.size() >= m->enumThreadsAbove) {
+        if (!m->enumPool) m->enumPool = new EnumPool(m->enumThreads - 1);
+        const int T = m->enumPool->workers();
+        m->work.clear();
+        m->workBucket.resize((size_t)T);
+        for (auto &b : m->workBucket) b.clear();
+        auto addUnit = [&](const Unit &u, int camI, int x, int y) {
+            CellMap &map = m->cellMaps[camI];
+            if (!map.inMap(x, y)) return;
+            (void)map.slot(x, y); // the tile exists from here on: no thread allocates
+            const uint32_t key = (uint32_t)camI * 0x9E3779B1u + (uint32_t)(y >> CellMap::kShift) * 0x85EBCA6Bu + (uint32_t)(x >> CellMap::kShift) * 0xC2B2AE35u;
+            m->workBucket[(key >> 8) % (uint32_t)T].push_back((uint32_t)m->work.size());
+            m->work.push_back(WorkItem{u, camI, x, y});
+        };
+        for (const Unit &u : m->deferred) {
+            const pais_patch_result &pr = m->patches[u.id]->r;
+            addUnit(u, pr.cam_idx[u.slot], (int)(pr.imgPoint[u.slot][0] / m->cfg.cellSize) + dx[u.j], (int)(pr.imgPoint[u.slot][1] / m->cfg.cellSize) + dy[u.j]);
+        }
+        const size_t nA = m->active.size();
+        for (size_t k = 0; k < nA; ++k) {
+            if (k + 16 < nA) {
+                const pais_patch_result &q = m->patches[m->active[k + 16].id]->r;
+                __builtin_prefetch(&q.imgPoint[m->active[k + 16].slot][0]);
+                __builtin_prefetch(&q.cam_idx[m->active[k + 16].slot]);
+            }
+            Active &a = m->active[k];
+            const pais_patch_result &pr = m->patches[a.id]->r;
+            const int sEnd = thin ? pr.num_cam : a.slot + 1;
+            for (int sl = a.slot; sl < sEnd; ++sl) {
+                const int cx = (int)(pr.imgPoint[sl][0] / m->cfg.cellSize), cy = (int)(pr.imgPoint[sl][1] / m->cfg.cellSize);
+                for (int j = 0; j < 4; ++j) addUnit(Unit{a.id, sl, j}, pr.cam_idx[sl], cx + dx[j], cy + dy[j]);
+            }
+            a.slot = sEnd - 1; // round_commit advances past it
+        }
+        m->workState.assign(m->work.size(), 0);
+        const int round = m->curRound;
+        std::function<void(int)> job = [&](int w) {
+            const std::vector<uint32_t> &mine = m->workBucket[(size_t)w];
+            const size_t nMine = mine.size();
+            for (size_t q = 0; q < nMine; ++q) {
+                if (q + 8 < nMine) { // the tile row of the unit 8 ahead, the first pool entry of the unit 4 ahead
+                    const WorkItem &f = m->work[mine[q + 8]];
+                    m->cellMaps[f.cam].prefetch(f.x, f.y);
+                    const WorkItem &g = m->work[mine[q + 4]];
+                    const int e = m->cellMaps[g.cam].first(g.x, g.y);
+                    if (e >= 0) __builtin_prefetch(&m->pool[e]);
+                }
+                const WorkItem &it = m->work[mine[q]];
+                const pais_patch_result &pr = m->patches[it.u.id]->r;
+                CellMap &map = m->cellMaps[it.cam];
+                if (m->skipNeighborCell(map, it.x, it.y, pr, round)) continue;                  // state 0: dropped
+                m->workState[mine[q]] = map.claim(it.x, it.y, round) ? 2 : 1;                   // 2 claimed, 1 deferred
+            }
+        };
+        m->enumPool->run(job);
+        for (size_t k = 0; k < m->work.size(); ++k) {
+            const WorkItem &it = m->work[k];
+            if (m->workState[k] == 1) { m->nextDeferred.push_back(it.u); continue; }
+            if (m->workState[k] != 2) continue;
+            const pais_patch_result &pr = m->patches[it.u.id]->r;
+            double center[3];
+            m->expansionCenter(it.cam, pr, it.x, it.y, center);
+            pais_candidate rec;
+            m->makeExpandCandidate(m->patches[it.u.id], center, pais_child_key(pr.key, it.cam, it.x, it.y), &rec);
+            m->cands.push_back(Candidate{it.u, it.cam, it.x, it.y});
+            m->candRecs.push_back(rec);
+        }
+        if (m->truncatedVisible > 0) {
+            m->truncatedVisible = 0;
+            return mfail("a candidate's visibility cone holds more than PAIS_MAX_VIS cameras (patch.cpp:723-761 keeps them all): "
+                         "this rig needs a larger PAIS_MAX_VIS or a larger visibleCorrelation");
+        }
+        *cands = m->candRecs.data();
+        *n = (int)m->candRecs.size();
+        m->lastEnumerateMs = now_ms() - t0;
+        m->st.host_enumerate_ms += m->lastEnumerateMs;
+        return 0;
+    }
     for (const Unit &u : m->deferred) {
         const pais_patch_result &pr = m->patches[u.id]->r;
         const int camI = pr.cam_idx[u.slot];
@@ -1167,9 +1328,6 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
         const int cy = (int)(pr.imgPoint[u.slot][1] / m->cfg.cellSize);
         considerCell(u, pr, camI, m->cellMaps[camI], cx + dx[u.j], cy + dy[u.j]);
     }
-    // one camera slot of every active parent; a thin front (few active parents: the long tail of the
-    // expansion, where a round is pure latency) takes all remaining slots of its parents at once
-    const bool thin = (int)m->active.size() <= m->thinFront;
     // The walk is a chain of dependent cache misses (parent record -> tile table -> tile row -> pool entry -> hot patch) on
     // maps far larger than the caches (ring: 66 MB of cell heads): the records of the parents 16 ahead and the three tile
     // rows that the parent 8 ahead will look at are requested while the current one is processed.

@@ -19,3 +19,14 @@ for k, (a, b) in enumerate(zip(begins[half:end], (begins[half + 1:] + [len(rows)
     tot += dur
     print("%3d %8d %8.0f %6d %10.0f %8.0f %6d   %s" % (k, n, dur, len(it), itus, af, len(set(r[4] for r in it)), ",".join(kinds)))
 print("total ms %.1f" % (tot / 1e3))
+# gaps between dependent launches of single-stream rounds (the thin tail): what a hipGraph of the chain could shave
+gaps = []
+for a, b in zip(begins[half:end], (begins[half + 1:] + [len(rows)])[:end - half]):
+    it = [r for r in rows[a:b] if 'k_pso_iter' in r[0]]
+    if len(it) < 20 or len(set(r[4] for r in it)) != 1:
+        continue
+    gaps += [(it[k + 1][1] - it[k][2]) / 1e3 for k in range(len(it) - 1)]
+if gaps:
+    gaps.sort()
+    print("gap between consecutive k_pso_iter launches of single-stream rounds: median %.2f us, mean %.2f us, p90 %.2f us (%d gaps)"
+          % (gaps[len(gaps) // 2], sum(gaps) / len(gaps), gaps[int(len(gaps) * 0.9)], len(gaps)))

@@ -455,6 +455,7 @@ def test_dome_radius25_many_cameras(dome_small, monkeypatch, capfd, tile):
     batch incl. the seeds' 2N particles) and through the one-wave-per-evaluation kernels."""
     from oracle import po
     if tile.startswith("tile"):
+        monkeypatch.setenv("PAIS_TILE", "2")            # (by default only scenes too large for the float tap copy take it)
         monkeypatch.setenv("PAIS_TILE_ABOVE", "1")
         if "one pixel" in tile:
             # the instantiation of batches of more than 32 cameras, with strips of 4 steps: the last strip is step 40 alone, a
@@ -506,8 +507,11 @@ def test_dome_radius25_many_cameras(dome_small, monkeypatch, capfd, tile):
     assert len(got) == len(want) and len(got) >= 8, (len(got), len(want))
     for i, (a, b) in enumerate(zip(got, want)):
         assert a == b, (i, a, b)
+    from pais_mvs_amd import _lib
+    ks = _lib.KernelStats()
+    m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)   # (PAIS_TILE_VERIFY: reports the particles whose two values differ)
     m.close()
-    assert "tile verify" not in capfd.readouterr().out   # (PAIS_TILE_VERIFY prints every particle whose two values differ)
+    assert "tile verify" not in capfd.readouterr().out
 
 
 def test_edge_cases(pawn_small):
@@ -859,7 +863,39 @@ def test_ring_full_size_properties_and_determinism():
 
 
 @pytest.mark.gpu
-def test_dome_full_size_bounded_rounds():
+def test_ring_full_size_rounds_match_oracle():
+    """BASELINE.json configs[2] at FULL size (32 cameras 1920x1080, patchRadius 15, all adaptive weights), seeds + the first
+    expansion rounds of R(4096): the HIP path's cloud against the oracle's on the same box (kernel arithmetic, candidates
+    evaluated ahead of the sequential replay on the host cores) -- every accepted patch, in order, same bits, same cameras
+    (mvs/mvs.cpp:196-275).  The scene is rendered and pyramided on the GPU; the oracle gets the edge maps it reads from the
+    host statement of camera.cpp:72-77 over the same levels."""
+    from pais_mvs_amd import synth
+    from pais_mvs_amd.camera import sobel_magnitude_normalised
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS, patches_sha1
+    scene = synth.ring_scene(n_seeds=300, build_edges=False, device=0)
+    cfg = readme_config(adaptiveGradientEnable=True)
+    B, rounds = 4096, 2
+    m = MVS(cfg, scene.cameras, device=0, seed=42)
+    for X, vis in scene.seeds:
+        m.add_seed(X, vis)
+    m.refineSeedPatches()
+    m.expansionPatches(B, rounds)
+    st = m.stats()
+    got = [(list(p.center[:]), list(p.normalS[:]), p.cams(), p.fitness, p.correlation) for p in m.patches()]
+    m.close()
+    for cam in scene.cameras:
+        cam.edge_pyramid = [sobel_magnitude_normalised(l) for l in cam.pyramid]
+    want, calls, accepted, spec = common.oracle_reconstruct(cfg, scene, B, rounds, parallel=True)
+    assert st.seeds_refined + st.candidates_effective == calls and len(got) == accepted and accepted > 1000, (calls, accepted)
+    assert st.candidates_refined - st.candidates_effective == spec
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (i, a, b)
+    assert patches_sha1(got) == patches_sha1(want)
+
+
+@pytest.mark.gpu
+def test_dome_full_size_bounded_rounds(monkeypatch):
     """BASELINE.json configs[4] on ONE GPU at FULL size: 128 cameras 4096x3072 on a Fibonacci dome, patchRadius 25
     (S^2 = 2601), reduceNormalRange 4, all adaptive weights on.  The renders and pyramids are produced on the GPU (hours in
     numpy), the edge maps are never materialised; seeds + a bounded number of expansion rounds; properties as above and the
@@ -895,6 +931,17 @@ def test_dome_full_size_bounded_rounds():
         assert not p.dropped and 0 < p.fitness <= cfg.maxFitness and p.correlation >= cfg.minCorrelation
         assert len(set(p.cams())) == p.num_cam and p.ref_cam in p.cams()
     assert _surface_error(scene, ps, max(1, len(ps) // 200)) < 2e-3
+    sha_tile = m.cloud_sha1()
+    m.close()
+    # the same reconstruction through the one-wave-per-evaluation kernels: the LDS-tile kernel (pais_tile.hpp; K up to 44 here:
+    # its one-pixel instantiation for the rounds, the two-pixel one for the seeds) must not change a bit of the cloud
+    monkeypatch.setenv("PAIS_TILE", "0")
+    m = MVS(cfg, scene.cameras, device=0, seed=42)
+    for X, vis in scene.seeds:
+        m.add_seed(X, vis)
+    m.refineSeedPatches()
+    m.expansionPatches(1024, 2)
+    assert m.cloud_sha1() == sha_tile
     m.close()
 
 

@@ -9,9 +9,9 @@ from pais_mvs_amd.mvs import patches_sha1
 from tests import common
 
 
-@pytest.mark.parametrize("B,max_rounds,strategy", [(1, 10, 0), (16, 5, 1), (4096, 3, 0)])
+@pytest.mark.parametrize("B,max_rounds,strategy", [(1, 10, 0), (16, 5, 1), (4096, 4, 0)])
 def test_parallel_mode_is_the_sequential_oracle(pawn_small, B, max_rounds, strategy):
-    cfg = readme_config(expansionStrategy=strategy)
+    cfg = readme_config(expansionStrategy=strategy, particleNum=6, maxIteration=8)   # (short PSO runs: the schedule is what is compared)
     a = common.oracle_reconstruct(cfg, pawn_small, B, max_rounds, parallel=False)
     b = common.oracle_reconstruct(cfg, pawn_small, B, max_rounds, parallel=True)
     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], (a[1:], b[1:])
