@@ -84,7 +84,7 @@ struct pais_ctx {
     int evalParts = 0;                  // waves per cost evaluation in k_pso_iter (1, 2, 4); 0 = chosen per slice
     double partFill = 0.75;             // ... such that parts * waves <= partFill * numCUs * 16 (= the 3 waves per SIMD the kernels' registers allow)
     int psoStreams = 2;
-    int tileStrip2 = 14, tileStrip1 = 20; // 64-pixel steps per strip of the two instantiations (PAIS_TILE_STRIP2 / PAIS_TILE_STRIP1)
+    int tileStrip2 = 14, tileStrip1 = 24; // 64-pixel steps per strip of the two instantiations (PAIS_TILE_STRIP2 / PAIS_TILE_STRIP1)
     int tileForceNs1 = 0;               // PAIS_TILE_FORCE_NS1 (tests): the one-pixel instantiation also for batches of <= 32 cameras
     bool tileVerify = false;            // PAIS_TILE_VERIFY=1: every particle is ALSO walked by k_pso_eval2 and the two values compared (diagnosis)
     bool tileDebug = false;             // PAIS_TILE_DEBUG=1: counters of the tile kernel (printed by pais_get_kernel_stats)

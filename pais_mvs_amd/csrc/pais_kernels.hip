@@ -1706,7 +1706,7 @@ hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, 
                     int strip2, int strip1, int forceNs1, unsigned long long *dbg, hipStream_t stream)
 {
     // two pixels per lane while the colours of 2 x 32 cameras fit the registers; one pixel per lane beyond.  Strip lengths
-    // swept on the full-size dome (profiles/r03_dome_tile_sweep.txt): 14 / 20 steps; longer strips = fewer barriers, until the
+    // swept on the full-size dome (profiles/r03_dome_tile_sweep.txt): 14 / 24 steps; longer strips = fewer barriers, until the
     // tiles of a strip stop fitting the tile area (cameras then tap global memory)
     if (Kmax <= 32 && !forceNs1) return pso_tile_launch<2, 16>(sc, states, n, Nmax, Kmax, evalBlocks, win, (strip2 + 1) & ~1, dbg, stream);
     return pso_tile_launch<1, 32>(sc, states, n, Nmax, Kmax, evalBlocks, win, strip1, dbg, stream);

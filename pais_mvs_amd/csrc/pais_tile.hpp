@@ -13,18 +13,18 @@
 // particle.  The window is cut into strips of whole 64-pixel steps; per strip
 //   1. every wave maps the strip's bounding rectangle through its particle's homographies (one camera per lane) and
 //      merges the image-space bounding boxes per camera with LDS atomics;
-//   2. wave 0 lays the per-camera tiles out in one HALF of the tile area (exclusive scan of their sizes);
-//   3. all waves issue the copy of the tiles global -> LDS as LDS-DMA (global_load_lds_dword: no registers, nothing to
-//      wait for) -- the only global image traffic -- and
-//   4. walk the steps of the PREVIOUS strip, whose tiles landed in the other half meanwhile: the taps are byte reads at
-//      (py - y0) * tw + (px - x0).
+//   2. every wave lays the per-camera tiles out in the tile area (camera c in lane c: an exclusive scan of the sizes; the
+//      same layout in every wave, so no second barrier) and notes each camera's tile in its homography record;
+//   3. the waves issue the copy of the tiles global -> LDS as LDS-DMA (global_load_lds_dword: no registers; every
+//      instruction of the strip in flight at once) -- the only global image traffic; one wait + barrier; then
+//   4. every wave walks the strip's steps for its particle: the taps are byte reads at (py - y0) * tw + (px - x0).
 // The colours of a pixel stay in REGISTERS (camera pairs statically unrolled, the odd tail's group behind them), so the
 // workgroup's LDS is the tiles + 2.5 KB of homographies per wave: 8 waves per CU at <= 256 VGPRs.  A lane carries TWO
 // window pixels (consecutive steps) through every camera group: the wave-uniform operands of a camera -- its homography
 // and its tile -- are LDS reads (ds_read_b128, 4 LDS cycles each whatever the lanes read), the LDS pipe is shared by the
-// CU's four SIMDs, and with one pixel per lane those reads alone keep it as busy as the VALUs (measured: the first,
-// one-pixel version of this kernel was SLOWER than the global-memory kernels).  The tile of a camera rides in the padding
-// of its homography record, so a camera costs five 16-byte reads per two pixels.
+// CU's four SIMDs, and those reads keep it as busy as the VALUs: the LDS pipe, not the VALU, bounds the walk (measured:
+// dropping ONE 8-byte wave-uniform read per camera and pixel -- the tile word, now in the padding of the homography record
+// -- shortened the walk by 15 %).  A camera costs five 16-byte reads per two pixels (one pixel beyond 32 cameras).
 // Same arithmetic, same operation order and same reduction shape as eval_window<1, false, true, true>: identical bits
 // (tests/test_gpu_parity.py: test_dome_radius25_many_cameras).
 //
@@ -40,29 +40,26 @@
 #ifndef TILE_STRIP_STEPS
 #define TILE_STRIP_STEPS 12       // 64-pixel steps per strip, even (r = 25: 41 steps -> strips of 12, 12, 12, 5: ~15 window rows)
 #endif
-#ifndef TILE_DOUBLE_BUFFER
-#define TILE_DOUBLE_BUFFER 0      // 1: two half-size tile areas, the next strip's tiles are staged while this one is walked
-#endif
+#define TILE_DOUBLE_BUFFER 0      // (a variant with two half-size tile areas -- the next strip staged while this one is walked -- was
+                                  //  measured slower, see the header; the half / halfBytes arithmetic of the layout is what is left of it)
 
-// tile of a camera in a strip, as the taps read it (one ds_read_b64; two sets: the strip being walked / being staged)
+// tile of a camera in a strip, as the taps read it: two ints in the 10th (padding) double of the camera's homography record
 //   base : byte index in the tile area of image pixel (0, 0): off - y0 * tw - x0
 //   tw   : row stride of the tile in bytes (multiple of 4); 0: not staged, the camera is tapped in global memory
-struct TileWord { int32_t base, tw; };
 struct TileBox { int32_t xmin, ymin, xmax, ymax; };
-struct TileLay { int32_t off, tw, x0, y0, th, pad0, pad1, pad2; }; // layout of one camera's tile for the copy (LDS)
 
 __host__ __device__ inline size_t tile_fixed_lds_bytes(int Kmax)
 {
     size_t b = eval_block_bytes(Kmax);                                   // EvalPatch + EvalCam[Kmax], shared by the waves
     b += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE_WAVES;     // homographies, per wave
-    b += (sizeof(TileLay) + sizeof(TileBox) + 2 * sizeof(TileWord)) * (size_t)Kmax + 64; // tile layout, boxes, tile words, flags
+    b += 2 * sizeof(TileBox) * (size_t)Kmax + 64;                        // boxes (two sets), flags
     return (b + 15) & ~(size_t)15;
 }
 
 // one camera group of the lane's two window pixels from the tiles: the statements of tap_group<G, 1, false, true> per
 // pixel, with LDS rows
 template <int G, int NS>
-__device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam *cams, const unsigned char *tiles, const TileWord *tword,
+__device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam *cams, const unsigned char *tiles,
                                                const double *Hbuf, int c0, double *x, double *y, double (*col)[NS], double *sum)
 {
 #pragma unroll
@@ -73,10 +70,9 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
     for (int u = 0; u < G; ++u) {
         const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
         const double2 ha = H2[0], hb = H2[1], hc = H2[2], hd = H2[3], he = H2[4];
-        TileWord tv;
-        __builtin_memcpy(&tv, __builtin_assume_aligned(&tword[c0 + u], 8), sizeof(tv));
-        tbase[u] = tv.base;
-        ttw[u] = __builtin_amdgcn_readfirstlane(tv.tw);
+        // (the camera's tile rides in the padding of its homography record: no read of its own)
+        tbase[u] = __double2loint(he.y);
+        ttw[u] = __builtin_amdgcn_readfirstlane(__double2hiint(he.y));
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             w[q][u] = fma(hd.y, y[q], fma(hd.x, x[q], he.x));
@@ -162,9 +158,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     size_t o = eval_block_bytes(Kmax);
     double *Hbuf = (double *)(smem + o) + (size_t)wave * Kmax * PAIS_H_STRIDE; o += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE_WAVES;
-    TileLay *lay = (TileLay *)(smem + o);                                       o += sizeof(TileLay) * (size_t)Kmax;
-    TileBox *box = (TileBox *)(smem + o);                                       o += sizeof(TileBox) * (size_t)Kmax;
-    TileWord *twordAll = (TileWord *)(smem + o);                                o += 2 * sizeof(TileWord) * (size_t)Kmax; // [2][Kmax]
+    TileBox *boxAll = (TileBox *)(smem + o);                                    o += 2 * sizeof(TileBox) * (size_t)Kmax; // [2][Kmax]
     int *flags = (int *)(smem + o);                                             // [0]: some particle of the group walks the tiles
     unsigned char *tiles = smem + tile_fixed_lds_bytes(Kmax);
     const int halfBytes = TILE_DOUBLE_BUFFER ? ((tileBytes / 2) & ~15) : tileBytes; // (two halves: the strip being walked, the strip being staged)
@@ -189,6 +183,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
             const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
             uint64_t *dst = (uint64_t *)smem;
             for (int q = threadIdx.x; q < nwMax; q += 64 * TILE_WAVES) dst[q] = src[q];
+            for (int q = threadIdx.x; q < 2 * Kmax; q += 64 * TILE_WAVES) boxAll[q] = TileBox{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
             if (threadIdx.x == 0) flags[0] = 0;
         }
         __syncthreads();
@@ -249,11 +244,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
 
         // stage(strip, half): boxes -> layout -> LDS-DMA of the strip's tiles into `half`.  Two workgroup barriers inside;
         // every wave calls it with the same arguments.
-        auto stage = [&](int s0, int half) {
+        auto stage = [&](int s0, int half, int par) {
             const int s1 = min(s0 + stripSteps, nSteps);
+            TileBox *box = boxAll + par * Kmax; // (two sets, used alternately: this strip's was cleared during the previous strip's layout)
             // ---- 1. bounding boxes of the strip's rectangle (full window rows ya .. yb) in every camera
-            for (int q = threadIdx.x; q < M; q += 64 * TILE_WAVES) box[q] = TileBox{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
-            __syncthreads(); // (also: every wave has finished walking the strip that used `half` before)
             if (state == 0) {
                 const int ya = (64 * s0) / S, yb = (min(64 * s1, S2) - 1) / S;
                 for (int cc = lane; cc < M; cc += 64) {
@@ -271,52 +265,47 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                     atomicMax(&box[cc].xmax, xmax); atomicMax(&box[cc].ymax, ymax);
                 }
             }
-            __syncthreads();
-            // ---- 2. layout: one pixel of margin against the rounding of the corner quotients, +1 for the bilinear neighbour
-            if (wave == 0) {
-                int carry = 0;
-                for (int cb = 0; cb < M; cb += 64) {
-                    const int cc = cb + lane;
-                    int x0 = 0, y0 = 0, tw = 0, th = 0;
-                    if (cc < M && box[cc].xmax >= box[cc].xmin) {
-                        const int lw = cams[cc].w, lh = cams[cc].h;
-                        x0 = max(box[cc].xmin - 1, 0); y0 = max(box[cc].ymin - 1, 0);
-                        const int x1 = min(box[cc].xmax + 2, lw - 1), y1 = min(box[cc].ymax + 2, lh - 1);
-                        tw = max(((x1 - x0 + 1) + 3) & ~3, 8); // (>= 2 dwords: the copy's division by tw / 4 is a multiplication by
-                                                                //  2^32 / (tw / 4), which a one-dword row would overflow -- a single
-                                                                //  window row CAN map onto one image column)
-                        th = y1 - y0 + 1;
-                    }
-                    int sz = tw * th, incl = sz;
+            __syncthreads(); // the boxes are complete -- and every wave has finished walking the strip before this one
+            // ---- 2. layout, by EVERY wave alike (camera cc in lane cc, M <= 64; no second barrier for it): one pixel of margin
+            // against the rounding of the corner quotients, +1 for the bilinear neighbour
+            int x0 = 0, y0 = 0, tw = 0, th = 0;
+            if (lane < M && box[lane].xmax >= box[lane].xmin) {
+                const int lw = cams[lane].w, lh = cams[lane].h;
+                x0 = max(box[lane].xmin - 1, 0); y0 = max(box[lane].ymin - 1, 0);
+                const int x1 = min(box[lane].xmax + 2, lw - 1), y1 = min(box[lane].ymax + 2, lh - 1);
+                tw = max(((x1 - x0 + 1) + 3) & ~3, 8); // (>= 2 dwords: the copy's division by tw / 4 is a multiplication by
+                                                        //  2^32 / (tw / 4), which a one-dword row would overflow -- a single
+                                                        //  window row CAN map onto one image column)
+                th = y1 - y0 + 1;
+            }
+            const int sz = tw * th;
+            int incl = sz;
 #pragma unroll
-                    for (int m = 1; m < 64; m <<= 1) {
-                        const int up = __shfl_up(incl, m, 64);
-                        incl += (lane >= m) ? up : 0;
-                    }
-                    const int off = half * halfBytes + carry + incl - sz;
-                    const bool fits = sz > 0 && carry + incl <= halfBytes;
-                    if (cc < M) {
-                        if (dbg && sz > 0) atomicAdd(&dbg[fits ? 3 : 4], 1ULL); // [3] tiles staged, [4] cameras left in global memory
-                        if (dbg && fits) atomicAdd(&dbg[5], (unsigned long long)sz); // [5] bytes staged
-                        TileLay tl;
-                        tl.off = off; tl.tw = fits ? tw : 0; tl.x0 = x0; tl.y0 = y0; tl.th = fits ? th : 0; tl.pad0 = tl.pad1 = tl.pad2 = 0;
-                        lay[cc] = tl;
-                        twordAll[half * Kmax + cc] = TileWord{fits ? (off - y0 * tw - x0) : 0, fits ? tw : 0};
-                    }
-                    carry += __shfl(incl, 63, 64);
+            for (int m = 1; m < 64; m <<= 1) {
+                const int up = __shfl_up(incl, m, 64);
+                incl += (lane >= m) ? up : 0;
+            }
+            const int off = half * halfBytes + incl - sz;
+            const bool fits = sz > 0 && incl <= halfBytes;
+            if (!fits) { tw = 0; th = 0; }
+            if (lane < M) {
+                // the tile of camera `lane` as the taps read it -- base = byte index in the tile area of image pixel (0, 0), row
+                // stride (0: not staged) -- into the padding double of this wave's homography record of the camera
+                Hbuf[lane * PAIS_H_STRIDE + 9] = __hiloint2double(tw, fits ? (off - y0 * tw - x0) : 0);
+                if (wave == 0) {
+                    boxAll[(par ^ 1) * Kmax + lane] = TileBox{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
+                    if (dbg && sz > 0) atomicAdd(&dbg[fits ? 3 : 4], 1ULL); // [3] tiles staged, [4] cameras left in global memory
+                    if (dbg && fits) atomicAdd(&dbg[5], (unsigned long long)sz); // [5] bytes staged
                 }
             }
-            // the tiles that are about to be walked (staged by the PREVIOUS call) have landed in LDS: this wave's part once
-            // its own LDS-DMA count is down to zero, everybody's after the barrier
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
             // ---- 3. copy as LDS-DMA: cameras dealt to the waves; a tile is th * tw / 4 consecutive dwords of LDS, dword j of it
             // is image byte (y0 + j / twd) * w + x0 + 4 (j % twd); one instruction moves 64 of them
-            int inFlight = 0; // LDS-DMA instructions of this wave not waited for yet: the counter behind s_waitcnt vmcnt has 6 bits
+            int inFlight = 0; // LDS-DMA instructions of this wave not waited for yet (the counter behind s_waitcnt vmcnt has 6 bits)
             for (int cc = wave; cc < M; cc += TILE_WAVES) {
-                const TileLay tl = lay[cc];
-                if (tl.tw == 0) continue;
-                const uint32_t twd = (uint32_t)tl.tw >> 2, J = twd * (uint32_t)tl.th;
+                const int ctw = __shfl(tw, cc, 64), cth = __shfl(th, cc, 64);
+                const int cx0 = __shfl(x0, cc, 64), cy0 = __shfl(y0, cc, 64), coff = __shfl(off, cc, 64);
+                if (ctw == 0) continue;
+                const uint32_t twd = (uint32_t)ctw >> 2, J = twd * (uint32_t)cth;
                 const int need = (int)((J + 63) >> 6);
                 if (inFlight + need > 48) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -324,9 +313,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                 }
                 inFlight += need;
                 const uint32_t magic = 0xFFFFFFFFu / twd + 1; // j / twd == umulhi(j, magic) for j * twd < 2^32
-                const unsigned char *lvl = sc.imgBlob + cams[cc].imgOff + (size_t)(uint32_t)tl.y0 * (uint32_t)cams[cc].w + (uint32_t)tl.x0;
+                const unsigned char *lvl = sc.imgBlob + cams[cc].imgOff + (size_t)(uint32_t)cy0 * (uint32_t)cams[cc].w + (uint32_t)cx0;
                 const uint32_t lw = (uint32_t)cams[cc].w;
-                const unsigned ldsTile = (unsigned)(uintptr_t)(tiles + tl.off);
+                const unsigned ldsTile = (unsigned)(uintptr_t)(tiles + coff);
                 for (uint32_t j0 = 0; j0 < J; j0 += 64) {
                     const uint32_t j = j0 + lane;
                     if (j < J) {
@@ -342,20 +331,14 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
         };
 
         const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0;
-        if (TILE_DOUBLE_BUFFER) stage(0, 0);
         unsigned long long tWalk = 0;
         int sIdx = 0;
         for (int s0 = 0; s0 < nSteps; s0 += stripSteps, ++sIdx) {
             const int s1 = min(s0 + stripSteps, nSteps);
-            const int half = TILE_DOUBLE_BUFFER ? (sIdx & 1) : 0;
-            if (TILE_DOUBLE_BUFFER && s1 < nSteps) {
-                stage(s1, half ^ 1); // (its second barrier is also the one behind which this strip's tiles are complete)
-            } else {
-                if (!TILE_DOUBLE_BUFFER) stage(s0, 0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-            const TileWord *tword = twordAll + half * Kmax;
+            const int half = 0;
+            stage(s0, 0, sIdx & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's LDS-DMA has landed ...
+            __syncthreads();                                  // ... everybody's has
             const unsigned long long tc3 = dbg ? __builtin_readcyclecounter() : 0;
             // ---- 4. the strip's steps for this wave's particle, NS steps (NS pixels per lane) per trip
             if (state == 0) {
@@ -394,14 +377,14 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                     for (int q = 0; q < NS; ++q) t3[0][q] = t3[1][q] = t3[2][q] = 0;
 #pragma unroll
                     for (int u = 0; u < NP; ++u) {
-                        if (u < nPairs) tile_tap_group<2, NS>(sc, cams, tiles, tword, Hbuf, 2 * u, x, y, &col[2 * u], sum);
+                        if (u < nPairs) tile_tap_group<2, NS>(sc, cams, tiles, Hbuf, 2 * u, x, y, &col[2 * u], sum);
                         else {
 #pragma unroll
                             for (int q = 0; q < NS; ++q) col[2 * u][q] = col[2 * u + 1][q] = 0;
                         }
                     }
-                    if (nTail == 3) tile_tap_group<3, NS>(sc, cams, tiles, tword, Hbuf, tail0, x, y, t3, sum);
-                    else if (nTail == 1) tile_tap_group<1, NS>(sc, cams, tiles, tword, Hbuf, tail0, x, y, t3, sum);
+                    if (nTail == 3) tile_tap_group<3, NS>(sc, cams, tiles, Hbuf, tail0, x, y, t3, sum);
+                    else if (nTail == 1) tile_tap_group<1, NS>(sc, cams, tiles, Hbuf, tail0, x, y, t3, sum);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) {
                         if (st + q >= s1) break; // uniform: the strip (the window) has no such step

@@ -5,9 +5,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', round(d['value'],1), round(d['ms_per_step'],1), d['config']['cloud_sha1'][:10], {k:round(v,1) for k,v in d['kernel_ms_per_step'].items()})"
   grep "pais tile" gpurun_out/r03e/err_$name.txt | tail -2
 }
-run s1_14 PAIS_TILE_STRIP1=14
-run s1_16 PAIS_TILE_STRIP1=16
-run s1_21 PAIS_TILE_STRIP1=21
-run s1_14_s2_14 PAIS_TILE_STRIP1=14 PAIS_TILE_STRIP2=14
-run s1_14_s2_10 PAIS_TILE_STRIP1=14 PAIS_TILE_STRIP2=10
-run s1_8 PAIS_TILE_STRIP1=8
+run default X=1
+
+
+run s1_24 PAIS_TILE_STRIP1=24
