@@ -222,6 +222,7 @@ static int ctx_init(pais_ctx *ctx, const pais_config *cfg, int num_cams, const p
     }
     // pyramid levels straight from the caller's buffers into HBM (rows repacked to stride == width); the padding between
     // levels is zero
+    if (imgBytes >= ((size_t)1 << 40)) return fail_msg("pyramids of 2^40 bytes or more (a level's start is packed into 40 bits next to its homography)");
     HIPCHK(hipMalloc(&ctx->d_img, imgBytes));
     HIPCHK(hipMemsetAsync(ctx->d_img, 0, imgBytes, ctx->stream));
     for (int c = 0; c < num_cams; ++c) {

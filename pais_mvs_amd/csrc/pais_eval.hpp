@@ -243,12 +243,16 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
     constexpr uint32_t kElem = Tap<BYTES>::kElem;
     const unsigned char *base[G];
     uint32_t off[NS][G], cwv[G];
+    uint64_t tapWord[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         // five 16-byte LDS reads per homography (half the LDS cycles of nine 8-byte ones)
         const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
         const double2 ha = H2[0], hb = H2[1], hc = H2[2], hd = H2[3], he = H2[4];
         const double h0 = ha.x, h1 = ha.y, h2 = hb.x, h3 = hb.y, h4 = hc.x, h5 = hc.y, h6 = hd.x, h7 = hd.y, h8 = he.x;
+        // the 10th double of the record: where the camera's level starts in the blob (40 bits) and its row length (24 bits),
+        // written next to the homography (eval_fitness_parts) -- the taps need no read of the EvalCam record
+        tapWord[u] = (uint64_t)__double_as_longlong(he.y);
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             w[q][u] = fma(h7, y[q], fma(h6, x[q], h8));
@@ -278,14 +282,17 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         const int c = c0 + u;
-        TapInfo ti;
-        __builtin_memcpy(&ti, __builtin_assume_aligned(&cams[c].imgOff, 16), sizeof(ti));
-        const int qxmax = (int)(ti.qpack & 0xffffu), qymax = (int)(ti.qpack >> 16);
-        const uint32_t cw = (uint32_t)ti.w;
+        int qxmax = 0, qymax = 0;
+        if (CHECK) { // (the checked walk also reads the tap bounds of the camera)
+            const uint32_t qp = cams[c].qpack;
+            qxmax = (int)(qp & 0xffffu);
+            qymax = (int)(qp >> 16);
+        }
+        uint32_t cw;
         {   // wave-uniform: keep the base in SGPRs so that the taps are global_load ... v_off, s[base] (no 64-bit VALU address math)
-            const uint64_t io = ti.imgOff;
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)io), hi = __builtin_amdgcn_readfirstlane((uint32_t)(io >> 32));
-            base[u] = Tap<BYTES>::blob(sc) + (((uint64_t)hi << 32) | lo) * kElem;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)tapWord[u]), hi = __builtin_amdgcn_readfirstlane((uint32_t)(tapWord[u] >> 32));
+            base[u] = Tap<BYTES>::blob(sc) + (((uint64_t)(hi & 0xffu) << 32) | lo) * kElem;
+            cw = hi >> 8;
         }
         cwv[u] = cw;
 #pragma unroll
@@ -461,6 +468,8 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
                 mul33(Mc, invH, H);
             }
             for (int i = 0; i < 9; ++i) Hbuf[c * PAIS_H_STRIDE + i] = H[i];
+            // (pais_ctx_create bounds the blob: levels start below 2^40 elements and are at most 65535 pixels wide)
+            Hbuf[c * PAIS_H_STRIDE + 9] = __longlong_as_double((long long)((cams[c].imgOff & 0xFFFFFFFFFFull) | ((uint64_t)(uint32_t)cams[c].w << 40)));
         }
     }
     wave_sync();
