@@ -1,3 +1,4 @@
+# strip-length sweep of the tile kernel on the full-size dome: bash scripts/dome_tile_sweep.sh on the GPU box -> profiles/r03_dome_tile_sweep.txt
 mkdir -p gpurun_out/r03e
 run() { name=$1; shift
   env "$@" PAIS_TILE_DEBUG=1 timeout 600 python bench.py --scene dome --steps 1 --warmup 0 --max-rounds 3 --parents-per-round 1024 --no-cpu-baseline 2>gpurun_out/r03e/err_$name.txt | python -c "

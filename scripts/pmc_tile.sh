@@ -1,3 +1,4 @@
+# PMC passes over the tile kernel (dome, seeds + 2 rounds): bash scripts/pmc_tile.sh on the GPU box -> profiles/r03_pmc_tile.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc_tile; rm -rf $out; mkdir -p $out
 i=0
