@@ -996,3 +996,42 @@ def test_scene_half_of_runtime_filtering_on_the_device(pawn_small, monkeypatch):
         seen.add(r.stage)
     assert 5 in seen
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_wire_slots_packed_on_the_device_are_the_host_statement(pawn_small):
+    """include/pais_hip.h "wire format of a record": k_pack_records (what a rank sends in the per-round exchange) against the
+    host statement pais_pack_records on real records of a seed batch, and pack -> unpack reproduces those records byte for
+    byte (the batch calls write no array element beyond a candidate's own camera count)."""
+    import torch
+    from pais_mvs_amd import _lib
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import Context
+    cfg = readme_config(particleNum=6, maxIteration=8)
+    S = common.oracle_scene(cfg, pawn_small)
+    _, cands = common.seed_candidates(S, pawn_small)
+    ctx = Context(cfg, pawn_small.cameras, device=0, seed=42)
+    res = ctx.refine_batch(cands)
+    n = len(res)
+    L = ctx.L
+    L.pais_record_wire_bytes.restype = C.c_size_t
+    L.pais_record_wire_bytes.argtypes = [C.c_int]
+    L.pais_pack_records.argtypes = [C.c_int, C.POINTER(_lib.PatchResult), C.c_int, C.c_void_p]
+    L.pais_unpack_records.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(_lib.PatchResult)]
+    L.pais_pack_records_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    K = max(c.num_cam for c in cands)
+    wb = L.pais_record_wire_bytes(K)
+    recs = (_lib.PatchResult * n)(*res)
+    host = (C.c_uint8 * (wb * n))()
+    assert L.pais_pack_records(n, recs, K, host) == 0
+    raw = np.frombuffer(recs, dtype=np.uint8).copy()
+    d_recs = torch.from_numpy(raw).cuda()
+    d_wire = torch.zeros(wb * n, dtype=torch.uint8, device="cuda")
+    assert L.pais_pack_records_device(ctx.h, n, C.c_void_p(d_recs.data_ptr()), K, C.c_void_p(d_wire.data_ptr())) == 0
+    assert L.pais_ctx_synchronize(ctx.h) == 0
+    assert bytes(d_wire.cpu().numpy().tobytes()) == bytes(host)
+    back = (_lib.PatchResult * n)()
+    assert L.pais_unpack_records(n, host, K, back) == 0
+    assert bytes(back) == raw.tobytes()
+    ctx.close()
+
