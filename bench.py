@@ -366,6 +366,7 @@ def main():
                        "cloud_sha1": cloud_sha1, "cloud_sha1_expected": gold_sha, "cloud_matches_oracle_golden": gold_ok,
                        "speculative_extra_refines_per_step": spec // max(args.steps, 1),
                        "rounds_per_step": int(last.rounds) if last else 0,
+                       "rounds_streamed_per_step": int(last.rounds_streamed) if last else 0,
                        "pso_evals_per_patch": evals_eff / max(units, 1),
                        "batches_sharded_per_step": int(last.batches_sharded) if last else 0,
                        "batches_replicated_per_step": int(last.batches_replicated) if last else 0,

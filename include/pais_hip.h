@@ -192,6 +192,30 @@ int  pais_refine_batch(pais_ctx *ctx, int n, const pais_candidate *cands, pais_p
  * pinned staging buffer, valid until the next batch call on this context (what
  * MVS::refineSeedPatches / expansionPatches need: they read every record once). */
 int  pais_refine_batch_view(pais_ctx *ctx, int n, const pais_candidate *cands, const pais_patch_result **view);
+/* pais_refine_batch_view in two halves.  _begin copies the candidates to pinned memory and enqueues the whole batch
+ * (copy up, refine, copy down); for a pure expansion batch it returns as soon as that is enqueued (a batch that holds
+ * seeds is refined before it returns: the seed loop takes host decisions).  _end waits for the batch and hands out the
+ * view.  Exactly one batch can be open per context; the caller's `cands` are not read after _begin returns. */
+int  pais_refine_batch_begin(pais_ctx *ctx, int n, const pais_candidate *cands);
+int  pais_refine_batch_end(pais_ctx *ctx, const pais_patch_result **view);
+/* _begin cut in pieces, for a driver that keeps two lanes busy: the launches of a batch are a chain per PSO iteration,
+ * and a chain that is enqueued in one go keeps the host away from the other lane for its whole length.  _open = _begin
+ * that stops after the first `iterations` PSO iterations; _enqueue adds up to `iterations` more (<= 0: all that remain)
+ * and returns 1 once the batch is enqueued to its end (after-stage and copy down included), 0 while iterations remain,
+ * < 0 on error.  _end enqueues whatever remains. */
+int  pais_refine_batch_open(pais_ctx *ctx, int n, const pais_candidate *cands, int iterations);
+int  pais_refine_batch_enqueue(pais_ctx *ctx, int iterations);
+/* A second lane over the same scene: a context that shares the parent's cameras, pyramids and configuration (nothing
+ * is copied or re-uploaded) and has its own stream, work buffers and staging, so that a batch can be open on each --
+ * the drivers of include/pais_mvs.h enumerate the second half of a round while the first half is being refined.
+ * The lane belongs to the parent: pais_ctx_destroy(parent) releases it, pais_ctx_set_config / _set_neighbor_radius /
+ * _set_fine_timing on the parent apply to it, pais_get_kernel_stats(parent) includes its launches.  Records are the
+ * same bit for bit whichever lane refines a candidate. */
+int  pais_ctx_fork_lane(pais_ctx *parent, pais_ctx **lane);
+/* The next batch of this context is one of several parts of a round of about `n_round` candidates that are refined at
+ * the same time (on other lanes): the launch shapes -- which PSO pipeline, how many sub-streams, how many waves per
+ * evaluation -- are chosen for the round, not for the part.  Applies to one batch; never changes a record. */
+int  pais_ctx_set_round_hint(pais_ctx *ctx, int n_round);
 
 /* Same, with device pointers (results stay in HBM, e.g. as the send buffer of
  * the per-round RCCL all-gather).  Work is enqueued on the context's stream

@@ -49,6 +49,9 @@ typedef struct pais_mvs_stats {
     int64_t batches_replicated;   /* multi-rank batches too small to split: every rank refined all of them      */
     double  exchange_ms;          /* host time spent in the all-gathers (incl. waiting for the slowest rank)    */
     int64_t exchange_bytes;       /* bytes a rank received in them: world x (64-byte header + shard x wire slot) per batch */
+    int64_t rounds_streamed;      /* rounds whose work list went to the GPU in two parts (the second enumerated, the first
+                                   * committed, while the other was being refined); host_enumerate_ms / host_commit_ms then
+                                   * include host work that ran under the GPU's, gpu_refine_ms only what the host waited for */
 } pais_mvs_stats;
 
 /* One entry per GPU batch of the last reconstruction (the seed batch first, then one per expansion round with

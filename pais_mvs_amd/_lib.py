@@ -121,6 +121,12 @@ def load(build_if_needed: bool = True):
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.pais_refine_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(Candidate), C.POINTER(PatchResult)]
     L.pais_refine_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.pais_refine_batch_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(Candidate)]
+    L.pais_refine_batch_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(Candidate), C.c_int]
+    L.pais_refine_batch_enqueue.argtypes = [C.c_void_p, C.c_int]
+    L.pais_ctx_set_round_hint.argtypes = [C.c_void_p, C.c_int]
+    L.pais_refine_batch_end.argtypes = [C.c_void_p, C.POINTER(C.POINTER(PatchResult))]
+    L.pais_ctx_fork_lane.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.pais_get_kernel_stats.argtypes = [C.c_void_p, C.POINTER(KernelStats), C.c_int]
     L.pais_ctx_set_fine_timing.argtypes = [C.c_void_p, C.c_int]
     L.pais_neighbor_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_double)]

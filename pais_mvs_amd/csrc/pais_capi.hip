@@ -39,6 +39,29 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
+struct pais_ctx;
+// brackets a region of a stream with an event pair while profiling is on (defined below)
+struct Timed {
+    pais_ctx *ctx = nullptr;
+    hipStream_t st = nullptr;
+    std::vector<EventPair> *into = nullptr;
+    EventPair e{nullptr, nullptr};
+    bool on = false;
+    int begin(pais_ctx *c, hipStream_t s, std::vector<EventPair> *v);
+    int end();
+};
+// a PSO pass of a batch between pass_open and pass_close (refine batch section)
+struct PassPlan {
+    struct Slice { int lo, hi, parts; hipStream_t st; bool own; };
+    int n = 0, Nmax = 0, Kmax = 0, maxIt = 0, nSl = 0, S = 1, afterGrid = 0, itNext = 0;
+    bool useIter = false, useTile = false;
+    Slice sl[16];
+    int *cnt = nullptr, *nextCnt = nullptr;
+    size_t SB = 0, EB = 0, WB = 0;
+    pais_patch_result *d_out = nullptr;
+    Timed tp;
+};
+
 struct pais_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -110,6 +133,13 @@ struct pais_ctx {
     std::vector<EventPair> evFree;
     double psoMs = 0, beginMs = 0, afterMs = 0, evalMs = 0, eval2Ms = 0;
     int64_t psoLaunches = 0, evalLaunches = 0, eval2Launches = 0;
+    // lanes (pais_ctx_fork_lane): contexts over this one's scene with their own stream and work buffers
+    pais_ctx *parent = nullptr;         // != nullptr: this is a lane; the scene's allocations belong to the parent
+    std::vector<pais_ctx *> lanes;
+    int openBatch = -1;                 // records of the batch between pais_refine_batch_begin and _end (-1: none)
+    PassPlan plan;                      // of the open batch (pais_refine_batch_open .. _enqueue)
+    bool planDone = true;               // the open batch is enqueued to its end
+    int roundHint = 0;                  // pais_ctx_set_round_hint: candidates of the round the next batch is a part of (0: it is the round)
 };
 
 // MVS::initPatchDistanceWeighting, mvs.cpp:97-114 (host; same arithmetic as the reference)
@@ -162,6 +192,7 @@ extern "C" uint32_t pais_rand31(uint64_t seed, uint64_t key, uint32_t run, uint3
 extern "C" uint64_t pais_child_key(uint64_t parent_key, int cam, int cx, int cy) { return pais::child_key(parent_key, cam, cx, cy); }
 
 static int ctx_init(pais_ctx *ctx, const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device, uint64_t pso_seed);
+static int ctx_init_work(pais_ctx *ctx);
 extern "C" int pais_ctx_create(const pais_config *cfg, int num_cams, const pais_camera_desc *cams, int device,
                                uint64_t pso_seed, pais_ctx **out)
 {
@@ -307,6 +338,12 @@ static int ctx_init(pais_ctx *ctx, const pais_config *cfg, int num_cams, const p
     ctx->sc.imgF = ctx->d_imgF;
     ctx->sc.edgeBlob = ctx->d_edge;
 
+    return ctx_init_work(ctx);
+}
+
+// everything of a context that is not the scene: counters, statistics, knobs, sub-streams (a lane has its own)
+static int ctx_init_work(pais_ctx *ctx)
+{
     HIPCHK(hipMalloc(&ctx->d_counters, sizeof(int) * 8));
     HIPCHK(hipMemset(ctx->d_counters, 0, sizeof(int) * 8));
     HIPCHK(hipMalloc(&ctx->d_stat, sizeof(unsigned long long) * 24));
@@ -341,6 +378,18 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->parent) { // a lane destroyed on its own: the parent forgets it
+        auto &v = ctx->parent->lanes;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == ctx) { v.erase(v.begin() + (long)i); break; }
+        ctx->parent = nullptr;
+    }
+    while (!ctx->lanes.empty()) {
+        pais_ctx *l = ctx->lanes.back();
+        ctx->lanes.pop_back();
+        l->parent = nullptr;
+        pais_ctx_destroy(l);
+    }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     auto freeEv = [](std::vector<EventPair> &v) {
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -369,16 +418,47 @@ extern "C" int pais_ctx_set_config(pais_ctx *ctx, const pais_config *cfg)
     HIPCHK(hipSetDevice(ctx->device));
     if (cfg->adaptiveGradientEnable && !ctx->d_edge && !ctx->edgesOnTheFly)
         return fail_msg("adaptiveGradientEnable needs the gradient weighting enabled at create time (edge pyramids or their on-the-fly statistics)");
-    double nr = ctx->sc.cfg.neighborRadius;
+    if (ctx->parent) return fail_msg("pais_ctx_set_config: a lane takes its configuration from its parent");
+    for (pais_ctx *l : ctx->lanes) HIPCHK(hipStreamSynchronize(l->stream)); // (the table is reallocated)
     int rc = apply_config(ctx, cfg);
-    (void)nr;
-    return rc;
+    if (rc) return rc;
+    for (pais_ctx *l : ctx->lanes) {
+        l->sc.cfg = ctx->sc.cfg;
+        l->sc.gauss = ctx->sc.gauss;
+        for (int i = 0; i < PAIS_MAX_LEVELS; ++i) l->sc.lodScale[i] = ctx->sc.lodScale[i];
+    }
+    return 0;
+}
+
+extern "C" int pais_ctx_fork_lane(pais_ctx *parent, pais_ctx **out)
+{
+    if (!parent || !out) return fail_msg("pais_ctx_fork_lane: bad argument");
+    if (parent->parent) return fail_msg("pais_ctx_fork_lane: a lane cannot be forked");
+    HIPCHK(hipSetDevice(parent->device));
+    pais_ctx *l = new pais_ctx();
+    l->device = parent->device;
+    l->numCUs = parent->numCUs;
+    l->ldsLimit = parent->ldsLimit;
+    l->sc = parent->sc; // the parent's cameras, blobs and table: shared, not owned (d_cams, d_img ... stay null here)
+    l->edgesOnTheFly = parent->edgesOnTheFly;
+    l->imgBytes = parent->imgBytes;
+    l->edgeBytes = parent->edgeBytes;
+    hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete l; return fail("hipStreamCreateWithFlags", e); }
+    const int rc = ctx_init_work(l);
+    if (rc) { pais_ctx_destroy(l); return rc; }
+    l->fineTiming = parent->fineTiming;
+    l->parent = parent;
+    parent->lanes.push_back(l);
+    *out = l;
+    return 0;
 }
 
 extern "C" int pais_ctx_set_neighbor_radius(pais_ctx *ctx, double r)
 {
     if (!ctx) return fail_msg("bad ctx");
     ctx->sc.cfg.neighborRadius = r;
+    for (pais_ctx *l : ctx->lanes) l->sc.cfg.neighborRadius = r;
     return 0;
 }
 
@@ -414,29 +494,21 @@ static int drain_events(pais_ctx *ctx, std::vector<EventPair> &v, double &acc)
     v.clear();
     return 0;
 }
-// brackets a region of `st` with an event pair while profiling is on
-struct Timed {
-    pais_ctx *ctx;
-    hipStream_t st;
-    std::vector<EventPair> *into;
-    EventPair e{nullptr, nullptr};
-    bool on;
-    int begin(pais_ctx *c, hipStream_t s, std::vector<EventPair> *v)
-    {
-        ctx = c; st = s; into = v; on = c->fineTiming;
-        if (!on) return 0;
-        if (get_event_pair(c, e)) return -2;
-        HIPCHK(hipEventRecord(e.a, s));
-        return 0;
-    }
-    int end()
-    {
-        if (!on) return 0;
-        HIPCHK(hipEventRecord(e.b, st));
-        into->push_back(e);
-        return 0;
-    }
-};
+int Timed::begin(pais_ctx *c, hipStream_t s, std::vector<EventPair> *v)
+{
+    ctx = c; st = s; into = v; on = c->fineTiming;
+    if (!on) return 0;
+    if (get_event_pair(c, e)) return -2;
+    HIPCHK(hipEventRecord(e.a, s));
+    return 0;
+}
+int Timed::end()
+{
+    if (!on) return 0;
+    HIPCHK(hipEventRecord(e.b, st));
+    into->push_back(e);
+    return 0;
+}
 
 template <typename T> static int grow(pais_ctx *ctx, T *&ptr, size_t &capBytes, size_t needBytes)
 {
@@ -489,6 +561,7 @@ extern "C" int pais_ctx_set_fine_timing(pais_ctx *ctx, int on)
 {
     if (!ctx) return fail_msg("pais_ctx_set_fine_timing: bad argument");
     ctx->fineTiming = on != 0;
+    for (pais_ctx *l : ctx->lanes) l->fineTiming = on != 0;
     return 0;
 }
 
@@ -544,12 +617,132 @@ extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_
 }
 
 // ------------------------------------------------------------- refine batch --
-extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out,
-                                        int max_num_cam, int has_seeds)
+// One PSO pass of a batch as the host enqueues it: opened (pipeline chosen, slices forked to the sub-streams), its
+// iterations enqueued in one or several pieces, closed (sub-streams joined, after-stage).  Pieces exist so that the
+// launch sequences of two lanes can be interleaved by a driver (pais_refine_batch_open / _enqueue).
+static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
 {
-    if (!ctx || n < 0) return fail_msg("pais_refine_batch_device: bad argument");
-    if (n == 0) return 0;
-    if (!d_cands || !d_out) return fail_msg("pais_refine_batch_device: null pointer");
+    const DevScene &sc = ctx->sc;
+    P.cnt = ctx->d_counters + 4 * (ctx->passSerial & 1);
+    P.nextCnt = ctx->d_counters + 4 * ((ctx->passSerial + 1) & 1);
+    ctx->passSerial++;
+    if (P.tp.begin(ctx, ctx->stream, &ctx->evPso)) return -2;
+    if (pass > 0) // (pass 0: done by the begin launch)
+        HIPCHK(pais_launch::pso_init(sc, P.d_out, P.n, ctx->d_psoStates, P.Nmax, ctx->d_active, P.cnt + 2, ctx->d_evalBlocks, ctx->d_win, P.Kmax,
+                                     ctx->stream));
+    // k_pso_iter needs the swarm of a candidate in the lanes of one wave; a batch of several residency passes
+    // (>= 3 x 12 waves per CU) is throughput bound: there the step replay in every evaluation wave (~13 % of a wave's
+    // time) costs more than a separate one-wave-per-candidate k_pso_step launch per iteration, whose latency the other
+    // sub-stream hides
+    // the tile kernel pays where the taps miss the caches: scenes whose pyramids exceed PAIS_TAP_FLOAT_MAX_MB (those that tap
+    // the byte blob; the dome: PSO passes -22 %).  On the 184 MB ring, whose taps hit L2, it LOSES 35 % against the
+    // one-wave kernels (profiles/r03_ring_tile_ab.txt) -- PAIS_TILE=2 forces it regardless (tests)
+    const bool tileOk = (ctx->tileMode == 2 || (ctx->tileMode == 1 && ctx->sc.imgF == nullptr)) && pais_launch::tile_eligible(P.Kmax);
+    // (the tile kernel is an evaluation launch of the large-batch pipeline: batches that are eligible for it take that
+    // pipeline from PAIS_TILE_ABOVE waves per iteration on)
+    // (a batch that is one part of a streamed round shares the GPU with the other part: the pipeline is chosen for the round)
+    const int n = P.n, Nmax = P.Nmax;
+    const int nPlan = ctx->roundHint > n ? ctx->roundHint : n;
+    P.useIter = Nmax <= 64 && (long)nPlan * Nmax < (tileOk ? ctx->tileAbove : ctx->splitAbove);
+    P.useTile = tileOk && !P.useIter;
+    // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
+    // its length is n at most in the first pass and exactly the "again" count afterwards
+    const int nRun = P.useIter ? (pass == 0 ? n : againCount) : n;
+    int S = ctx->psoStreams;
+    if (nPlan > n) S = (int)((double)S * n / nPlan + 0.5); // the round's sub-streams are shared out among its parts
+    const int minPer = ctx->psoMinPer; // slices smaller than this only add launch overhead
+    if (nRun < S * minPer) S = (nRun + minPer - 1) / minPer;
+    if (S < 1) S = 1;
+    P.S = S;
+    if (S > 1) HIPCHK(hipEventRecord(ctx->forkEv, ctx->stream));
+    // slice 0 stays on the context's own stream, the others fork to sub-streams and join back
+    P.nSl = 0;
+    for (int sI = 0; sI < S; ++sI) {
+        PassPlan::Slice q;
+        q.lo = (int)((long)nRun * sI / S);
+        q.hi = (int)((long)nRun * (sI + 1) / S);
+        if (q.hi <= q.lo) continue;
+        q.own = (S == 1) || (sI == 0);
+        q.st = q.own ? ctx->stream : ctx->sub[sI - 1];
+        if (!q.own) HIPCHK(hipStreamWaitEvent(q.st, ctx->forkEv, 0));
+        // waves per evaluation: a slice that leaves the GPU mostly empty is bound by the latency of
+        // one evaluation wave, so share each evaluation among 4 (2) waves while they all stay resident
+        q.parts = 1;
+        if (P.useIter) {
+            const long waves = (long)(q.hi - q.lo) * Nmax, resident = (long)((double)ctx->numCUs * 16 * ctx->partFill * n / nPlan);
+            q.parts = ctx->evalParts > 0 ? ctx->evalParts : (waves * 4 <= resident ? 4 : (waves * 2 <= resident ? 2 : 1));
+        }
+        P.sl[P.nSl++] = q;
+    }
+    P.itNext = 0;
+    return 0;
+}
+
+// iterations [P.itNext, itEnd) of the pass (itEnd is clamped to maxIt + 1: launch `it` = step it - 1 + cost of the moved swarm)
+static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
+{
+    const DevScene &sc = ctx->sc;
+    if (itEnd > P.maxIt + 1) itEnd = P.maxIt + 1;
+    // enqueued iteration by iteration across the slices: every sub-stream has work from the start (slice by slice, the
+    // second slice would begin one host enqueue pass -- 62 launches -- after the first)
+    for (int it = P.itNext; it < itEnd; ++it) {
+        for (int k = 0; k < P.nSl; ++k) {
+            const PassPlan::Slice &q = P.sl[k];
+            unsigned char *stp = ctx->d_psoStates + P.SB * (size_t)q.lo;
+            Timed te; // events on the stream the kernel is launched on
+            if (te.begin(ctx, q.st, P.useIter ? &ctx->evEval : &ctx->evEval2)) return -2;
+            if (P.useIter)
+                HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, P.cnt + 2, q.lo, q.hi, P.Nmax, P.Kmax, P.d_out,
+                                             ctx->d_stat, it, 0, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
+            else if (P.useTile) {
+                // many cameras: footprints staged in LDS (pais_tile.hpp); the particles it flags take the checked walk
+                HIPCHK(pais_launch::pso_tile(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
+                                             ctx->d_win + P.WB * (size_t)q.lo, ctx->tileStrip2, ctx->tileStrip1, ctx->tileForceNs1,
+                                             ctx->tileDebug ? ctx->d_stat + 8 : nullptr, q.st));
+                HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
+                                             ctx->d_win + P.WB * (size_t)q.lo, ctx->tileVerify ? 2 : 1, ctx->d_stat + 18, q.st));
+            } else
+                HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
+                                             ctx->d_win + P.WB * (size_t)q.lo, 0, nullptr, q.st));
+            if (te.end()) return -2;
+            ctx->evalLaunches++;
+            if (!P.useIter) ctx->eval2Launches++;
+            if (!P.useIter) HIPCHK(pais_launch::pso_step(sc, P.d_out + q.lo, stp, q.hi - q.lo, P.Nmax, ctx->d_stat, q.st));
+        }
+    }
+    if (itEnd > P.itNext) P.itNext = itEnd;
+    return 0;
+}
+
+static int pass_close(pais_ctx *ctx, PassPlan &P)
+{
+    const DevScene &sc = ctx->sc;
+    for (int k = 0; k < P.nSl; ++k) {
+        const PassPlan::Slice &q = P.sl[k];
+        // the launch after the last possible iteration only ends the runs still active
+        if (P.useIter)
+            HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, P.cnt + 2, q.lo, q.hi, P.Nmax, P.Kmax, P.d_out,
+                                         ctx->d_stat, P.maxIt + 1, 1, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
+    }
+    for (int sI = 1; sI < P.S; ++sI) {
+        bool used = false;
+        for (int k = 0; k < P.nSl; ++k) used = used || (P.sl[k].st == ctx->sub[sI - 1]);
+        if (!used) continue;
+        HIPCHK(hipEventRecord(ctx->subDone[sI - 1], ctx->sub[sI - 1]));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
+    }
+    if (P.tp.end()) return -2;
+    ctx->psoLaunches++;
+    Timed ta;
+    if (ta.begin(ctx, ctx->stream, &ctx->evAfter)) return -2;
+    HIPCHK(pais_launch::after(sc, P.d_out, P.n, ctx->d_hp, P.afterGrid, P.cnt, ctx->d_stat, P.Kmax, ctx->d_ratios, P.nextCnt, ctx->stream));
+    if (ta.end()) return -2;
+    return 0;
+}
+
+// work buffers, the head of refine() and the set-up of every candidate's first PSO run (k_begin)
+static int batch_setup(pais_ctx *ctx, PassPlan &P, int n, const pais_candidate *d_cands, pais_patch_result *d_out, int max_num_cam, int has_seeds)
+{
     HIPCHK(hipSetDevice(ctx->device));
     const DevScene &sc = ctx->sc;
     int Kmax = max_num_cam > 0 ? max_num_cam : sc.numCams;
@@ -575,7 +768,15 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     const size_t SB = pais_launch::pso_state_bytes_host(Nmax);
     if (grow(ctx, ctx->d_psoStates, ctx->psoStateBytes, SB * (size_t)n)) return -2;
     if (grow(ctx, ctx->d_ratios, ctx->ratioBytes, sizeof(double) * PAIS_MAX_VIS * (size_t)n)) return -2;
-    const size_t EB = pais_launch::eval_block_bytes_host(Kmax), WB = pais_launch::win_bytes_per_candidate(sc);
+    P.n = n;
+    P.Nmax = Nmax;
+    P.Kmax = Kmax;
+    P.afterGrid = afterGrid;
+    P.maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
+    P.SB = SB;
+    P.EB = pais_launch::eval_block_bytes_host(Kmax);
+    P.WB = pais_launch::win_bytes_per_candidate(sc);
+    P.d_out = d_out;
 
     if (ctx->countersDirty) HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 8, ctx->stream));
     ctx->countersDirty = true; // until this batch has run through
@@ -585,113 +786,40 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     HIPCHK(pais_launch::begin(sc, d_cands, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, ctx->d_counters + 4 * (ctx->passSerial & 1) + 2,
                               ctx->d_evalBlocks, ctx->d_win, Kmax, ctx->stream));
     if (tb.end()) return -2;
+    return 0;
+}
 
+extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out,
+                                        int max_num_cam, int has_seeds)
+{
+    if (!ctx || n < 0) return fail_msg("pais_refine_batch_device: bad argument");
+    if (n == 0) return 0;
+    if (!d_cands || !d_out) return fail_msg("pais_refine_batch_device: null pointer");
+    if (ctx->openBatch >= 0) return fail_msg("pais_refine_batch_device: a batch is open on this context");
+    PassPlan &P = ctx->plan;
+    int rc = batch_setup(ctx, P, n, d_cands, d_out, max_num_cam, has_seeds);
     int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
     const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
-    const int maxIt = has_seeds ? sc.cfg.maxIteration * 2 : sc.cfg.maxIteration;
-    for (int pass = 0; pass < maxPass; ++pass) {
-        int *cnt = ctx->d_counters + 4 * (ctx->passSerial & 1), *nextCnt = ctx->d_counters + 4 * ((ctx->passSerial + 1) & 1);
-        ctx->passSerial++;
-        Timed tp;
-        if (tp.begin(ctx, ctx->stream, &ctx->evPso)) return -2;
-        if (pass > 0) // (pass 0: done by the begin launch)
-            HIPCHK(pais_launch::pso_init(sc, d_out, n, ctx->d_psoStates, Nmax, ctx->d_active, cnt + 2, ctx->d_evalBlocks, ctx->d_win, Kmax,
-                                         ctx->stream));
-        // k_pso_iter needs the swarm of a candidate in the lanes of one wave; a batch of several residency passes
-        // (>= 3 x 12 waves per CU) is throughput bound: there the step replay in every evaluation wave (~13 % of a wave's
-        // time) costs more than a separate one-wave-per-candidate k_pso_step launch per iteration, whose latency the other
-        // sub-stream hides
-        // the tile kernel pays where the taps miss the caches: scenes whose pyramids exceed PAIS_TAP_FLOAT_MAX_MB (those that tap
-        // the byte blob; the dome: PSO passes -22 %).  On the 184 MB ring, whose taps hit L2, it LOSES 35 % against the
-        // one-wave kernels (profiles/r03_ring_tile_ab.txt) -- PAIS_TILE=2 forces it regardless (tests)
-        const bool tileOk = (ctx->tileMode == 2 || (ctx->tileMode == 1 && ctx->d_imgF == nullptr)) && pais_launch::tile_eligible(Kmax);
-        // (the tile kernel is an evaluation launch of the large-batch pipeline: batches that are eligible for it take that
-        // pipeline from PAIS_TILE_ABOVE waves per iteration on)
-        const bool useIter = Nmax <= 64 && (long)n * Nmax < (tileOk ? ctx->tileAbove : ctx->splitAbove);
-        const bool useTile = tileOk && !useIter;
-        // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
-        // its length is n at most in the first pass and exactly the "again" count afterwards
-        const int nRun = useIter ? (pass == 0 ? n : againCount) : n;
-        int S = ctx->psoStreams;
-        const int minPer = ctx->psoMinPer; // slices smaller than this only add launch overhead
-        if (nRun < S * minPer) S = (nRun + minPer - 1) / minPer;
-        if (S < 1) S = 1;
-        if (S > 1) HIPCHK(hipEventRecord(ctx->forkEv, ctx->stream));
-        // slice 0 stays on the context's own stream, the others fork to sub-streams and join back
-        struct Slice { int lo, hi, parts; hipStream_t st; bool own; };
-        Slice sl[16];
-        int nSl = 0;
-        for (int sI = 0; sI < S; ++sI) {
-            Slice q;
-            q.lo = (int)((long)nRun * sI / S);
-            q.hi = (int)((long)nRun * (sI + 1) / S);
-            if (q.hi <= q.lo) continue;
-            q.own = (S == 1) || (sI == 0);
-            q.st = q.own ? ctx->stream : ctx->sub[sI - 1];
-            if (!q.own) HIPCHK(hipStreamWaitEvent(q.st, ctx->forkEv, 0));
-            // waves per evaluation: a slice that leaves the GPU mostly empty is bound by the latency of
-            // one evaluation wave, so share each evaluation among 4 (2) waves while they all stay resident
-            q.parts = 1;
-            if (useIter) {
-                const long waves = (long)(q.hi - q.lo) * Nmax, resident = (long)((double)ctx->numCUs * 16 * ctx->partFill);
-                q.parts = ctx->evalParts > 0 ? ctx->evalParts : (waves * 4 <= resident ? 4 : (waves * 2 <= resident ? 2 : 1));
-            }
-            sl[nSl++] = q;
-        }
-        // enqueued iteration by iteration across the slices: every sub-stream has work from the start (slice by slice, the
-        // second slice would begin one host enqueue pass -- 62 launches -- after the first)
-        for (int it = 0; it <= maxIt; ++it) {
-            for (int k = 0; k < nSl; ++k) {
-                const Slice &q = sl[k];
-                unsigned char *stp = ctx->d_psoStates + SB * (size_t)q.lo;
-                Timed te; // events on the stream the kernel is launched on
-                if (te.begin(ctx, q.st, useIter ? &ctx->evEval : &ctx->evEval2)) return -2;
-                if (useIter)
-                    HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, cnt + 2, q.lo, q.hi, Nmax, Kmax, d_out,
-                                                 ctx->d_stat, it, 0, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
-                else if (useTile) {
-                    // many cameras: footprints staged in LDS (pais_tile.hpp); the particles it flags take the checked walk
-                    HIPCHK(pais_launch::pso_tile(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
-                                                 ctx->d_win + WB * (size_t)q.lo, ctx->tileStrip2, ctx->tileStrip1, ctx->tileForceNs1,
-                                                 ctx->tileDebug ? ctx->d_stat + 8 : nullptr, q.st));
-                    HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
-                                                 ctx->d_win + WB * (size_t)q.lo, ctx->tileVerify ? 2 : 1, ctx->d_stat + 18, q.st));
-                } else
-                    HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, Nmax, Kmax, ctx->d_evalBlocks + EB * (size_t)q.lo,
-                                                 ctx->d_win + WB * (size_t)q.lo, 0, nullptr, q.st));
-                if (te.end()) return -2;
-                ctx->evalLaunches++;
-                if (!useIter) ctx->eval2Launches++;
-                if (!useIter) HIPCHK(pais_launch::pso_step(sc, d_out + q.lo, stp, q.hi - q.lo, Nmax, ctx->d_stat, q.st));
-            }
-        }
-        for (int k = 0; k < nSl; ++k) {
-            const Slice &q = sl[k];
-            // the launch after the last possible iteration only ends the runs still active
-            if (useIter)
-                HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, cnt + 2, q.lo, q.hi, Nmax, Kmax, d_out,
-                                             ctx->d_stat, maxIt + 1, 1, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
-        }
-        for (int sI = 1; sI < S; ++sI) {
-            bool used = false;
-            for (int k = 0; k < nSl; ++k) used = used || (sl[k].st == ctx->sub[sI - 1]);
-            if (!used) continue;
-            HIPCHK(hipEventRecord(ctx->subDone[sI - 1], ctx->sub[sI - 1]));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
-        }
-        if (tp.end()) return -2;
-        ctx->psoLaunches++;
-        Timed ta;
-        if (ta.begin(ctx, ctx->stream, &ctx->evAfter)) return -2;
-        HIPCHK(pais_launch::after(sc, d_out, n, ctx->d_hp, afterGrid, cnt, ctx->d_stat, Kmax, ctx->d_ratios, nextCnt, ctx->stream));
-        if (ta.end()) return -2;
+    for (int pass = 0; !rc && pass < maxPass; ++pass) {
+        if ((rc = pass_open(ctx, P, pass, againCount)) != 0) break;
+        if ((rc = pass_iterations(ctx, P, P.maxIt + 1)) != 0) break;
+        if ((rc = pass_close(ctx, P)) != 0) break;
         if (!has_seeds) break;
-        HIPCHK(hipMemcpyAsync(ctx->h_counters, cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->h_counters, P.cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ctx->h_counters[1] == 0) break;
         againCount = ctx->h_counters[1];
     }
+    ctx->roundHint = 0;
+    if (rc) return rc;
     ctx->countersDirty = false;
+    return 0;
+}
+
+extern "C" int pais_ctx_set_round_hint(pais_ctx *ctx, int n_round)
+{
+    if (!ctx) return fail_msg("pais_ctx_set_round_hint: bad argument");
+    ctx->roundHint = n_round > 0 ? n_round : 0;
     return 0;
 }
 
@@ -702,6 +830,58 @@ extern "C" int pais_refine_batch_view(pais_ctx *ctx, int n, const pais_candidate
     if (!ctx || n < 0) return fail_msg("pais_refine_batch: bad argument");
     if (n == 0) return 0;
     if (!cands || !view) return fail_msg("pais_refine_batch: null pointer");
+    int rc = pais_refine_batch_begin(ctx, n, cands);
+    if (rc) return rc;
+    return pais_refine_batch_end(ctx, view);
+}
+
+extern "C" int pais_refine_batch_begin(pais_ctx *ctx, int n, const pais_candidate *cands)
+{
+    int rc = pais_refine_batch_open(ctx, n, cands, 1 << 20);
+    if (rc) return rc;
+    rc = pais_refine_batch_enqueue(ctx, 0);
+    return rc < 0 ? rc : 0;
+}
+
+// the rest of an opened batch's launches, at most `iterations` PSO iterations of them (<= 0: all); 1: the batch is enqueued
+// to its end (after-stage and the copy down included), 0: iterations remain
+extern "C" int pais_refine_batch_enqueue(pais_ctx *ctx, int iterations)
+{
+    if (!ctx) return fail_msg("pais_refine_batch_enqueue: bad argument");
+    if (ctx->openBatch < 0) return fail_msg("pais_refine_batch_enqueue: no batch is open on this context");
+    if (ctx->planDone) return 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    PassPlan &P = ctx->plan;
+    const int itEnd = iterations > 0 && iterations < P.maxIt + 1 - P.itNext ? P.itNext + iterations : P.maxIt + 1;
+    int rc = pass_iterations(ctx, P, itEnd);
+    if (!rc && P.itNext <= P.maxIt) return 0;
+    if (!rc) rc = pass_close(ctx, P);
+    if (rc) { ctx->openBatch = -1; return rc; } // (the counters stay marked dirty: cleared before the next batch)
+    ctx->countersDirty = false;
+    HIPCHK(hipMemcpyAsync(ctx->h_recs, ctx->d_recs, sizeof(pais_patch_result) * (size_t)ctx->openBatch, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->planDone = true;
+    return 1;
+}
+
+extern "C" int pais_refine_batch_end(pais_ctx *ctx, const pais_patch_result **view)
+{
+    if (!ctx || !view) return fail_msg("pais_refine_batch_end: bad argument");
+    if (ctx->openBatch < 0) return fail_msg("pais_refine_batch_end: no batch is open on this context");
+    if (!ctx->planDone) {
+        const int rc = pais_refine_batch_enqueue(ctx, 0);
+        if (rc < 0) return rc;
+    }
+    ctx->openBatch = -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *view = ctx->h_recs;
+    return 0;
+}
+
+extern "C" int pais_refine_batch_open(pais_ctx *ctx, int n, const pais_candidate *cands, int iterations)
+{
+    if (!ctx || n <= 0 || !cands) return fail_msg("pais_refine_batch_begin: bad argument");
+    if (ctx->openBatch >= 0) return fail_msg("pais_refine_batch_begin: a batch is open on this context already");
     HIPCHK(hipSetDevice(ctx->device));
     int Kmax = 1, hasSeeds = 0;
     for (int i = 0; i < n; ++i) {
@@ -729,11 +909,23 @@ extern "C" int pais_refine_batch_view(pais_ctx *ctx, int n, const pais_candidate
     }
     memcpy(ctx->h_cands, cands, sizeof(pais_candidate) * (size_t)n);
     HIPCHK(hipMemcpyAsync(ctx->d_cands, ctx->h_cands, sizeof(pais_candidate) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    int rc = pais_refine_batch_device(ctx, n, ctx->d_cands, ctx->d_recs, Kmax, hasSeeds);
+    if (hasSeeds) {
+        // the seed loop takes a host decision per pass: refined here and now
+        int rc = pais_refine_batch_device(ctx, n, ctx->d_cands, ctx->d_recs, Kmax, 1);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->h_recs, ctx->d_recs, sizeof(pais_patch_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->openBatch = n;
+        ctx->planDone = true;
+        return 0;
+    }
+    PassPlan &P = ctx->plan;
+    int rc = batch_setup(ctx, P, n, ctx->d_cands, ctx->d_recs, Kmax, 0);
+    if (!rc) rc = pass_open(ctx, P, 0, 0);
+    ctx->roundHint = 0;
+    if (!rc) rc = pass_iterations(ctx, P, iterations > 0 ? iterations : 0);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->h_recs, ctx->d_recs, sizeof(pais_patch_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    *view = ctx->h_recs;
+    ctx->openBatch = n;
+    ctx->planDone = false;
     return 0;
 }
 
@@ -801,10 +993,9 @@ extern "C" int pais_pack_records_device(pais_ctx *ctx, int n, const pais_patch_r
     return 0;
 }
 
-extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset)
+// the launches of one context (a lane is folded into its parent's figures by pais_get_kernel_stats)
+static int collect_stats(pais_ctx *ctx, unsigned long long *st)
 {
-    if (!ctx || !out) return fail_msg("pais_get_kernel_stats: bad argument");
-    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (drain_events(ctx, ctx->evPso, ctx->psoMs)) return -2;
     if (drain_events(ctx, ctx->evBegin, ctx->beginMs)) return -2;
@@ -816,8 +1007,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
         ctx->eval2Ms += ms2;
         ctx->evalMs += ms2;
     }
-    unsigned long long st[24];
-    HIPCHK(hipMemcpy(st, ctx->d_stat, sizeof(st), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st, ctx->d_stat, sizeof(unsigned long long) * 24, hipMemcpyDeviceToHost));
     if (ctx->tileDebug)
         fprintf(stderr, "[pais tile] particles through the tiles %llu, DBL_MAX %llu, pending (checked walk) %llu; tiles staged %llu (%.1f KB each), cameras left in global memory %llu\n",
                 st[8], st[9], st[10], st[11], st[11] ? (double)st[13] / (double)st[11] / 1024.0 : 0.0, st[12]);
@@ -831,28 +1021,43 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
     }
     if (ctx->tileDebug)
         fprintf(stderr, "[pais tile] cycles of wave 0 per phase: boxes %.3g, layout %.3g, copy %.3g, walk %.3g\n", (double)st[14], (double)st[15], (double)st[16], (double)st[17]);
+    return 0;
+}
+
+extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset)
+{
+    if (!ctx || !out) return fail_msg("pais_get_kernel_stats: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<pais_ctx *> all(1, ctx);
+    all.insert(all.end(), ctx->lanes.begin(), ctx->lanes.end());
+    memset(out, 0, sizeof(*out));
     const double S2 = (double)ctx->sc.cfg.patchSize * ctx->sc.cfg.patchSize;
-    out->pso_ms = ctx->psoMs;
-    out->begin_ms = ctx->beginMs;
-    out->after_ms = ctx->afterMs;
-    out->pso_launches = ctx->psoLaunches;
-    out->pso_evals = (int64_t)st[0];
-    out->pso_patches = (int64_t)st[2];
-    out->pso_algorithmic_bytes = (double)st[1] * S2;
-    out->ncc_tables = (int64_t)st[3];
-    out->ncc_algorithmic_bytes = (double)st[4] * S2 * 4.0;
-    out->eval_ms = ctx->evalMs;
-    out->eval_launches = ctx->evalLaunches;
-    out->eval2_ms = ctx->eval2Ms;
-    out->eval2_launches = ctx->eval2Launches;
-    out->eval2_evals = (int64_t)st[5];
-    out->eval2_algorithmic_bytes = (double)st[6] * S2;
-    if (reset) {
-        HIPCHK(hipMemset(ctx->d_stat, 0, sizeof(unsigned long long) * 24));
-        ctx->psoMs = ctx->beginMs = ctx->afterMs = ctx->evalMs = ctx->eval2Ms = 0;
-        ctx->psoLaunches = 0;
-        ctx->evalLaunches = 0;
-        ctx->eval2Launches = 0;
+    for (pais_ctx *c : all) {
+        unsigned long long st[24];
+        const int rc = collect_stats(c, st);
+        if (rc) return rc;
+        out->pso_ms += c->psoMs;
+        out->begin_ms += c->beginMs;
+        out->after_ms += c->afterMs;
+        out->pso_launches += c->psoLaunches;
+        out->pso_evals += (int64_t)st[0];
+        out->pso_patches += (int64_t)st[2];
+        out->pso_algorithmic_bytes += (double)st[1] * S2;
+        out->ncc_tables += (int64_t)st[3];
+        out->ncc_algorithmic_bytes += (double)st[4] * S2 * 4.0;
+        out->eval_ms += c->evalMs;
+        out->eval_launches += c->evalLaunches;
+        out->eval2_ms += c->eval2Ms;
+        out->eval2_launches += c->eval2Launches;
+        out->eval2_evals += (int64_t)st[5];
+        out->eval2_algorithmic_bytes += (double)st[6] * S2;
+        if (reset) {
+            HIPCHK(hipMemset(c->d_stat, 0, sizeof(unsigned long long) * 24));
+            c->psoMs = c->beginMs = c->afterMs = c->evalMs = c->eval2Ms = 0;
+            c->psoLaunches = 0;
+            c->evalLaunches = 0;
+            c->eval2Launches = 0;
+        }
     }
     return 0;
 }

@@ -299,6 +299,23 @@ struct pais_mvs {
     std::vector<WorkItem> work;
     std::vector<unsigned char> workState;
     std::vector<std::vector<uint32_t>> workBucket;
+    // streamed rounds (pais_mvs_expansion_patches on one GPU): the candidates of the first part of a round's work list are on
+    // the GPU (this context) while the host enumerates the rest (-> lane1), and the first part's records are committed while
+    // the second part is still being refined.  Same work list, same commit order: same result.
+    pais_ctx *lane1 = nullptr;         // owned by ctx (pais_ctx_fork_lane)
+    int streamRounds = 1;              // PAIS_STREAM_ROUNDS: 0 every round is one batch; 1 rounds whose host work is worth hiding (below); 2 every
+                                       // round of at least streamAbove active parents
+    // Streaming costs about 0.3 ms of GPU time per round (each part runs alone for a while, with one sub-stream) and hides at most
+    // the enumeration of the second part and the commit of the first: measured +5 % on the ring (1.7 ms of host work per round
+    // of 17 ms), -2 % on the pawn scene (0.45 of 6 ms).  A round is streamed when the previous round's host work was at
+    // least streamHostMs and at least streamHostShare of its GPU time -- a choice that never changes a record.
+    double streamHostMs = 0.9, streamHostShare = 0.04; // PAIS_STREAM_HOST_MS / PAIS_STREAM_HOST_SHARE
+    double prevHostMs = 0, prevGpuMs = 0;
+    size_t streamAbove = 192;          // PAIS_STREAM_ABOVE: active parents from which a round is streamed
+    double streamSplit = 0.5;          // PAIS_STREAM_SPLIT: share of the active parents in the first part
+    int streamHead = 4, streamStep = 2; // PAIS_STREAM_HEAD / _STEP: PSO iterations of a part enqueued when it is opened / per turn after that
+    const std::function<int(const pais_candidate *, int)> *onFirstPart = nullptr; // set by the streamed driver for one round_begin
+    int firstPart = -1;                // candidates of the first part of the current round (-1: the round is one batch)
     std::string err;
 
     ~pais_mvs()
@@ -706,6 +723,13 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
         if (const char *e = getenv("PAIS_ENUM_THREADS")) m->enumThreads = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("PAIS_ENUM_ABOVE")) m->enumThreadsAbove = (size_t)std::max(0, atoi(e));
     }
+    if (const char *e = getenv("PAIS_STREAM_ROUNDS")) m->streamRounds = atoi(e);
+    if (const char *e = getenv("PAIS_STREAM_ABOVE")) m->streamAbove = (size_t)std::max(0, atoi(e));
+    if (const char *e = getenv("PAIS_STREAM_HOST_MS")) m->streamHostMs = atof(e);
+    if (const char *e = getenv("PAIS_STREAM_HOST_SHARE")) m->streamHostShare = atof(e);
+    if (const char *e = getenv("PAIS_STREAM_HEAD")) m->streamHead = std::max(1, atoi(e));
+    if (const char *e = getenv("PAIS_STREAM_STEP")) m->streamStep = std::max(1, atoi(e));
+    if (const char *e = getenv("PAIS_STREAM_SPLIT")) { const double v = atof(e); if (v > 0 && v < 1) m->streamSplit = v; }
     memset(&m->st, 0, sizeof(m->st));
     m->cfg = *cfg;
     m->cfg.patchSize = (cfg->patchRadius << 1) + 1;
@@ -768,6 +792,7 @@ extern "C" int pais_mvs_reset(pais_mvs *m)
     m->seedIds.clear();
     memset(&m->st, 0, sizeof(m->st));
     m->roundLog.clear();
+    m->prevHostMs = m->prevGpuMs = 0;
     return 0;
 }
 extern "C" pais_ctx *pais_mvs_ctx(pais_mvs *m) { return m ? m->ctx : nullptr; }
@@ -1371,7 +1396,14 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
     for (size_t k = 0; m->deepPrefetch && k < 4 && k < nAct; ++k) prefetchEntries(k, false);
     for (size_t k = 0; m->deepPrefetch && k < 2 && k < nAct; ++k) prefetchEntries(k, true);
     size_t actIdx = 0;
+    m->firstPart = -1;
+    const size_t splitAt = (m->onFirstPart && nAct >= m->streamAbove && !thin) ? (size_t)((double)nAct * m->streamSplit) : (size_t)-1;
     for (Active &a : m->active) {
+        if (actIdx == splitAt) {
+            // streamed round: what has been listed so far goes to the GPU now (the callback copies the candidates)
+            m->firstPart = (int)m->candRecs.size();
+            if (m->firstPart > 0 && (*m->onFirstPart)(m->candRecs.data(), m->firstPart)) return -2;
+        }
         prefetchRecord(actIdx + 16);
         prefetchCells(actIdx + 8);
         if (m->deepPrefetch) {
@@ -1402,18 +1434,33 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
     return 0;
 }
 
-extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *results, int n)
+// the sequential replay of candidates [q0, q1) of the round; results[0] is the record of candidate q0
+static void commit_records(pais_mvs *m, const pais_patch_result *results, int q0, int q1)
 {
-    if (!m || n != (int)m->cands.size() || (n && !results)) return mfail("pais_mvs_round_commit: bad argument");
-    double t0 = now_ms();
-    for (int q = 0; q < n; ++q) {
+    for (int q = q0; q < q1; ++q) {
         const Candidate &c = m->cands[q];
         const pais_patch_result &pr = m->patches[c.u.id]->r; // stable: patches are heap objects
         if (m->skipNeighborCell(m->cellMaps[c.cam], c.cx, c.cy, pr, -1)) continue; // mvs.cpp:558 on the live state
         m->st.candidates_effective++;
-        m->st.pso_evals_effective += results[q].pso_evals;
-        m->insertPatch(results[q]); // expandCell, mvs.cpp:576
+        m->st.pso_evals_effective += results[q - q0].pso_evals;
+        m->insertPatch(results[q - q0]); // expandCell, mvs.cpp:576
     }
+}
+static int commit_finish(pais_mvs *m, int n);
+
+extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *results, int n)
+{
+    if (!m || n != (int)m->cands.size() || (n && !results)) return mfail("pais_mvs_round_commit: bad argument");
+    double t0 = now_ms();
+    commit_records(m, results, 0, n);
+    const int rc = commit_finish(m, n);
+    m->st.host_commit_ms += now_ms() - t0;
+    return rc;
+}
+
+// end of a round: the cursors, the deferred units, the counters
+static int commit_finish(pais_mvs *m, int n)
+{
     // advance the cursors; parents that have shown all their cameras leave the set
     size_t w = 0;
     for (size_t a = 0; a < m->active.size(); ++a) {
@@ -1428,7 +1475,6 @@ extern "C" int pais_mvs_round_commit(pais_mvs *m, const pais_patch_result *resul
     m->st.rounds++;
     m->curRound++;
     m->cands.clear();
-    m->st.host_commit_ms += now_ms() - t0;
     return 0;
 }
 
@@ -1649,9 +1695,90 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         const pais_candidate *c;
         const pais_patch_result *recs = m->results.data();
         int n;
+        // one GPU, large round: streamed (see pais_mvs::lane1)
+        const bool canStream = m->ctx && m->world <= 1 && !m->nccl && !m->gatherCb &&
+                               (m->streamRounds >= 2 ||
+                                (m->streamRounds == 1 && m->prevHostMs >= m->streamHostMs && m->prevHostMs >= m->streamHostShare * m->prevGpuMs));
+        int beginRc = 0;
+        double tFirst = 0;
+        double enqueueMs = 0; // host time of the first part's enqueue: inside round_begin, but not enumeration
+        const std::function<int(const pais_candidate *, int)> firstPart = [&](const pais_candidate *cc, int n0) {
+            tFirst = now_ms();
+            (void)pais_ctx_set_round_hint(m->ctx, (int)((double)n0 / m->streamSplit)); // the round's size, as far as it is known
+            beginRc = pais_refine_batch_open(m->ctx, n0, cc, m->streamHead); // the head of its launch chain; the rest below
+            if (beginRc) g_mvs_err = pais_last_error();
+            enqueueMs = now_ms() - tFirst;
+            return beginRc;
+        };
+        m->onFirstPart = canStream ? &firstPart : nullptr;
         rc = pais_mvs_round_begin(m, B, &c, &n);
-        if (rc < 0) return rc;
+        m->onFirstPart = nullptr;
+        m->lastEnumerateMs -= enqueueMs;
+        m->st.host_enumerate_ms -= enqueueMs;
+        if (rc < 0) {
+            const pais_patch_result *dummy;
+            if (m->firstPart > 0 && !beginRc) (void)pais_refine_batch_end(m->ctx, &dummy); // nothing stays open behind an error
+            m->firstPart = -1;
+            return beginRc ? beginRc : rc;
+        }
         if (rc == 1) break;
+        if (m->firstPart >= 0) {
+            const int n0 = m->firstPart, n1 = n - n0;
+            const double enumMs = m->lastEnumerateMs;
+            int kmax = 1;
+            for (int i = 0; i < n; ++i) kmax = std::max(kmax, c[i].num_cam);
+            if (n1 > 0) {
+                if (!m->lane1 && pais_ctx_fork_lane(m->ctx, &m->lane1)) { g_mvs_err = pais_last_error(); return -2; }
+                if (n0 == 0) tFirst = now_ms();
+                (void)pais_ctx_set_round_hint(m->lane1, n);
+                if (pais_refine_batch_open(m->lane1, n1, c + n0, m->streamHead)) {
+                    g_mvs_err = pais_last_error();
+                    const pais_patch_result *dummy;
+                    if (n0 > 0) (void)pais_refine_batch_end(m->ctx, &dummy); // nothing stays open behind an error
+                    return -2;
+                }
+            }
+            // the two launch chains, a few PSO iterations of each in turn: neither lane waits for the other's whole chain
+            for (int a = n0 > 0 ? 0 : 1, b = n1 > 0 ? 0 : 1; !a || !b;) {
+                if (!a) a = pais_refine_batch_enqueue(m->ctx, m->streamStep);
+                if (!b && a >= 0) b = pais_refine_batch_enqueue(m->lane1, m->streamStep);
+                if (a < 0 || b < 0) {
+                    g_mvs_err = pais_last_error();
+                    const pais_patch_result *dummy;
+                    if (a >= 0 && n0 > 0) (void)pais_refine_batch_end(m->ctx, &dummy);
+                    if (b >= 0 && n1 > 0) (void)pais_refine_batch_end(m->lane1, &dummy);
+                    return -2;
+                }
+            }
+            double commitMs = 0;
+            const pais_patch_result *v0 = nullptr, *v1 = nullptr;
+            if (n0 > 0) {
+                if (pais_refine_batch_end(m->ctx, &v0)) {
+                    g_mvs_err = pais_last_error();
+                    if (n1 > 0) (void)pais_refine_batch_end(m->lane1, &v1);
+                    return -2;
+                }
+                const double t1 = now_ms();
+                commit_records(m, v0, 0, n0);
+                commitMs += now_ms() - t1;
+            }
+            if (n1 > 0 && pais_refine_batch_end(m->lane1, &v1)) { g_mvs_err = pais_last_error(); return -2; }
+            const double t2 = now_ms();
+            if (n1 > 0) commit_records(m, v1, n0, n);
+            rc = commit_finish(m, n);
+            commitMs += now_ms() - t2;
+            m->st.host_commit_ms += commitMs;
+            if (rc) return rc;
+            // GPU time that the host waited for: from the first launch to the end of the round, less the commits inside it
+            const double tRef = n > 0 ? std::max(0.0, (now_ms() - tFirst) - commitMs) : 0.0;
+            m->st.gpu_refine_ms += tRef;
+            m->st.rounds_streamed++;
+            if (n > 0) m->roundLog.push_back(pais_round_log{n, 0, 0, kmax, tRef, enumMs, commitMs});
+            m->prevHostMs = enumMs + commitMs;
+            m->prevGpuMs = tRef + commitMs; // (what the GPU was busy for, roughly: the wait and the commit inside it)
+            if (max_rounds > 0 && ++rounds >= max_rounds) break;
+            continue;
+        }
         m->results.resize((size_t)(n > 0 ? n : 1));
         const double enumMs = m->lastEnumerateMs;
         double tRef = 0;
@@ -1668,7 +1795,10 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         const double t1 = now_ms();
         rc = pais_mvs_round_commit(m, n > 0 ? recs : m->results.data(), n);
         if (rc) return rc;
-        if (n > 0) m->roundLog.push_back(pais_round_log{n, 0, m->st.batches_sharded > shardedBefore ? 1 : 0, kmax, tRef, enumMs, now_ms() - t1});
+        const double commitMs1 = now_ms() - t1;
+        if (n > 0) m->roundLog.push_back(pais_round_log{n, 0, m->st.batches_sharded > shardedBefore ? 1 : 0, kmax, tRef, enumMs, commitMs1});
+        m->prevHostMs = enumMs + commitMs1;
+        m->prevGpuMs = tRef;
         if (max_rounds > 0 && ++rounds >= max_rounds) break;
     }
     return pais_mvs_expansion_end(m);

@@ -1035,3 +1035,84 @@ def test_wire_slots_packed_on_the_device_are_the_host_statement(pawn_small):
     assert bytes(back) == raw.tobytes()
     ctx.close()
 
+
+
+@pytest.mark.gpu
+def test_streamed_rounds_are_the_same_reconstruction(pawn_small, monkeypatch):
+    """A streamed round (pais_mvs.hip: the first part of the work list is refined on the context while the host enumerates
+    the rest for the lane context, and is committed while the lane still refines) is the same round: the cloud of a streamed
+    reconstruction equals the oracle's patch for patch, and equals the unstreamed one's hash."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS, patches_sha1
+    cfg = readme_config(particleNum=8, maxIteration=12)
+    rows, calls, acc, _ = common.oracle_reconstruct(cfg, pawn_small, 4096, 14)
+    shas = {}
+    for mode, env in (("streamed", {"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_SPLIT": "0.4"}),
+                      ("one batch per round", {"PAIS_STREAM_ROUNDS": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = MVS(cfg, pawn_small.cameras, device=0, seed=42)
+        for X, vis in pawn_small.seeds:
+            m.add_seed(X, vis)
+        m.refineSeedPatches()
+        m.expansionPatches(4096, 14)
+        st = m.stats()
+        got = [(list(p.center[:]), list(p.normalS[:]), p.cams(), p.fitness, p.correlation) for p in m.patches()]
+        assert st.seeds_refined + st.candidates_effective == calls and len(got) == acc, (mode, st.candidates_effective, calls)
+        for i, (a, b) in enumerate(zip(got, rows)):
+            assert a == b, (mode, i, a, b)
+        assert (st.rounds_streamed > 0) == (mode == "streamed"), (mode, st.rounds_streamed, st.rounds)
+        shas[mode] = m.cloud_sha1()
+        m.close()
+    assert shas["streamed"] == shas["one batch per round"] == patches_sha1(rows)
+
+
+@pytest.mark.gpu
+def test_two_lanes_refine_concurrently_like_one(pawn_small):
+    """pais_refine_batch_begin / _end and pais_ctx_fork_lane (include/pais_hip.h): two batches open at once, one on the
+    context and one on its lane, give the records of pais_refine_batch byte for byte; the lane's launches are counted in the
+    parent's kernel statistics; a second _begin on a context with an open batch is refused."""
+    from pais_mvs_amd import _lib
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import Context
+    from oracle import po
+    cfg = readme_config(particleNum=6, maxIteration=8)
+    S = common.oracle_scene(cfg, pawn_small)
+    S.set_kernel_arithmetic(True)
+    parents, seeds = common.seed_candidates(S, pawn_small)
+    ctx = Context(cfg, pawn_small.cameras, device=0, seed=42)
+    kept = [r for r in ctx.refine_batch(seeds) if not r.dropped]
+    assert len(kept) >= 8
+    # expansion candidates around the refined seeds (pure expansion batches are the asynchronous ones)
+    from pais_mvs_amd.context import make_candidate
+    cands = []
+    for i, r in enumerate(kept):
+        for j in range(3):
+            cen = [r.center[0] + 0.002 * (j - 1), r.center[1] + 0.001 * j, r.center[2]]
+            cands.append(make_candidate(cen, list(r.normal[:]), [r.cam_idx[k] for k in range(r.num_cam)], 1000 + 7 * i + j, 1,
+                                        normalS=list(r.normalS[:])))
+    n = len(cands)
+    want = ctx.refine_batch(cands)
+    L = ctx.L
+    ctx.kernel_stats(reset=True)
+    lane = C.c_void_p()
+    assert L.pais_ctx_fork_lane(ctx.h, C.byref(lane)) == 0
+    n0 = n // 3
+    a0 = (_lib.Candidate * n0)(*cands[:n0])
+    a1 = (_lib.Candidate * (n - n0))(*cands[n0:])
+    assert L.pais_refine_batch_open(ctx.h, n0, a0, 2) == 0         # the first two PSO iterations of its launch chain
+    assert L.pais_refine_batch_begin(lane, n - n0, a1) == 0       # a whole chain
+    assert L.pais_refine_batch_begin(ctx.h, n0, a0) != 0          # one open batch per context
+    assert L.pais_refine_batch_enqueue(ctx.h, 3) == 0             # three more: iterations remain
+    assert L.pais_refine_batch_enqueue(lane, 1) == 1              # (nothing left to enqueue there)
+    v0, v1 = C.POINTER(_lib.PatchResult)(), C.POINTER(_lib.PatchResult)()
+    assert L.pais_refine_batch_end(lane, C.byref(v1)) == 0
+    assert L.pais_refine_batch_end(ctx.h, C.byref(v0)) == 0
+    assert L.pais_refine_batch_end(ctx.h, C.byref(v0)) != 0       # nothing open any more
+    sz = C.sizeof(_lib.PatchResult)
+    got = C.string_at(v0, sz * n0) + C.string_at(v1, sz * (n - n0))
+    assert got == bytes(want)
+    ks = ctx.kernel_stats()
+    assert ks.pso_patches == sum(r.pso_runs for r in want) > 0, (ks.pso_patches, n)   # both lanes' runs, counted by the parent
+    ctx.close()
+    S.close()
