@@ -375,7 +375,11 @@ def main():
                        "predicted_speedup_at": scaling_model,
                        "parallelism": "1 process per GPU, candidates of a round sharded over %d GPU(s), one ncclAllGather of the "
                                       "records per sharded round (thin rounds replicated)" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_pso_eval2 (PAIS::getFitness, one wave per candidate x particle; the launches of the large batches)",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_pso_tile (PAIS::getFitness, one workgroup per candidate x 8 particles, camera footprints staged in LDS; "
+                                    "%d of the %d evaluation launches of the large batches, the rest k_pso_eval2)" % (int(ks.tile_launches), e2_n))
+                         if ks.tile_launches * 2 > e2_n else
+                         "k_pso_eval2 (PAIS::getFitness, one wave per candidate x particle; the launches of the large batches)",
                          "achieved": e2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e2_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": e2_n, "avg_launch_ms": e2_ms / e2_n,
                          "algorithmic_bytes_per_launch": ks.eval2_algorithmic_bytes / e2_n,
@@ -388,8 +392,8 @@ def main():
                                                      "achieved_over_pso_pass_wall": (ks.pso_algorithmic_bytes / 1e9) / (ks.pso_ms / 1e3) if ks.pso_ms > 0 else 0.0},
                          # whole reconstruction against the saturated kernel: cost evaluations the sequential order consumed
                          # per second of the timed region / the microbenchmark's rate (profiles/microbench_eval.json)
-                         "evals_per_s": evals_per_s, "microbench_evals_per_s": mb,
-                         "evals_per_s_over_microbench": (evals_per_s / mb) if mb else None,
+                         "evals_per_s": evals_per_s, "microbench_evals_per_s": mb if args.scene == "pawn" else None,
+                         "evals_per_s_over_microbench": (evals_per_s / mb) if (mb and args.scene == "pawn") else None,
                          "note": "rank-0, one extra instrumented step; bytes = S^2*(4K+1+8[dist]+8[grad]) per cost evaluation "
                                  "(SURVEY 8d) x evaluations; durations from HIP events on the launching sub-stream (the two "
                                  "sub-streams' launches overlap, which stretches each).  The kernel is FP64-VALU bound, not HBM "

@@ -268,6 +268,7 @@ typedef struct pais_kernel_stats {
     int64_t  eval2_launches;
     int64_t  eval2_evals;
     double   eval2_algorithmic_bytes;
+    int64_t  tile_launches;      /* of eval2_launches: evaluations by the LDS-tile kernel k_pso_tile (many-camera batches) */
 } pais_kernel_stats;
 int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
 /* on != 0: bracket every cost-evaluation launch (k_pso_iter / k_fitness) with HIP events on the stream it is

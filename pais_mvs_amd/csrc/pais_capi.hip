@@ -132,7 +132,7 @@ struct pais_ctx {
     std::vector<EventPair> evPso, evBegin, evAfter, evEval, evEval2;
     std::vector<EventPair> evFree;
     double psoMs = 0, beginMs = 0, afterMs = 0, evalMs = 0, eval2Ms = 0;
-    int64_t psoLaunches = 0, evalLaunches = 0, eval2Launches = 0;
+    int64_t psoLaunches = 0, evalLaunches = 0, eval2Launches = 0, tileLaunches = 0;
     // lanes (pais_ctx_fork_lane): contexts over this one's scene with their own stream and work buffers
     pais_ctx *parent = nullptr;         // != nullptr: this is a lane; the scene's allocations belong to the parent
     std::vector<pais_ctx *> lanes;
@@ -707,6 +707,7 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
             if (te.end()) return -2;
             ctx->evalLaunches++;
             if (!P.useIter) ctx->eval2Launches++;
+            if (P.useTile) ctx->tileLaunches++;
             if (!P.useIter) HIPCHK(pais_launch::pso_step(sc, P.d_out + q.lo, stp, q.hi - q.lo, P.Nmax, ctx->d_stat, q.st));
         }
     }
@@ -1049,6 +1050,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
         out->eval_launches += c->evalLaunches;
         out->eval2_ms += c->eval2Ms;
         out->eval2_launches += c->eval2Launches;
+        out->tile_launches += c->tileLaunches;
         out->eval2_evals += (int64_t)st[5];
         out->eval2_algorithmic_bytes += (double)st[6] * S2;
         if (reset) {
@@ -1057,6 +1059,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
             c->psoLaunches = 0;
             c->evalLaunches = 0;
             c->eval2Launches = 0;
+            c->tileLaunches = 0;
         }
     }
     return 0;
