@@ -105,7 +105,8 @@ struct pais_ctx {
     long splitAbove = 0;
     int psoMinPer = 64;
     int evalParts = 0;                  // waves per cost evaluation in k_pso_iter (1, 2, 4); 0 = chosen per slice
-    double partFill = 0.75;             // ... such that parts * waves <= partFill * numCUs * 16 (= the 3 waves per SIMD the kernels' registers allow)
+    double partFill = 0.5;              // ... such that parts * waves <= partFill * numCUs * 16 (= the 2 waves per SIMD that the multi-wave kernels'
+                                        // 192 registers allow: they are built without an occupancy target, pais_kernels.hip PAIS_ITER_BOUNDS)
     int psoStreams = 2;
     int tileStrip2 = 14, tileStrip1 = 24; // 64-pixel steps per strip of the two instantiations (PAIS_TILE_STRIP2 / PAIS_TILE_STRIP1)
     int tileForceNs1 = 0;               // PAIS_TILE_FORCE_NS1 (tests): the one-pixel instantiation also for batches of <= 32 cameras

@@ -65,6 +65,13 @@ using namespace pais;
 #define PAIS_NS2_WAVES 3
 #endif
 #define PAIS_EVAL_BOUNDS(NS) __launch_bounds__(64 * PAIS_WG_WAVES, (NS) == 1 ? PAIS_NS1_WAVES : PAIS_NS2_WAVES)
+// k_pso_iter launches that share an evaluation among several waves run with the GPU nearly empty and are bound by the latency
+// of one wave: no occupancy to protect, so the register allocator gets the whole file (no scratch reloads -- each a memory
+// round trip -- on the step replay's critical path)
+#ifndef PAIS_ITER_FREE_REGS_FROM
+#define PAIS_ITER_FREE_REGS_FROM 2
+#endif
+#define PAIS_ITER_BOUNDS(P, NS) __launch_bounds__(64 * PAIS_WG_WAVES, (P) >= PAIS_ITER_FREE_REGS_FROM ? 1 : ((NS) == 1 ? PAIS_NS1_WAVES : PAIS_NS2_WAVES))
 //   PAIS_TWO_PIXELS_MAXK  largest camera count of a batch that still runs two window pixels per lane (NS = 2)
 #ifndef PAIS_TWO_PIXELS_MAXK
 #define PAIS_TWO_PIXELS_MAXK 6
@@ -821,6 +828,44 @@ __device__ __forceinline__ int wave_argmin_lex(bool valid, double key, int tie)
     return v ? t : -1;
 }
 
+// The same selection for a swarm that sits in lanes 0 .. N-1 of the first DPP row(s) (N <= 32: every swarm of an expansion
+// candidate or seed with the README's particle count): the exchanges inside a row of 16 lanes are DPP operand modifiers of
+// ordinary VALU moves (row_mirror, row_half_mirror, two quad permutations -- four symmetric pairings that together connect
+// all 16 lanes) instead of ds_bpermute round trips through the LDS crossbar (~130 cycles each; the step replay of a latency-
+// bound launch is a chain of four such selections: measured 16.6 k of the 34 k cycles of a thin launch's wave).  (key, tie)
+// pairs are distinct, so any all-to-all pairing order selects the same winner.  Result of lane 0, broadcast.
+template <int CTRL> __device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ void argmin_dpp_step(double &k, int &t, int &v)
+{
+    const int olo = dpp_mov_i<CTRL>(__double2loint(k)), ohi = dpp_mov_i<CTRL>(__double2hiint(k));
+    const int ot = dpp_mov_i<CTRL>(t), ov = dpp_mov_i<CTRL>(v);
+    const double ok = __hiloint2double(ohi, olo);
+    const bool take = ov && (!v || ok < k || (ok == k && ot < t));
+    k = take ? ok : k;
+    t = take ? ot : t;
+    v = take ? 1 : v;
+}
+__device__ __forceinline__ int wave_argmin_lex_n(bool valid, double key, int tie, int N)
+{
+    if (N > 32) return wave_argmin_lex(valid, key, tie);
+    double k = key;
+    int t = tie;
+    int v = valid ? 1 : 0;
+    if (N > 16) { // rows 0 and 1 first (one crossbar exchange)
+        const double ok = __shfl_xor(k, 16, 64);
+        const int ot = __shfl_xor(t, 16, 64), ov = __shfl_xor(v, 16, 64);
+        const bool take = ov && (!v || ok < k || (ok == k && ot < t));
+        k = take ? ok : k;
+        t = take ? ot : t;
+        v = take ? 1 : v;
+    }
+    argmin_dpp_step<0x140>(k, t, v); // row_mirror: lane i <-> 15 - i
+    argmin_dpp_step<0x141>(k, t, v); // row_half_mirror: i <-> 7 - i
+    argmin_dpp_step<0x1B>(k, t, v);  // quad_perm [3, 2, 1, 0]
+    argmin_dpp_step<0xB1>(k, t, v);  // quad_perm [1, 0, 3, 2]
+    return __builtin_amdgcn_readfirstlane(v ? t : -1);
+}
+
 // moveParticles for particle i with the swarm in lanes (lane j = particle j, N <= 64): same selections as
 // pso_move_particle (pais_dev.hpp), evaluated across lanes
 __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw, const double *u, const double *pos,
@@ -850,7 +895,7 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
         rank += (o < dj || (o == dj && j < lane)) ? 1 : 0;
     }
     const bool sel = pv && rank < localK;
-    const int w = wave_argmin_lex(sel && pbf < DBL_MAX, pbf, rank * 64 + lane);
+    const int w = wave_argmin_lex_n(sel && pbf < DBL_MAX, pbf, rank * 64 + lane, N);
     const int lIdx = (w < 0) ? i : (w & 63);
     // setNearNeighborBest: per dimension the first maximum of the fitness-distance ratio
     const double fitI = lane_get(fitj, i);
@@ -858,7 +903,7 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
         const double pd = lane_get(pos[d], i);
         const double FDR = (fitI - pbf) / fabs(pd - pb[d]);
         const bool cand = pv && lane != i && FDR > -DBL_MAX;
-        const int wn = wave_argmin_lex(cand, -FDR, lane);
+        const int wn = wave_argmin_lex_n(cand, -FDR, lane, N);
         const double o = lane_get(pb[d], wn < 0 ? 0 : wn);
         outNb[d] = (wn < 0) ? nbI[d] : o;
     }
@@ -880,7 +925,7 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
 // NS = 2 (3 waves per SIMD) for patches seen by few cameras, NS = 1 (4 waves per SIMD) beyond: a wave's LDS scratch
 // grows with NS * K and caps the occupancy (measured: K ~ 4: NS 2 +3 %, K ~ 7: NS 1 +9 %)
 template <int nparts, int NS, bool BYTES, bool ACCR>
-__global__ PAIS_EVAL_BOUNDS(NS) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
+__global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned char *states, const int *activeList,
                                             const int *activeCount, int listLo, int listHi, int Nmax, int Kmax,
                                             pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                                             const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win)
