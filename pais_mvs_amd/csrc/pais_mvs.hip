@@ -1226,6 +1226,7 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
     if (B < 1) B = 1;
     *cands = nullptr;
     *n = 0;
+    m->firstPart = -1; // (set below if this round's first part is handed out early)
     while ((int)m->active.size() < B && !m->queueExhausted) {
         int id = m->queuePop();
         if (id < 0) break;
