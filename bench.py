@@ -382,6 +382,11 @@ def main():
                          "k_pso_eval2 (PAIS::getFitness, one wave per candidate x particle; the launches of the large batches)",
                          "achieved": e2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e2_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": e2_n, "avg_launch_ms": e2_ms / e2_n,
+                         # the launches overlap on two sub-streams (each is stretched by its neighbour): the same bytes over
+                         # the time during which at least one of them was running (union of their HIP-event intervals)
+                         "busy_ms": ks.eval2_busy_ms,
+                         "achieved_over_busy_time": ((ks.eval2_algorithmic_bytes / 1e9) / (ks.eval2_busy_ms / 1e3)) if ks.eval2_busy_ms > 0 else None,
+                         "frac_over_busy_time": ((ks.eval2_algorithmic_bytes / 1e9) / (ks.eval2_busy_ms / 1e3) / HBM_PEAK_GBS) if ks.eval2_busy_ms > 0 else None,
                          "algorithmic_bytes_per_launch": ks.eval2_algorithmic_bytes / e2_n,
                          "evals": int(ks.eval2_evals),
                          "algorithmic_bytes_per_eval": (ks.eval2_algorithmic_bytes / ks.eval2_evals) if ks.eval2_evals else 0,

@@ -269,6 +269,10 @@ typedef struct pais_kernel_stats {
     int64_t  eval2_evals;
     double   eval2_algorithmic_bytes;
     int64_t  tile_launches;      /* of eval2_launches: evaluations by the LDS-tile kernel k_pso_tile (many-camera batches) */
+    /* the launches of eval2_ms run on two (streamed rounds: up to four) streams at once, which stretches each of them:
+     * eval2_busy_ms is the length of the UNION of their [start, end] intervals -- the time during which at least one of
+     * them was running (<= eval2_ms; 0 unless fine timing was on) */
+    double   eval2_busy_ms;
 } pais_kernel_stats;
 int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
 /* on != 0: bracket every cost-evaluation launch (k_pso_iter / k_fitness) with HIP events on the stream it is

@@ -11,6 +11,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/pais_hip.h"
 #include "pais_dev.hpp"
@@ -133,6 +134,8 @@ struct pais_ctx {
     std::vector<EventPair> evPso, evBegin, evAfter, evEval, evEval2;
     std::vector<EventPair> evFree;
     double psoMs = 0, beginMs = 0, afterMs = 0, evalMs = 0, eval2Ms = 0;
+    hipEvent_t refEv = nullptr;         // common time origin of the evEval2 intervals (recorded when fine timing is switched on; a lane uses its parent's)
+    std::vector<std::pair<float, float>> eval2Intervals; // [start, end] of the drained evEval2 pairs, ms since refEv
     int64_t psoLaunches = 0, evalLaunches = 0, eval2Launches = 0, tileLaunches = 0;
     // lanes (pais_ctx_fork_lane): contexts over this one's scene with their own stream and work buffers
     pais_ctx *parent = nullptr;         // != nullptr: this is a lane; the scene's allocations belong to the parent
@@ -404,6 +407,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     for (auto st : ctx->sub) (void)hipStreamDestroy(st);
     for (auto ev : ctx->subDone) (void)hipEventDestroy(ev);
     if (ctx->forkEv) (void)hipEventDestroy(ctx->forkEv);
+    if (ctx->refEv) (void)hipEventDestroy(ctx->refEv);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_imgF); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
     (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active); (void)hipFree(ctx->d_evalBlocks); (void)hipHostFree(ctx->h_cands); (void)hipHostFree(ctx->h_recs);
@@ -561,6 +565,12 @@ extern "C" int pais_neighbor_count(pais_ctx *ctx, int n, const double *centers, 
 extern "C" int pais_ctx_set_fine_timing(pais_ctx *ctx, int on)
 {
     if (!ctx) return fail_msg("pais_ctx_set_fine_timing: bad argument");
+    if (on && !ctx->parent) {
+        HIPCHK(hipSetDevice(ctx->device));
+        if (!ctx->refEv) HIPCHK(hipEventCreate(&ctx->refEv));
+        HIPCHK(hipEventRecord(ctx->refEv, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     ctx->fineTiming = on != 0;
     for (pais_ctx *l : ctx->lanes) l->fineTiming = on != 0;
     return 0;
@@ -1005,6 +1015,13 @@ static int collect_stats(pais_ctx *ctx, unsigned long long *st)
     if (drain_events(ctx, ctx->evEval, ctx->evalMs)) return -2;
     {
         double ms2 = 0;
+        hipEvent_t ref = ctx->parent ? ctx->parent->refEv : ctx->refEv;
+        if (ref)
+            for (auto &p : ctx->evEval2) {
+                float a = 0, b = 0;
+                if (hipEventElapsedTime(&a, ref, p.a) == hipSuccess && hipEventElapsedTime(&b, ref, p.b) == hipSuccess)
+                    ctx->eval2Intervals.push_back(std::make_pair(a, b));
+            }
         if (drain_events(ctx, ctx->evEval2, ms2)) return -2;
         ctx->eval2Ms += ms2;
         ctx->evalMs += ms2;
@@ -1034,6 +1051,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
     all.insert(all.end(), ctx->lanes.begin(), ctx->lanes.end());
     memset(out, 0, sizeof(*out));
     const double S2 = (double)ctx->sc.cfg.patchSize * ctx->sc.cfg.patchSize;
+    std::vector<std::pair<float, float>> iv;
     for (pais_ctx *c : all) {
         unsigned long long st[24];
         const int rc = collect_stats(c, st);
@@ -1052,6 +1070,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
         out->eval2_ms += c->eval2Ms;
         out->eval2_launches += c->eval2Launches;
         out->tile_launches += c->tileLaunches;
+        iv.insert(iv.end(), c->eval2Intervals.begin(), c->eval2Intervals.end());
         out->eval2_evals += (int64_t)st[5];
         out->eval2_algorithmic_bytes += (double)st[6] * S2;
         if (reset) {
@@ -1061,7 +1080,23 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
             c->evalLaunches = 0;
             c->eval2Launches = 0;
             c->tileLaunches = 0;
+            c->eval2Intervals.clear();
         }
     }
+    // union of the evaluation launches' intervals (all streams, all lanes)
+    std::sort(iv.begin(), iv.end());
+    double busy = 0;
+    float curA = 0, curB = -1;
+    for (auto &p : iv) {
+        if (curB < curA || p.first > curB) {
+            if (curB >= curA) busy += curB - curA;
+            curA = p.first;
+            curB = p.second;
+        } else if (p.second > curB) {
+            curB = p.second;
+        }
+    }
+    if (curB >= curA) busy += curB - curA;
+    out->eval2_busy_ms = busy;
     return 0;
 }
