@@ -67,8 +67,8 @@ __device__ __forceinline__ int clamp_i32(int v, int lo, int hi)
 // BYTES = false: from the float2 copy {I, dI}; BYTES = true: two adjacent bytes of the byte blob (pais_internal.h).
 template <bool BYTES> struct Tap;
 template <> struct Tap<false> {
-    typedef float2 Row;
-    static constexpr uint32_t kElem = 8;
+    typedef PaisImgT Row;
+    static constexpr uint32_t kElem = sizeof(PaisImgT);
     static __device__ __forceinline__ const unsigned char *blob(const DevScene &sc) { return (const unsigned char *)sc.imgF; }
 };
 template <> struct Tap<true> {
@@ -95,6 +95,10 @@ __device__ __forceinline__ double lerp3(double i00, double d0, double i01, doubl
 __device__ __forceinline__ double lerp3(float2 r0, float2 r1, double bx, double by)
 {
     return lerp3((double)r0.x, (double)r0.y, (double)r1.x, (double)r1.y, bx, by);
+}
+__device__ __forceinline__ double lerp3(double2 r0, double2 r1, double bx, double by)
+{
+    return lerp3(r0.x, r0.y, r1.x, r1.y, bx, by);
 }
 __device__ __forceinline__ double lerp3(uint16_t r0, uint16_t r1, double bx, double by)
 {

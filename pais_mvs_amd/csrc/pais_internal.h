@@ -41,7 +41,14 @@ struct DevCamera {
 //                                 of pyramids, and the taps of a batch stop missing L2 / the TLB); equal on the ring.
 // pais_create expands the float2 copy when the byte pyramids are at most PAIS_TAP_FLOAT_MAX_MB (default 256 MB, i.e. a
 // 2 GB copy); larger scenes run the BYTES instantiations of the evaluation kernels.
+#ifndef PAIS_TAP_DOUBLE
+#define PAIS_TAP_DOUBLE 0
+#endif
+#if PAIS_TAP_DOUBLE
+typedef double2 PaisImgT; // experiment: no conversion at the tap, twice the bytes again
+#else
 typedef float2 PaisImgT;
+#endif
 
 struct DevScene {
     pais_config cfg;
