@@ -55,7 +55,7 @@ struct Timed {
 struct PassPlan {
     struct Slice { int lo, hi, parts; hipStream_t st; bool own; };
     int n = 0, Nmax = 0, Kmax = 0, maxIt = 0, nSl = 0, S = 1, afterGrid = 0, itNext = 0;
-    bool useIter = false, useTile = false;
+    bool useIter = false, useTile = false, useRing = false, hasSeeds = false, hostBatch = false;
     Slice sl[16];
     int *cnt = nullptr, *nextCnt = nullptr;
     size_t SB = 0, EB = 0, WB = 0;
@@ -141,6 +141,15 @@ struct pais_ctx {
     pais_ctx *parent = nullptr;         // != nullptr: this is a lane; the scene's allocations belong to the parent
     std::vector<pais_ctx *> lanes;
     int openBatch = -1;                 // records of the batch between pais_refine_batch_begin and _end (-1: none)
+    // k_pso_ring (pais_kernels.hip): the PSO pass of a large expansion batch as ONE launch over a device-side task ring
+    int ringMode = 1;                   // PAIS_PSO_RING=0: large batches take the per-iteration launches (k_pso_eval2 + k_pso_step) instead
+    unsigned *d_ring = nullptr;         // task ring
+    size_t ringBytes = 0;
+    unsigned *d_ringCtl = nullptr;      // head, tail, done, error
+    unsigned *h_ringCtl = nullptr;      // pinned copy, read when the batch ends
+    int *d_arrive = nullptr;            // per candidate: evaluations of the current iteration that have been delivered
+    size_t arriveBytes = 0;
+    bool ringUsed = false;              // by the open batch
     PassPlan plan;                      // of the open batch (pais_refine_batch_open .. _enqueue)
     bool planDone = true;               // the open batch is enqueued to its end
     int roundHint = 0;                  // pais_ctx_set_round_hint: candidates of the round the next batch is a part of (0: it is the round)
@@ -359,6 +368,11 @@ static int ctx_init_work(pais_ctx *ctx)
     if (const char *e = getenv("PAIS_SPLIT_ABOVE")) { long v = atol(e); if (v > 0) ctx->splitAbove = v; }
     if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
+    if (const char *e = getenv("PAIS_PSO_RING")) ctx->ringMode = atoi(e);
+    HIPCHK(hipMalloc(&ctx->d_ringCtl, 64 * 8));
+    HIPCHK(hipMemset(ctx->d_ringCtl, 0, 64 * 8));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_ringCtl, 64 * 8, hipHostMallocDefault));
+    memset(ctx->h_ringCtl, 0, 64 * 8);
     if (const char *e = getenv("PAIS_TILE")) ctx->tileMode = atoi(e);
     if (const char *e = getenv("PAIS_TILE_DEBUG")) ctx->tileDebug = atoi(e) != 0;
     if (const char *e = getenv("PAIS_TILE_VERIFY")) ctx->tileVerify = atoi(e) != 0;
@@ -408,6 +422,8 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     for (auto ev : ctx->subDone) (void)hipEventDestroy(ev);
     if (ctx->forkEv) (void)hipEventDestroy(ctx->forkEv);
     if (ctx->refEv) (void)hipEventDestroy(ctx->refEv);
+    (void)hipFree(ctx->d_ring); (void)hipFree(ctx->d_ringCtl); (void)hipFree(ctx->d_arrive);
+    if (ctx->h_ringCtl) (void)hipHostFree(ctx->h_ringCtl);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_imgF); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
     (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_stat); (void)hipFree(ctx->d_active); (void)hipFree(ctx->d_evalBlocks); (void)hipHostFree(ctx->h_cands); (void)hipHostFree(ctx->h_recs);
@@ -656,10 +672,16 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
     const int nPlan = ctx->roundHint > n ? ctx->roundHint : n;
     P.useIter = Nmax <= 64 && (long)nPlan * Nmax < (tileOk ? ctx->tileAbove : ctx->splitAbove);
     P.useTile = tileOk && !P.useIter;
+    // the large-batch pipeline as one launch over a task ring (host batches only: the error word is read when the batch ends)
+    P.useRing = ctx->ringMode != 0 && P.hostBatch && !P.hasSeeds && !P.useIter && !P.useTile && Nmax <= 64;
+    if (P.useRing) {
+        if (grow(ctx, ctx->d_ring, ctx->ringBytes, pais_launch::ring_words(n, Nmax, P.maxIt) * sizeof(unsigned))) return -2;
+        if (grow(ctx, ctx->d_arrive, ctx->arriveBytes, sizeof(int) * (size_t)n)) return -2;
+    }
     // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
     // its length is n at most in the first pass and exactly the "again" count afterwards
     const int nRun = P.useIter ? (pass == 0 ? n : againCount) : n;
-    int S = ctx->psoStreams;
+    int S = P.useRing ? 1 : ctx->psoStreams;
     if (nPlan > n) S = (int)((double)S * n / nPlan + 0.5); // the round's sub-streams are shared out among its parts
     const int minPer = ctx->psoMinPer; // slices smaller than this only add launch overhead
     if (nRun < S * minPer) S = (nRun + minPer - 1) / minPer;
@@ -694,6 +716,21 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
 {
     const DevScene &sc = ctx->sc;
     if (itEnd > P.maxIt + 1) itEnd = P.maxIt + 1;
+    if (P.useRing) {
+        if (P.itNext == 0 && itEnd > 0) {
+            Timed te;
+            if (te.begin(ctx, ctx->stream, &ctx->evEval2)) return -2;
+            HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, ctx->numCUs, ctx->stream));
+            if (te.end()) return -2;
+            HIPCHK(hipMemcpyAsync(ctx->h_ringCtl, ctx->d_ringCtl, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->ringUsed = true;
+            ctx->evalLaunches++;
+            ctx->eval2Launches++;
+            P.itNext = P.maxIt + 1; // the launch covers every iteration of the pass
+        }
+        return 0;
+    }
     // enqueued iteration by iteration across the slices: every sub-stream has work from the start (slice by slice, the
     // second slice would begin one host enqueue pass -- 62 launches -- after the first)
     for (int it = P.itNext; it < itEnd; ++it) {
@@ -781,6 +818,7 @@ static int batch_setup(pais_ctx *ctx, PassPlan &P, int n, const pais_candidate *
     if (grow(ctx, ctx->d_psoStates, ctx->psoStateBytes, SB * (size_t)n)) return -2;
     if (grow(ctx, ctx->d_ratios, ctx->ratioBytes, sizeof(double) * PAIS_MAX_VIS * (size_t)n)) return -2;
     P.n = n;
+    P.hasSeeds = has_seeds != 0;
     P.Nmax = Nmax;
     P.Kmax = Kmax;
     P.afterGrid = afterGrid;
@@ -809,6 +847,7 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     if (!d_cands || !d_out) return fail_msg("pais_refine_batch_device: null pointer");
     if (ctx->openBatch >= 0) return fail_msg("pais_refine_batch_device: a batch is open on this context");
     PassPlan &P = ctx->plan;
+    P.hostBatch = false;
     int rc = batch_setup(ctx, P, n, d_cands, d_out, max_num_cam, has_seeds);
     int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
     const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
@@ -886,6 +925,18 @@ extern "C" int pais_refine_batch_end(pais_ctx *ctx, const pais_patch_result **vi
     ctx->openBatch = -1;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->ringUsed) {
+        ctx->ringUsed = false;
+        // per ring {head, tail, done, total, error}: a wave that ran out of patience, or runs that never ended
+        unsigned done = 0, err = 0;
+        for (int r = 0; r < 8; ++r) { done += ctx->h_ringCtl[16 * r + 2]; err |= ctx->h_ringCtl[16 * r + 4]; }
+        if (err != 0 || done != (unsigned)ctx->plan.n) {
+            ctx->countersDirty = true;
+            char msg[160];
+            snprintf(msg, sizeof(msg), "k_pso_ring did not complete (error %u, %u of %d runs ended)", err, done, ctx->plan.n);
+            return fail_msg(msg);
+        }
+    }
     *view = ctx->h_recs;
     return 0;
 }
@@ -931,6 +982,8 @@ extern "C" int pais_refine_batch_open(pais_ctx *ctx, int n, const pais_candidate
         return 0;
     }
     PassPlan &P = ctx->plan;
+    P.hostBatch = true;
+    ctx->ringUsed = false;
     int rc = batch_setup(ctx, P, n, ctx->d_cands, ctx->d_recs, Kmax, 0);
     if (!rc) rc = pass_open(ctx, P, 0, 0);
     ctx->roundHint = 0;

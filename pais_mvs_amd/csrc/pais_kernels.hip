@@ -1138,6 +1138,28 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
 // Everything of PsoSolver::run() between two fitness passes, for ONE candidate, by one wave.
 // smem: Nmax*(3*4+2) doubles of LDS scratch.
 // Everything it reads was written by a previous launch.  Returns 1 if the run continues.
+// Device-coherent access to the swarm state (k_pso_ring: the state of a candidate is handed from wave to wave INSIDE a launch,
+// across XCDs with their own L2): agent-scope relaxed atomics compile to plain loads / stores with the sc1 bit -- served
+// at the device's coherence point, no fence, no cache invalidation under the image taps.
+__device__ __forceinline__ double cload(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void cstore(double *p, double v)
+{
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int cload(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool COH, class T> __device__ __forceinline__ T sload(const T *p) { return COH ? cload(p) : *p; }
+template <bool COH, class T> __device__ __forceinline__ void sstore(T *p, T v)
+{
+    if (COH) cstore(p, v);
+    else *p = v;
+}
+
+// COH: the state was written by another wave of THIS launch (k_pso_ring) and is read / written coherently
+template <bool COH = false>
 __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
                                unsigned char *smem, unsigned long long *stat, int lane)
 {
@@ -1152,20 +1174,20 @@ __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c,
     __syncthreads();
     for (int i = lane; i < N; i += 64) {
         for (int d = 0; d < 3; ++d) {
-            pos[i][d] = A.pos[i][d];
-            vec[i][d] = A.vec[i][d];
-            pBest[i][d] = A.pBest[i][d];
-            nBest[i][d] = A.nBest[i][d];
+            pos[i][d] = sload<COH>(&A.pos[i][d]);
+            vec[i][d] = sload<COH>(&A.vec[i][d]);
+            pBest[i][d] = sload<COH>(&A.pBest[i][d]);
+            nBest[i][d] = sload<COH>(&A.nBest[i][d]);
         }
-        fit[i] = A.fit[i];
-        pBestFit[i] = A.pBestFit[i];
+        fit[i] = sload<COH>(&A.fit[i]);
+        pBestFit[i] = sload<COH>(&A.pBestFit[i]);
     }
     __syncthreads();
-    int it = hd->iteration;
-    int g = hd->gIdx;
-    double gf = hd->gBestFitness;
-    double iw = hd->iw;
-    const int started = hd->started;
+    int it = sload<COH>(&hd->iteration);
+    int g = sload<COH>(&hd->gIdx);
+    double gf = sload<COH>(&hd->gBestFitness);
+    double iw = sload<COH>(&hd->iw);
+    const int started = sload<COH>(&hd->started);
     if (!started) {
         // initFitness (:112-119) + run(): gBest = particles[0].pBest; updateGbest (:137-149)
         for (int i = lane; i < N; i += 64) pBestFit[i] = fit[i];
@@ -1231,19 +1253,19 @@ __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c,
         __syncthreads();
         for (int i = lane; i < N; i += 64) {
             for (int d = 0; d < 3; ++d) {
-                A.pos[i][d] = pos[i][d];
-                A.vec[i][d] = vec[i][d];
-                A.pBest[i][d] = pBest[i][d];
-                A.nBest[i][d] = nBest[i][d];
+                sstore<COH>(&A.pos[i][d], pos[i][d]);
+                sstore<COH>(&A.vec[i][d], vec[i][d]);
+                sstore<COH>(&A.pBest[i][d], pBest[i][d]);
+                sstore<COH>(&A.nBest[i][d], nBest[i][d]);
             }
-            A.pBestFit[i] = pBestFit[i];
+            sstore<COH>(&A.pBestFit[i], pBestFit[i]);
         }
         if (lane == 0) {
-            hd->iteration = it;
-            hd->gIdx = g;
-            hd->gBestFitness = gf;
-            hd->iw = iw;
-            hd->started = 1;
+            sstore<COH>(&hd->iteration, it);
+            sstore<COH>(&hd->gIdx, g);
+            sstore<COH>(&hd->gBestFitness, gf);
+            sstore<COH>(&hd->iw, iw);
+            sstore<COH>(&hd->started, 1);
         }
         return 1;
     } else if (lane == 0) {
@@ -1295,6 +1317,131 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         if (!hd->active) continue;
         pso_step_wave(sc, recs, c, hd, Nmax, smem, stat, lane);
+    }
+}
+
+// ---------------------------------------------------------------- k_pso_ring ---
+// A PSO pass of a large batch WITHOUT per-iteration launches.  Iteration i + 1 of a candidate depends on that candidate's N
+// evaluations of iteration i and on nothing else, so the pass is a pool of tasks -- (candidate, particle): evaluate the
+// particle where it stands -- on a ring in global memory, worked off by a fixed set of resident waves:
+//   * a wave takes the next ring index (one atomic), waits until that entry is published, evaluates, stores the fitness
+//     and counts itself in at the candidate (one atomic);
+//   * the wave that completes a candidate's count runs the candidate's swarm step (pso_step_wave: the code of k_pso_step)
+//     and publishes the N tasks of the next iteration at the ring's tail -- or the result, if the run has ended.
+// Nobody waits for a particular wave: an index beyond the published tail is only ever held by a wave that would otherwise be
+// idle, and the tasks whose completion will publish it are being executed by waves that are not waiting -- no deadlock, with
+// any number of resident waves.  The swarm state crosses waves (and XCDs) through sc1 loads / stores (cload / cstore above);
+// a payload is complete (s_waitcnt vmcnt(0)) before the atomic that lets another wave look at it.  Every wait is bounded: a
+// wave that polls PAIS_RING_SPIN_LIMIT times raises the error word and leaves; the host fails the batch.
+// Same evaluation code, same step code, per-candidate order of operations unchanged: the records are those of
+// k_pso_eval2 + k_pso_step bit for bit.
+#define PAIS_RING_EMPTY 0xFFFFFFFFu
+#ifndef PAIS_RING_SPIN_LIMIT
+#define PAIS_RING_SPIN_LIMIT 1000000
+#endif
+#define PAIS_RINGS 8 // one ring per XCD (workgroup b runs on XCD b % 8): a ring's counters and its candidates' state stay in one L2
+struct RingCtl { unsigned head, tail, done, total, error, pad[11]; }; // one 64-byte line per ring
+
+// candidates c with c % PAIS_RINGS == r belong to ring r; its segment of the ring memory starts at r * segWords
+// tasks of iteration 0 (the initial swarm); candidates whose refinement ended in k_begin count as done
+__global__ __launch_bounds__(256) void k_ring_init(unsigned char *states, int n, int Nmax, unsigned *ring, unsigned segWords, RingCtl *ctl)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    RingCtl *rc = &ctl[c % PAIS_RINGS];
+    atomicAdd(&rc->total, 1u);
+    const PsoState *hd = (const PsoState *)(states + pso_state_bytes(Nmax) * (size_t)c);
+    if (!hd->active) {
+        atomicAdd(&rc->done, 1u);
+        return;
+    }
+    const int N = hd->N;
+    const unsigned base = atomicAdd(&rc->tail, (unsigned)N);
+    unsigned *seg = ring + (size_t)(c % PAIS_RINGS) * segWords;
+    for (int j = 0; j < N; ++j) seg[base + j] = ((unsigned)c << 8) | (unsigned)j;
+}
+
+template <int NS, bool BYTES, bool ACCR>
+__global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax,
+                                                const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win, unsigned *ringAll,
+                                                unsigned segWords, RingCtl *ctlAll, int *arrive, unsigned long long *stat, size_t ldsPerWave)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
+    unsigned char *smem = smem0 + (threadIdx.x >> 6) * ldsPerWave; // wave-private scratch (evaluation; the step reuses it)
+    EvalPatch *ep = (EvalPatch *)smem;
+    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
+    double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
+    double *cbuf = Hbuf + Kmax * PAIS_H_STRIDE;
+    const int lane = threadIdx.x & 63;
+    const size_t SB = pso_state_bytes(Nmax);
+    const int WS = win_stride(sc);
+    const int nwMax = (int)(eval_block_bytes(Kmax) / 8);
+    const int myRing = (int)(blockIdx.x % PAIS_RINGS);
+    RingCtl *ctl = &ctlAll[myRing];
+    unsigned *ring = ringAll + (size_t)myRing * segWords;
+    const unsigned cap = segWords;
+    const unsigned total = ctl->total; // (written by k_ring_init, before this launch)
+    for (;;) {
+        unsigned idx = 0;
+        if (lane == 0) idx = __hip_atomic_fetch_add(&ctl->head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx >= cap) break;
+        unsigned e = PAIS_RING_EMPTY;
+        for (int spins = 0;; ++spins) {
+            e = __hip_atomic_load(&ring[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e != PAIS_RING_EMPTY) break;
+            if ((spins & 7) == 7) { // (the shared words are looked at now and then: thousands of idle waves poll)
+                if (__hip_atomic_load(&ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break; // every run of this ring has ended
+                if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            }
+            if (spins > PAIS_RING_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
+        if (e == PAIS_RING_EMPTY) break;
+        const int c = (int)(e >> 8), i = (int)(e & 255u);
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+        const double p0 = cload(&A.pos[i][0]), p1 = cload(&A.pos[i][1]), p2 = cload(&A.pos[i][2]);
+        const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0;
+        const int N = hd->N; // (written by k_begin, before this launch)
+        wave_sync();
+        stage_eval_block(smem, src, nwMax, lane, v0, v1);
+        wave_sync();
+        double f4[4], w4[4];
+        const int st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
+        int old = 0;
+        if (lane == 0) {
+            cstore(&A.fit[i], st ? DBL_MAX : combine_parts(f4, w4));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the fitness is at the coherence point before it is counted
+            old = __hip_atomic_fetch_add(&arrive[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != N - 1) continue;
+        // this wave completed the candidate's iteration: its swarm step, then the next iteration's tasks (or the result)
+        __builtin_amdgcn_s_setprio(3); // the step sits on the candidate's critical path
+        if (lane == 0) cstore(&arrive[c], 0);
+        wave_sync();
+        const int cont = pso_step_wave<true>(sc, recs, c, hd, Nmax, smem, stat, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every lane's part of the new swarm (and the counter reset) is out
+        wave_sync();
+        if (__builtin_amdgcn_readfirstlane(cont)) {
+            unsigned base = 0;
+            if (lane == 0) base = __hip_atomic_fetch_add(&ctl->tail, (unsigned)N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + (unsigned)N > cap) { // cannot happen (a segment holds every task of its candidates); never write past it
+                if (lane == 0) __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            if (lane < N) __hip_atomic_store(&ring[base + lane], ((unsigned)c << 8) | (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0) {
+            __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -1789,6 +1936,46 @@ hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *active
     if (nparts == 2) { PAIS_SHAPE_DISPATCH(pso_iter_launch2, PAIS_ARGS); }
     PAIS_SHAPE_DISPATCH(pso_iter_launch1, PAIS_ARGS);
 #undef PAIS_ARGS
+}
+// k_pso_ring: a whole PSO pass of a large batch in one launch (ring: n * Nmax * (maxIt + 2) words, ctl: 8 words, arrive: n ints --
+// all zeroed / emptied here).  waves: resident waves to work the ring off with.
+static size_t ring_seg_words(int n, int Nmax, int maxIt) { return (size_t)((n + PAIS_RINGS - 1) / PAIS_RINGS) * Nmax * ((size_t)maxIt + 2); }
+size_t ring_words(int n, int Nmax, int maxIt) { return ring_seg_words(n, Nmax, maxIt) * PAIS_RINGS; }
+template <int NS, bool BYTES, bool ACCR>
+static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
+                                  const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive,
+                                  unsigned long long *stat, int waves, hipStream_t stream)
+{
+    static LdsAttr attr;
+    size_t per = eval_lds_bytes(NS, Kmax, ACCR);
+    const size_t stepBytes = sizeof(double) * (size_t)Nmax * (3 * 4 + 2) + 16;
+    if (per < stepBytes) per = stepBytes;
+    per = (per + 15) & ~(size_t)15;
+    const size_t lds = per * PAIS_WG_WAVES;
+    hipError_t e = attr.ensure((const void *)k_pso_ring<NS, BYTES, ACCR>, lds);
+    if (e != hipSuccess) return e;
+    const size_t words = ring_words(n, Nmax, maxIt), seg = ring_seg_words(n, Nmax, maxIt);
+    if (seg >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    e = hipMemsetAsync(ring, 0xFF, words * sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ctl, 0, sizeof(RingCtl) * PAIS_RINGS, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(arrive, 0, sizeof(int) * (size_t)n, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ring_init, dim3((n + 255) / 256), dim3(256), 0, stream, states, n, Nmax, ring, (unsigned)seg, (RingCtl *)ctl);
+    long tasks = (long)n * Nmax;
+    waves *= (NS == 1 ? 4 * PAIS_NS1_WAVES : 4 * PAIS_NS2_WAVES); // `waves` arrives as the number of CUs: resident waves per CU by shape
+    int grid = (int)(tasks < waves ? tasks : waves);
+    grid = (grid + PAIS_RINGS - 1) / PAIS_RINGS * PAIS_RINGS;
+    hipLaunchKernelGGL((k_pso_ring<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, recs, states, n, Nmax, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win, ring, (unsigned)seg, (RingCtl *)ctl, arrive, stat, per);
+    return hipGetLastError();
+}
+hipError_t pso_ring(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
+                    const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive, unsigned long long *stat,
+                    int waves, hipStream_t stream)
+{
+    PAIS_SHAPE_DISPATCH(pso_ring_launch, sc, recs, states, n, Nmax, Kmax, maxIt, evalBlocks, win, ring, ctl, arrive, stat, waves, stream);
 }
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                     unsigned long long *stat, hipStream_t stream)
