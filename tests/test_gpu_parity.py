@@ -1116,3 +1116,46 @@ def test_two_lanes_refine_concurrently_like_one(pawn_small):
     assert ks.pso_patches == sum(r.pso_runs for r in want) > 0, (ks.pso_patches, n)   # both lanes' runs, counted by the parent
     ctx.close()
     S.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["pawn_small", "ring_small"])
+def test_task_ring_pass_is_the_launch_per_iteration_pass(request, scene_name, monkeypatch):
+    """k_pso_ring (one launch per PSO pass: waves pop (candidate, particle) tasks from per-XCD rings, the wave that delivers a
+    candidate's last fitness runs its swarm step and publishes the next iteration) against the per-iteration launches
+    (k_pso_eval2 + k_pso_step) and against k_pso_iter: the same records byte for byte, in both evaluation shapes."""
+    from pais_mvs_amd import _lib
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import Context, make_candidate
+    scene = request.getfixturevalue(scene_name)
+    cfg = readme_config(adaptiveGradientEnable=(scene_name == "ring_small"))
+    S = common.oracle_scene(cfg, scene)
+    _, seeds = common.seed_candidates(S, scene)
+    ctx = Context(cfg, scene.cameras, device=0, seed=42)
+    kept = [r for r in ctx.refine_batch(seeds) if not r.dropped]
+    ctx.close()
+    assert len(kept) >= 8
+    cands = []
+    for i, r in enumerate(kept[:40]):
+        for j in range(4):
+            cen = [r.center[0] + 0.002 * (j - 1.5), r.center[1] + 0.001 * j, r.center[2] - 0.001 * j]
+            cands.append(make_candidate(cen, list(r.normal[:]), [r.cam_idx[k] for k in range(r.num_cam)], 5000 + 11 * i + j, 1, normalS=list(r.normalS[:])))
+
+    def run(env):
+        for k in ("PAIS_SPLIT_ABOVE", "PAIS_PSO_RING"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = Context(cfg, scene.cameras, device=0, seed=42)
+        out = bytes(c.refine_batch(cands))
+        ks = c.kernel_stats()
+        c.close()
+        return out, ks
+
+    ref, _ = run({})                                                       # small batch: k_pso_iter
+    ring, ks = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "1"})
+    assert ks.eval2_launches == 1, ks.eval2_launches                        # one launch for the whole pass
+    launches, ks2 = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "0"})
+    assert ks2.eval2_launches > 10
+    assert ring == launches == ref
+    S.close()
