@@ -379,6 +379,9 @@ def main():
                          "kernel": ("k_pso_tile (PAIS::getFitness, one workgroup per candidate x 8 particles, camera footprints staged in LDS; "
                                     "%d of the %d evaluation launches of the large batches, the rest k_pso_eval2)" % (int(ks.tile_launches), e2_n))
                          if ks.tile_launches * 2 > e2_n else
+                         ("k_pso_ring (PAIS::getFitness + PsoSolver::run of a large batch as ONE launch: resident waves pop (candidate, particle) "
+                          "evaluation tasks from per-XCD rings; %d of the %d evaluation launches of the large batches)" % (int(ks.ring_launches), e2_n))
+                         if ks.ring_launches * 2 > e2_n else
                          "k_pso_eval2 (PAIS::getFitness, one wave per candidate x particle; the launches of the large batches)",
                          "achieved": e2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e2_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": e2_n, "avg_launch_ms": e2_ms / e2_n,

@@ -273,6 +273,7 @@ typedef struct pais_kernel_stats {
      * eval2_busy_ms is the length of the UNION of their [start, end] intervals -- the time during which at least one of
      * them was running (<= eval2_ms; 0 unless fine timing was on) */
     double   eval2_busy_ms;
+    int64_t  ring_launches;      /* of eval2_launches: whole PSO passes run by k_pso_ring (one launch each) */
 } pais_kernel_stats;
 int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
 /* on != 0: bracket every cost-evaluation launch (k_pso_iter / k_fitness) with HIP events on the stream it is

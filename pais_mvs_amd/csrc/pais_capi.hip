@@ -136,7 +136,7 @@ struct pais_ctx {
     double psoMs = 0, beginMs = 0, afterMs = 0, evalMs = 0, eval2Ms = 0;
     hipEvent_t refEv = nullptr;         // common time origin of the evEval2 intervals (recorded when fine timing is switched on; a lane uses its parent's)
     std::vector<std::pair<float, float>> eval2Intervals; // [start, end] of the drained evEval2 pairs, ms since refEv
-    int64_t psoLaunches = 0, evalLaunches = 0, eval2Launches = 0, tileLaunches = 0;
+    int64_t psoLaunches = 0, evalLaunches = 0, eval2Launches = 0, tileLaunches = 0, ringLaunches = 0;
     // lanes (pais_ctx_fork_lane): contexts over this one's scene with their own stream and work buffers
     pais_ctx *parent = nullptr;         // != nullptr: this is a lane; the scene's allocations belong to the parent
     std::vector<pais_ctx *> lanes;
@@ -718,15 +718,18 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
     if (itEnd > P.maxIt + 1) itEnd = P.maxIt + 1;
     if (P.useRing) {
         if (P.itNext == 0 && itEnd > 0) {
-            Timed te;
+            HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, ctx->numCUs, 0, ctx->stream));
+            Timed te; // (the kernel alone)
             if (te.begin(ctx, ctx->stream, &ctx->evEval2)) return -2;
             HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
-                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, ctx->numCUs, ctx->stream));
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, ctx->numCUs, 1, ctx->stream));
             if (te.end()) return -2;
             HIPCHK(hipMemcpyAsync(ctx->h_ringCtl, ctx->d_ringCtl, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
             ctx->ringUsed = true;
             ctx->evalLaunches++;
             ctx->eval2Launches++;
+            ctx->ringLaunches++;
             P.itNext = P.maxIt + 1; // the launch covers every iteration of the pass
         }
         return 0;
@@ -1123,6 +1126,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
         out->eval2_ms += c->eval2Ms;
         out->eval2_launches += c->eval2Launches;
         out->tile_launches += c->tileLaunches;
+        out->ring_launches += c->ringLaunches;
         iv.insert(iv.end(), c->eval2Intervals.begin(), c->eval2Intervals.end());
         out->eval2_evals += (int64_t)st[5];
         out->eval2_algorithmic_bytes += (double)st[6] * S2;
@@ -1133,6 +1137,7 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
             c->evalLaunches = 0;
             c->eval2Launches = 0;
             c->tileLaunches = 0;
+            c->ringLaunches = 0;
             c->eval2Intervals.clear();
         }
     }

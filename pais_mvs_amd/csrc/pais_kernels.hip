@@ -1944,7 +1944,7 @@ size_t ring_words(int n, int Nmax, int maxIt) { return ring_seg_words(n, Nmax, m
 template <int NS, bool BYTES, bool ACCR>
 static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
                                   const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive,
-                                  unsigned long long *stat, int waves, hipStream_t stream)
+                                  unsigned long long *stat, int waves, int phase, hipStream_t stream)
 {
     static LdsAttr attr;
     size_t per = eval_lds_bytes(NS, Kmax, ACCR);
@@ -1956,13 +1956,16 @@ static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, u
     if (e != hipSuccess) return e;
     const size_t words = ring_words(n, Nmax, maxIt), seg = ring_seg_words(n, Nmax, maxIt);
     if (seg >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
-    e = hipMemsetAsync(ring, 0xFF, words * sizeof(unsigned), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ctl, 0, sizeof(RingCtl) * PAIS_RINGS, stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(arrive, 0, sizeof(int) * (size_t)n, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ring_init, dim3((n + 255) / 256), dim3(256), 0, stream, states, n, Nmax, ring, (unsigned)seg, (RingCtl *)ctl);
+    if (phase == 0) { // empty rings, zero counters, the tasks of iteration 0
+        e = hipMemsetAsync(ring, 0xFF, words * sizeof(unsigned), stream);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(ctl, 0, sizeof(RingCtl) * PAIS_RINGS, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(arrive, 0, sizeof(int) * (size_t)n, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ring_init, dim3((n + 255) / 256), dim3(256), 0, stream, states, n, Nmax, ring, (unsigned)seg, (RingCtl *)ctl);
+        return hipGetLastError();
+    }
     long tasks = (long)n * Nmax;
     waves *= (NS == 1 ? 4 * PAIS_NS1_WAVES : 4 * PAIS_NS2_WAVES); // `waves` arrives as the number of CUs: resident waves per CU by shape
     int grid = (int)(tasks < waves ? tasks : waves);
@@ -1973,9 +1976,9 @@ static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, u
 }
 hipError_t pso_ring(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
                     const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive, unsigned long long *stat,
-                    int waves, hipStream_t stream)
+                    int waves, int phase, hipStream_t stream)
 {
-    PAIS_SHAPE_DISPATCH(pso_ring_launch, sc, recs, states, n, Nmax, Kmax, maxIt, evalBlocks, win, ring, ctl, arrive, stat, waves, stream);
+    PAIS_SHAPE_DISPATCH(pso_ring_launch, sc, recs, states, n, Nmax, Kmax, maxIt, evalBlocks, win, ring, ctl, arrive, stat, waves, phase, stream);
 }
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                     unsigned long long *stat, hipStream_t stream)

@@ -42,8 +42,8 @@ if f:
         def per_launch(pred):
             tot=sum(v for (k,c),(v,n) in sums.items() if pred(k)); nl=sum(n for (k,c),(v,n) in sums.items() if pred(k))
             return (tot*1024.0/nl if nl else None), nl
-        raw_all,nl_all=per_launch(lambda k: k.startswith("k_pso_iter") or k.startswith("k_pso_eval"))
-        raw_e2,nl_e2=per_launch(lambda k: k.startswith("k_pso_eval") or k.startswith("k_pso_tile"))
+        raw_all,nl_all=per_launch(lambda k: k.startswith("k_pso_iter") or k.startswith("k_pso_eval") or k.startswith("k_pso_ring"))
+        raw_e2,nl_e2=per_launch(lambda k: k.startswith("k_pso_eval") or k.startswith("k_pso_tile") or k.startswith("k_pso_ring"))
         if nl_all:
             json.dump({"$SCENE": {"seeds": $SEEDS, "parents_per_round": $PPR, "max_rounds": $MAXR,
                        "eval2_hbm_read_bytes_per_launch": (2.0*raw_e2 if raw_e2 else None), "eval2_launches": nl_e2,
