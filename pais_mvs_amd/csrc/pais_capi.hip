@@ -56,6 +56,7 @@ struct PassPlan {
     struct Slice { int lo, hi, parts; hipStream_t st; bool own; };
     int n = 0, Nmax = 0, Kmax = 0, maxIt = 0, nSl = 0, S = 1, afterGrid = 0, itNext = 0;
     bool useIter = false, useTile = false, useRing = false, hasSeeds = false, hostBatch = false;
+    int ringCUs = 0; // CUs' worth of resident waves the ring launch may take (a part of a streamed round: its share)
     Slice sl[16];
     int *cnt = nullptr, *nextCnt = nullptr;
     size_t SB = 0, EB = 0, WB = 0;
@@ -674,6 +675,10 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
     P.useTile = tileOk && !P.useIter;
     // the large-batch pipeline as one launch over a task ring (host batches only: the error word is read when the batch ends)
     P.useRing = ctx->ringMode != 0 && P.hostBatch && !P.hasSeeds && !P.useIter && !P.useTile && Nmax <= 64;
+    // (the parts of a streamed round keep the per-iteration launches, which interleave on their lanes; two ring launches would
+    // run one after the other, or each on its share of the CUs -- ring scene 17.5 s against 18.3 / 19.7 s that way)
+    if (P.useRing && nPlan > n && ctx->ringMode != 3) P.useRing = false;
+    P.ringCUs = ctx->numCUs;
     if (P.useRing) {
         if (grow(ctx, ctx->d_ring, ctx->ringBytes, pais_launch::ring_words(n, Nmax, P.maxIt) * sizeof(unsigned))) return -2;
         if (grow(ctx, ctx->d_arrive, ctx->arriveBytes, sizeof(int) * (size_t)n)) return -2;
@@ -719,11 +724,11 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
     if (P.useRing) {
         if (P.itNext == 0 && itEnd > 0) {
             HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
-                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, ctx->numCUs, 0, ctx->stream));
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 0, ctx->stream));
             Timed te; // (the kernel alone)
             if (te.begin(ctx, ctx->stream, &ctx->evEval2)) return -2;
             HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
-                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, ctx->numCUs, 1, ctx->stream));
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 1, ctx->stream));
             if (te.end()) return -2;
             HIPCHK(hipMemcpyAsync(ctx->h_ringCtl, ctx->d_ringCtl, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
             ctx->ringUsed = true;
