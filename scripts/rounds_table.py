@@ -12,7 +12,7 @@ for k, (a, b) in enumerate(zip(begins[half:end], (begins[half + 1:] + [len(rows)
     seg = rows[a:b]
     n = seg[0][3] // 64
     dur = ((rows[b][1] if b < len(rows) else seg[-1][2]) - seg[0][1]) / 1e3
-    it = [r for r in seg if 'k_pso_iter' in r[0] or 'k_pso_eval' in r[0]]
+    it = [r for r in seg if 'k_pso_iter' in r[0] or 'k_pso_eval' in r[0] or 'k_pso_ring' in r[0] or 'k_pso_tile' in r[0]]
     af = sum((r[2] - r[1]) for r in seg if r[0].startswith('k_after') or r[0].startswith('k_region_ratio')) / 1e3
     itus = sum((r[2] - r[1]) for r in it) / 1e3
     kinds = sorted(set(r[0].replace('void ', '') for r in it))
