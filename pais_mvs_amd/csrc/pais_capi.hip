@@ -143,6 +143,7 @@ struct pais_ctx {
     std::vector<pais_ctx *> lanes;
     int openBatch = -1;                 // records of the batch between pais_refine_batch_begin and _end (-1: none)
     // k_pso_ring (pais_kernels.hip): the PSO pass of a large expansion batch as ONE launch over a device-side task ring
+    double ringPerCam = 1843.0;         // PAIS_RING_PER_CAM: 9216 waves per iteration at five cameras
     int ringMode = 1;                   // PAIS_PSO_RING=0: large batches take the per-iteration launches (k_pso_eval2 + k_pso_step) instead
     unsigned *d_ring = nullptr;         // task ring
     size_t ringBytes = 0;
@@ -370,6 +371,7 @@ static int ctx_init_work(pais_ctx *ctx)
     if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     if (const char *e = getenv("PAIS_PSO_RING")) ctx->ringMode = atoi(e);
+    if (const char *e = getenv("PAIS_RING_PER_CAM")) ctx->ringPerCam = atof(e);
     HIPCHK(hipMalloc(&ctx->d_ringCtl, 64 * 8));
     HIPCHK(hipMemset(ctx->d_ringCtl, 0, 64 * 8));
     HIPCHK(hipHostMalloc((void **)&ctx->h_ringCtl, 64 * 8, hipHostMallocDefault));
@@ -674,7 +676,10 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
     P.useIter = Nmax <= 64 && (long)nPlan * Nmax < (tileOk ? ctx->tileAbove : ctx->splitAbove);
     P.useTile = tileOk && !P.useIter;
     // the large-batch pipeline as one launch over a task ring (host batches only: the error word is read when the batch ends)
-    P.useRing = ctx->ringMode != 0 && P.hostBatch && !P.hasSeeds && !P.useIter && !P.useTile && Nmax <= 64;
+    // (a candidate's chain of maxIt evaluation + step latencies bounds a ring launch from below; the longer an evaluation -- more
+    // cameras --, the more candidates it takes for throughput to dominate that chain: PAIS_RING_PER_CAM waves per iteration and camera)
+    P.useRing = ctx->ringMode != 0 && P.hostBatch && !P.hasSeeds && !P.useIter && !P.useTile && Nmax <= 64 &&
+                (long)n * Nmax >= (long)(ctx->ringPerCam * P.Kmax);
     // (the parts of a streamed round keep the per-iteration launches, which interleave on their lanes; two ring launches would
     // run one after the other, or each on its share of the CUs -- ring scene 17.5 s against 18.3 / 19.7 s that way)
     if (P.useRing && nPlan > n && ctx->ringMode != 3) P.useRing = false;
