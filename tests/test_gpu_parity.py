@@ -1142,7 +1142,7 @@ def test_task_ring_pass_is_the_launch_per_iteration_pass(request, scene_name, mo
             cands.append(make_candidate(cen, list(r.normal[:]), [r.cam_idx[k] for k in range(r.num_cam)], 5000 + 11 * i + j, 1, normalS=list(r.normalS[:])))
 
     def run(env):
-        for k in ("PAIS_SPLIT_ABOVE", "PAIS_PSO_RING"):
+        for k in ("PAIS_SPLIT_ABOVE", "PAIS_PSO_RING", "PAIS_RING_PER_CAM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1153,7 +1153,7 @@ def test_task_ring_pass_is_the_launch_per_iteration_pass(request, scene_name, mo
         return out, ks
 
     ref, _ = run({})                                                       # small batch: k_pso_iter
-    ring, ks = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "1"})
+    ring, ks = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "1", "PAIS_RING_PER_CAM": "0"})   # (no size threshold: this batch is small)
     assert ks.eval2_launches == 1, ks.eval2_launches                        # one launch for the whole pass
     launches, ks2 = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "0"})
     assert ks2.eval2_launches > 10
