@@ -314,7 +314,9 @@ def main():
         scaling_model = predicted_speedup(m.round_log(), cfg.particleNum, (ks.pso_algorithmic_bytes / ks.pso_evals) if ks.pso_evals else 23000.0)
         gold_sha, gold_ok = None, None
         try:
-            g = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_cloud_%s.json" % args.scene)))
+            # (bounded workloads of the full-size scenes carry their round count in the name: bench_cloud_ring_r3.json)
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_cloud_%s%s.json"
+                                            % (args.scene, ("_r%d" % args.max_rounds) if args.max_rounds else ""))))
             if (g["seeds"], g["parents_per_round"], g["max_rounds"], g["pso_seed"]) == (len(scene.seeds), B, args.max_rounds, 42):
                 gold_sha = g["cloud_sha1"]
                 gold_ok = bool(cloud_sha1 == gold_sha and accepted == g["accepted_patches"]

@@ -198,7 +198,12 @@ int  pais_refine_batch_view(pais_ctx *ctx, int n, const pais_candidate *cands, c
  * view.  Exactly one batch can be open per context; the caller's `cands` are not read after _begin returns. */
 int  pais_refine_batch_begin(pais_ctx *ctx, int n, const pais_candidate *cands);
 int  pais_refine_batch_end(pais_ctx *ctx, const pais_patch_result **view);
-/* _begin cut in pieces, for a driver that keeps two lanes busy: the launches of a batch are a chain per PSO iteration,
+/* ---- ADVANCED: launch-chain scheduling (pais_refine_batch_open / _enqueue, pais_ctx_fork_lane, pais_ctx_set_round_hint).
+ * A maintainer who binds MVS::refineSeedPatches / expansionPatches never needs these four: pais_refine_batch(_view) and
+ * the drivers of include/pais_mvs.h are the whole drop-in surface.  They exist for a driver that overlaps its own host
+ * work with the GPU's (the streamed rounds of pais_mvs_expansion_patches are built on them) and are exported so that
+ * such a driver can live outside this library. ----
+ * _begin cut in pieces, for a driver that keeps two lanes busy: the launches of a batch are a chain per PSO iteration,
  * and a chain that is enqueued in one go keeps the host away from the other lane for its whole length.  _open = _begin
  * that stops after the first `iterations` PSO iterations; _enqueue adds up to `iterations` more (<= 0: all that remain)
  * and returns 1 once the batch is enqueued to its end (after-stage and copy down included), 0 while iterations remain,
@@ -245,10 +250,12 @@ void *pais_ctx_stream(pais_ctx *ctx);
 int  pais_ctx_synchronize(pais_ctx *ctx);
 
 /* Kernel timing accumulated since the last reset, measured with HIP events on the
- * launch stream.  pso_ms spans one whole PSO pass (k_pso_init + the k_pso_eval /
- * k_pso_step sequence, or the fused k_pso when PAIS_PSO_MODE=fused); eval_ms /
- * eval_launches cover the dominant kernel k_pso_eval alone and are only collected
- * when the environment sets PAIS_FINE_TIMING=1 (bench.py does).  Algorithmic bytes:
+ * launch stream.  pso_ms spans one whole PSO pass (k_pso_init + the pass's evaluation /
+ * step launches: k_pso_iter per iteration for small batches, k_pso_ring -- one launch --
+ * or k_pso_eval2 + k_pso_step per iteration for large ones, k_pso_tile for many cameras);
+ * eval_ms / eval_launches cover every cost-evaluation launch and are only collected while
+ * fine timing is on (pais_ctx_set_fine_timing, or PAIS_FINE_TIMING=1 in the environment;
+ * bench.py's roofline leg).  Algorithmic bytes:
  * SURVEY 8d, S^2*(4K+1+8[dist]+8[grad]) per cost evaluation. */
 typedef struct pais_kernel_stats {
     double   pso_ms;
@@ -274,6 +281,13 @@ typedef struct pais_kernel_stats {
      * them was running (<= eval2_ms; 0 unless fine timing was on) */
     double   eval2_busy_ms;
     int64_t  ring_launches;      /* of eval2_launches: whole PSO passes run by k_pso_ring (one launch each) */
+    /* the k_pso_ring launches ALONE (a subset of the eval2_* figures): sum of their durations (fine timing), the cost
+     * evaluations they ran and their algorithmic bytes -- what bench.py's roofline object is computed from */
+    double   ring_ms;
+    int64_t  ring_evals;
+    double   ring_algorithmic_bytes;
+    int64_t  ring_fallbacks;     /* ring passes that did not complete (a wave waited longer than PAIS_RING_TIMEOUT_MS) and
+                                  * were re-run through the per-iteration launches: same records, 0 in every healthy run */
 } pais_kernel_stats;
 int  pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int reset);
 /* on != 0: bracket every cost-evaluation launch (k_pso_iter / k_fitness) with HIP events on the stream it is

@@ -73,7 +73,8 @@ class KernelStats(C.Structure):
                 ("pso_algorithmic_bytes", C.c_double), ("ncc_algorithmic_bytes", C.c_double),
                 ("ncc_tables", C.c_int64), ("eval_ms", C.c_double), ("eval_launches", C.c_int64),
                 ("eval2_ms", C.c_double), ("eval2_launches", C.c_int64), ("eval2_evals", C.c_int64),
-                ("eval2_algorithmic_bytes", C.c_double), ("tile_launches", C.c_int64), ("eval2_busy_ms", C.c_double), ("ring_launches", C.c_int64)]
+                ("eval2_algorithmic_bytes", C.c_double), ("tile_launches", C.c_int64), ("eval2_busy_ms", C.c_double), ("ring_launches", C.c_int64),
+                ("ring_ms", C.c_double), ("ring_evals", C.c_int64), ("ring_algorithmic_bytes", C.c_double), ("ring_fallbacks", C.c_int64)]
 
 
 _lib = None

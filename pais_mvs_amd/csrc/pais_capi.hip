@@ -61,6 +61,7 @@ struct PassPlan {
     int *cnt = nullptr, *nextCnt = nullptr;
     size_t SB = 0, EB = 0, WB = 0;
     pais_patch_result *d_out = nullptr;
+    const pais_candidate *d_cands = nullptr;
     Timed tp;
 };
 
@@ -151,7 +152,14 @@ struct pais_ctx {
     unsigned *h_ringCtl = nullptr;      // pinned copy, read when the batch ends
     int *d_arrive = nullptr;            // per candidate: evaluations of the current iteration that have been delivered
     size_t arriveBytes = 0;
-    bool ringUsed = false;              // by the open batch
+    bool ringUsed = false;              // by the open batch (its error words are read when the batch ends)
+    bool ringSuppressed = false;        // while a batch whose ring pass failed is re-run
+    double ringTimeoutMs = 10000.0;     // PAIS_RING_TIMEOUT_MS: longest wait of a k_pso_ring wave for a ring entry (wall time, s_memrealtime)
+    long ringSeedAbove = 0;             // PAIS_RING_SEED_ABOVE: evaluation waves per iteration from which a pass of a SEED batch takes the ring
+    size_t ringMaxBytes = (size_t)512 << 20; // PAIS_RING_MAX_MB: batches whose ring would be larger keep the per-iteration launches
+    int64_t ringFallbacks = 0;          // ring passes that did not complete and were re-run through the per-iteration launches
+    std::vector<EventPair> evRing;      // the ring launches alone (fine timing)
+    double ringMs = 0;
     PassPlan plan;                      // of the open batch (pais_refine_batch_open .. _enqueue)
     bool planDone = true;               // the open batch is enqueued to its end
     int roundHint = 0;                  // pais_ctx_set_round_hint: candidates of the round the next batch is a part of (0: it is the round)
@@ -372,6 +380,10 @@ static int ctx_init_work(pais_ctx *ctx)
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     if (const char *e = getenv("PAIS_PSO_RING")) ctx->ringMode = atoi(e);
     if (const char *e = getenv("PAIS_RING_PER_CAM")) ctx->ringPerCam = atof(e);
+    if (const char *e = getenv("PAIS_RING_TIMEOUT_MS")) ctx->ringTimeoutMs = atof(e);
+    ctx->ringSeedAbove = ctx->splitAbove / 2;
+    if (const char *e = getenv("PAIS_RING_SEED_ABOVE")) ctx->ringSeedAbove = atol(e);
+    if (const char *e = getenv("PAIS_RING_MAX_MB")) { long v = atol(e); if (v > 0) ctx->ringMaxBytes = (size_t)v << 20; }
     HIPCHK(hipMalloc(&ctx->d_ringCtl, 64 * 8));
     HIPCHK(hipMemset(ctx->d_ringCtl, 0, 64 * 8));
     HIPCHK(hipHostMalloc((void **)&ctx->h_ringCtl, 64 * 8, hipHostMallocDefault));
@@ -675,17 +687,23 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
     const int nPlan = ctx->roundHint > n ? ctx->roundHint : n;
     P.useIter = Nmax <= 64 && (long)nPlan * Nmax < (tileOk ? ctx->tileAbove : ctx->splitAbove);
     P.useTile = tileOk && !P.useIter;
-    // the large-batch pipeline as one launch over a task ring (host batches only: the error word is read when the batch ends)
+    // the PSO pass as ONE launch over device-side task rings (k_pso_ring): host batches, device-pointer batches (the shards of
+    // the multi-GPU drivers) and the passes of seed batches alike -- the error words are read at the batch's (pass's) next
+    // synchronisation point and a pass that did not complete is re-run through the per-iteration launches (ring_failed below).
     // (a candidate's chain of maxIt evaluation + step latencies bounds a ring launch from below; the longer an evaluation -- more
     // cameras --, the more candidates it takes for throughput to dominate that chain: PAIS_RING_PER_CAM waves per iteration and camera)
-    P.useRing = ctx->ringMode != 0 && P.hostBatch && !P.hasSeeds && !P.useIter && !P.useTile && Nmax <= 64 &&
-                (long)n * Nmax >= (long)(ctx->ringPerCam * P.Kmax);
+    const long ringWaves = (long)(P.hasSeeds && pass > 0 ? againCount : n) * Nmax;
+    const size_t ringNeed = pais_launch::ring_words(n, Nmax, P.maxIt) * sizeof(unsigned);
+    P.useRing = ctx->ringMode != 0 && !ctx->ringSuppressed && !P.useTile && Nmax <= 64 && n < (1 << 24) && ringNeed <= ctx->ringMaxBytes &&
+                (P.hasSeeds ? (ctx->ringSeedAbove > 0 && ringWaves >= ctx->ringSeedAbove)
+                            : (!P.useIter && ringWaves >= (long)(ctx->ringPerCam * P.Kmax)));
     // (the parts of a streamed round keep the per-iteration launches, which interleave on their lanes; two ring launches would
     // run one after the other, or each on its share of the CUs -- ring scene 17.5 s against 18.3 / 19.7 s that way)
     if (P.useRing && nPlan > n && ctx->ringMode != 3) P.useRing = false;
+    if (P.useRing) P.useIter = false;
     P.ringCUs = ctx->numCUs;
     if (P.useRing) {
-        if (grow(ctx, ctx->d_ring, ctx->ringBytes, pais_launch::ring_words(n, Nmax, P.maxIt) * sizeof(unsigned))) return -2;
+        if (grow(ctx, ctx->d_ring, ctx->ringBytes, ringNeed)) return -2;
         if (grow(ctx, ctx->d_arrive, ctx->arriveBytes, sizeof(int) * (size_t)n)) return -2;
     }
     // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
@@ -728,12 +746,13 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
     if (itEnd > P.maxIt + 1) itEnd = P.maxIt + 1;
     if (P.useRing) {
         if (P.itNext == 0 && itEnd > 0) {
+            const unsigned long long ticks = (unsigned long long)(ctx->ringTimeoutMs * 1e5); // s_memrealtime counts at 100 MHz
             HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
-                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 0, ctx->stream));
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 0, ticks, ctx->stream));
             Timed te; // (the kernel alone)
-            if (te.begin(ctx, ctx->stream, &ctx->evEval2)) return -2;
+            if (te.begin(ctx, ctx->stream, &ctx->evRing)) return -2;
             HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
-                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 1, ctx->stream));
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 1, ticks, ctx->stream));
             if (te.end()) return -2;
             HIPCHK(hipMemcpyAsync(ctx->h_ringCtl, ctx->d_ringCtl, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
             ctx->ringUsed = true;
@@ -776,6 +795,20 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
     return 0;
 }
 
+// the sub-streams a pass forked to join the context's stream again (also on the error paths: nothing stays forked)
+static int pass_join(pais_ctx *ctx, PassPlan &P)
+{
+    for (int sI = 1; sI < P.S; ++sI) {
+        bool used = false;
+        for (int k = 0; k < P.nSl; ++k) used = used || (P.sl[k].st == ctx->sub[sI - 1]);
+        if (!used) continue;
+        HIPCHK(hipEventRecord(ctx->subDone[sI - 1], ctx->sub[sI - 1]));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
+    }
+    P.S = 1;
+    return 0;
+}
+
 static int pass_close(pais_ctx *ctx, PassPlan &P)
 {
     const DevScene &sc = ctx->sc;
@@ -786,13 +819,7 @@ static int pass_close(pais_ctx *ctx, PassPlan &P)
             HIPCHK(pais_launch::pso_iter(sc, ctx->d_psoStates, ctx->d_active, P.cnt + 2, q.lo, q.hi, P.Nmax, P.Kmax, P.d_out,
                                          ctx->d_stat, P.maxIt + 1, 1, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
     }
-    for (int sI = 1; sI < P.S; ++sI) {
-        bool used = false;
-        for (int k = 0; k < P.nSl; ++k) used = used || (P.sl[k].st == ctx->sub[sI - 1]);
-        if (!used) continue;
-        HIPCHK(hipEventRecord(ctx->subDone[sI - 1], ctx->sub[sI - 1]));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->subDone[sI - 1], 0));
-    }
+    if (pass_join(ctx, P)) return -2;
     if (P.tp.end()) return -2;
     ctx->psoLaunches++;
     Timed ta;
@@ -840,6 +867,7 @@ static int batch_setup(pais_ctx *ctx, PassPlan &P, int n, const pais_candidate *
     P.EB = pais_launch::eval_block_bytes_host(Kmax);
     P.WB = pais_launch::win_bytes_per_candidate(sc);
     P.d_out = d_out;
+    P.d_cands = d_cands;
 
     if (ctx->countersDirty) HIPCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(int) * 8, ctx->stream));
     ctx->countersDirty = true; // until this batch has run through
@@ -852,6 +880,47 @@ static int batch_setup(pais_ctx *ctx, PassPlan &P, int n, const pais_candidate *
     return 0;
 }
 
+// The error words of the ring pass that has just been synchronised with (h_ringCtl: per ring {head, tail, done, total, error}).
+// 0: every run ended; 1: a wave ran out of patience, or runs never ended -- the caller re-runs the batch without the ring.
+static int ring_failed(pais_ctx *ctx, int n)
+{
+    if (!ctx->ringUsed) return 0;
+    ctx->ringUsed = false;
+    unsigned done = 0, err = 0;
+    for (int r = 0; r < 8; ++r) { done += ctx->h_ringCtl[16 * r + 2]; err |= ctx->h_ringCtl[16 * r + 4]; }
+    if (err == 0 && done == (unsigned)n) return 0;
+    ctx->ringFallbacks++;
+    if (getenv("PAIS_RING_VERBOSE"))
+        fprintf(stderr, "[pais] k_pso_ring did not complete (error %u, %u of %d runs ended): the batch is re-run with one launch per iteration\n", err, done, n);
+    return 1;
+}
+
+// one batch on device pointers, start to end; returns 1 if a ring pass failed (the caller runs it again with the ring off)
+static int refine_device_once(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out, int max_num_cam, int has_seeds)
+{
+    PassPlan &P = ctx->plan;
+    P.hostBatch = false;
+    ctx->ringUsed = false;
+    int rc = batch_setup(ctx, P, n, d_cands, d_out, max_num_cam, has_seeds);
+    int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
+    const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
+    for (int pass = 0; !rc && pass < maxPass; ++pass) {
+        if ((rc = pass_open(ctx, P, pass, againCount)) != 0) break;
+        if ((rc = pass_iterations(ctx, P, P.maxIt + 1)) != 0) { (void)pass_join(ctx, P); break; }
+        if ((rc = pass_close(ctx, P)) != 0) break;
+        if (!has_seeds && !ctx->ringUsed) break; // (asynchronous at return)
+        if (has_seeds) HIPCHK(hipMemcpyAsync(ctx->h_counters, P.cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ring_failed(ctx, n)) { ctx->roundHint = 0; return 1; }
+        if (!has_seeds || ctx->h_counters[1] == 0) break;
+        againCount = ctx->h_counters[1];
+    }
+    ctx->roundHint = 0;
+    if (rc) return rc;
+    ctx->countersDirty = false;
+    return 0;
+}
+
 extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out,
                                         int max_num_cam, int has_seeds)
 {
@@ -859,25 +928,15 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
     if (n == 0) return 0;
     if (!d_cands || !d_out) return fail_msg("pais_refine_batch_device: null pointer");
     if (ctx->openBatch >= 0) return fail_msg("pais_refine_batch_device: a batch is open on this context");
-    PassPlan &P = ctx->plan;
-    P.hostBatch = false;
-    int rc = batch_setup(ctx, P, n, d_cands, d_out, max_num_cam, has_seeds);
-    int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
-    const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
-    for (int pass = 0; !rc && pass < maxPass; ++pass) {
-        if ((rc = pass_open(ctx, P, pass, againCount)) != 0) break;
-        if ((rc = pass_iterations(ctx, P, P.maxIt + 1)) != 0) break;
-        if ((rc = pass_close(ctx, P)) != 0) break;
-        if (!has_seeds) break;
-        HIPCHK(hipMemcpyAsync(ctx->h_counters, P.cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (ctx->h_counters[1] == 0) break;
-        againCount = ctx->h_counters[1];
+    const int hint = ctx->roundHint;
+    int rc = refine_device_once(ctx, n, d_cands, d_out, max_num_cam, has_seeds);
+    if (rc == 1) { // a ring pass did not complete: the same batch from its candidates, one launch per iteration
+        ctx->ringSuppressed = true;
+        ctx->roundHint = hint;
+        rc = refine_device_once(ctx, n, d_cands, d_out, max_num_cam, has_seeds);
+        ctx->ringSuppressed = false;
     }
-    ctx->roundHint = 0;
-    if (rc) return rc;
-    ctx->countersDirty = false;
-    return 0;
+    return rc;
 }
 
 extern "C" int pais_ctx_set_round_hint(pais_ctx *ctx, int n_round)
@@ -920,7 +979,7 @@ extern "C" int pais_refine_batch_enqueue(pais_ctx *ctx, int iterations)
     int rc = pass_iterations(ctx, P, itEnd);
     if (!rc && P.itNext <= P.maxIt) return 0;
     if (!rc) rc = pass_close(ctx, P);
-    if (rc) { ctx->openBatch = -1; return rc; } // (the counters stay marked dirty: cleared before the next batch)
+    if (rc) { (void)pass_join(ctx, P); ctx->openBatch = -1; ctx->ringUsed = false; return rc; } // (the counters stay marked dirty: cleared before the next batch)
     ctx->countersDirty = false;
     HIPCHK(hipMemcpyAsync(ctx->h_recs, ctx->d_recs, sizeof(pais_patch_result) * (size_t)ctx->openBatch, hipMemcpyDeviceToHost, ctx->stream));
     ctx->planDone = true;
@@ -938,17 +997,20 @@ extern "C" int pais_refine_batch_end(pais_ctx *ctx, const pais_patch_result **vi
     ctx->openBatch = -1;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ctx->ringUsed) {
-        ctx->ringUsed = false;
-        // per ring {head, tail, done, total, error}: a wave that ran out of patience, or runs that never ended
-        unsigned done = 0, err = 0;
-        for (int r = 0; r < 8; ++r) { done += ctx->h_ringCtl[16 * r + 2]; err |= ctx->h_ringCtl[16 * r + 4]; }
-        if (err != 0 || done != (unsigned)ctx->plan.n) {
-            ctx->countersDirty = true;
-            char msg[160];
-            snprintf(msg, sizeof(msg), "k_pso_ring did not complete (error %u, %u of %d runs ended)", err, done, ctx->plan.n);
-            return fail_msg(msg);
-        }
+    if (ring_failed(ctx, ctx->plan.n)) {
+        // the pass did not complete: the same batch again from its candidates (still in d_cands), one launch per iteration
+        PassPlan &P = ctx->plan;
+        const int n = P.n;
+        ctx->ringSuppressed = true;
+        int rc = batch_setup(ctx, P, n, ctx->d_cands, ctx->d_recs, P.Kmax, 0);
+        if (!rc) rc = pass_open(ctx, P, 0, 0);
+        if (!rc && (rc = pass_iterations(ctx, P, P.maxIt + 1)) != 0) (void)pass_join(ctx, P);
+        if (!rc) rc = pass_close(ctx, P);
+        ctx->ringSuppressed = false;
+        if (rc) return rc;
+        ctx->countersDirty = false;
+        HIPCHK(hipMemcpyAsync(ctx->h_recs, ctx->d_recs, sizeof(pais_patch_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     *view = ctx->h_recs;
     return 0;
@@ -959,6 +1021,7 @@ extern "C" int pais_refine_batch_open(pais_ctx *ctx, int n, const pais_candidate
     if (!ctx || n <= 0 || !cands) return fail_msg("pais_refine_batch_begin: bad argument");
     if (ctx->openBatch >= 0) return fail_msg("pais_refine_batch_begin: a batch is open on this context already");
     HIPCHK(hipSetDevice(ctx->device));
+    ctx->ringUsed = false;
     int Kmax = 1, hasSeeds = 0;
     for (int i = 0; i < n; ++i) {
         const pais_candidate &c = cands[i];
@@ -996,12 +1059,11 @@ extern "C" int pais_refine_batch_open(pais_ctx *ctx, int n, const pais_candidate
     }
     PassPlan &P = ctx->plan;
     P.hostBatch = true;
-    ctx->ringUsed = false;
     int rc = batch_setup(ctx, P, n, ctx->d_cands, ctx->d_recs, Kmax, 0);
     if (!rc) rc = pass_open(ctx, P, 0, 0);
     ctx->roundHint = 0;
-    if (!rc) rc = pass_iterations(ctx, P, iterations > 0 ? iterations : 0);
-    if (rc) return rc;
+    if (!rc && (rc = pass_iterations(ctx, P, iterations > 0 ? iterations : 0)) != 0) (void)pass_join(ctx, P); // (nothing stays forked behind an error)
+    if (rc) { ctx->ringUsed = false; return rc; }
     ctx->openBatch = n;
     ctx->planDone = false;
     return 0;
@@ -1091,6 +1153,18 @@ static int collect_stats(pais_ctx *ctx, unsigned long long *st)
         if (drain_events(ctx, ctx->evEval2, ms2)) return -2;
         ctx->eval2Ms += ms2;
         ctx->evalMs += ms2;
+        // the k_pso_ring launches: part of the large-batch figures above, and reported on their own
+        double msR = 0;
+        if (ref)
+            for (auto &p : ctx->evRing) {
+                float a = 0, b = 0;
+                if (hipEventElapsedTime(&a, ref, p.a) == hipSuccess && hipEventElapsedTime(&b, ref, p.b) == hipSuccess)
+                    ctx->eval2Intervals.push_back(std::make_pair(a, b));
+            }
+        if (drain_events(ctx, ctx->evRing, msR)) return -2;
+        ctx->ringMs += msR;
+        ctx->eval2Ms += msR;
+        ctx->evalMs += msR;
     }
     HIPCHK(hipMemcpy(st, ctx->d_stat, sizeof(unsigned long long) * 24, hipMemcpyDeviceToHost));
     if (ctx->tileDebug)
@@ -1137,12 +1211,17 @@ extern "C" int pais_get_kernel_stats(pais_ctx *ctx, pais_kernel_stats *out, int 
         out->eval2_launches += c->eval2Launches;
         out->tile_launches += c->tileLaunches;
         out->ring_launches += c->ringLaunches;
+        out->ring_ms += c->ringMs;
+        out->ring_evals += (int64_t)st[22];
+        out->ring_algorithmic_bytes += (double)st[23] * S2;
+        out->ring_fallbacks += c->ringFallbacks;
         iv.insert(iv.end(), c->eval2Intervals.begin(), c->eval2Intervals.end());
         out->eval2_evals += (int64_t)st[5];
         out->eval2_algorithmic_bytes += (double)st[6] * S2;
         if (reset) {
             HIPCHK(hipMemset(c->d_stat, 0, sizeof(unsigned long long) * 24));
-            c->psoMs = c->beginMs = c->afterMs = c->evalMs = c->eval2Ms = 0;
+            c->psoMs = c->beginMs = c->afterMs = c->evalMs = c->eval2Ms = c->ringMs = 0;
+            c->ringFallbacks = 0;
             c->psoLaunches = 0;
             c->evalLaunches = 0;
             c->eval2Launches = 0;

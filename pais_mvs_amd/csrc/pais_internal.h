@@ -91,7 +91,8 @@ hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *
 size_t ring_words(int n, int Nmax, int maxIt);
 hipError_t pso_ring(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
                     const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive, unsigned long long *stat,
-                    int waves, int phase, hipStream_t stream); // phase 0: rings and counters prepared; 1: the launch
+                    int waves, int phase, unsigned long long timeoutTicks, hipStream_t stream); // phase 0: rings and counters prepared; 1: the launch
+                    // timeoutTicks: longest wait of a wave for a ring entry, in ticks of the 100 MHz s_memrealtime counter
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
                  unsigned long long *stat, int Kmax, double *ratios, int *nextCounters, hipStream_t stream);
 } // namespace pais_launch

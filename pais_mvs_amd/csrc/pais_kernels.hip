@@ -1298,8 +1298,12 @@ __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c,
         atomicAdd(&stat[0], (unsigned long long)evals);
         atomicAdd(&stat[1], (unsigned long long)evals * perEval);
         atomicAdd(&stat[2], 1ULL);
-        atomicAdd(&stat[5], (unsigned long long)evals); // ... of which by the large-batch pipeline (k_pso_eval2)
+        atomicAdd(&stat[5], (unsigned long long)evals); // ... of which by the large-batch pipeline (k_pso_eval2 / k_pso_ring)
         atomicAdd(&stat[6], (unsigned long long)evals * perEval);
+        if (COH) { // ... of which inside a k_pso_ring launch
+            atomicAdd(&stat[22], (unsigned long long)evals);
+            atomicAdd(&stat[23], (unsigned long long)evals * perEval);
+        }
     }
     return 0;
 }
@@ -1331,14 +1335,15 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
 // Nobody waits for a particular wave: an index beyond the published tail is only ever held by a wave that would otherwise be
 // idle, and the tasks whose completion will publish it are being executed by waves that are not waiting -- no deadlock, with
 // any number of resident waves.  The swarm state crosses waves (and XCDs) through sc1 loads / stores (cload / cstore above);
-// a payload is complete (s_waitcnt vmcnt(0)) before the atomic that lets another wave look at it.  Every wait is bounded: a
-// wave that polls PAIS_RING_SPIN_LIMIT times raises the error word and leaves; the host fails the batch.
+// a payload is complete (s_waitcnt vmcnt(0)) before the atomic that lets another wave look at it.  Every wait is bounded in
+// WALL TIME (s_memrealtime, the 100 MHz constant counter: a poll count would depend on the clock, a profiler's serialisation
+// or a neighbour on a shared GPU): a wave that has waited `timeoutTicks` raises the error word and leaves; the host then
+// re-runs the batch through the per-iteration launches (pais_capi.hip ring_fallback) -- the records are the same.
 // Same evaluation code, same step code, per-candidate order of operations unchanged: the records are those of
 // k_pso_eval2 + k_pso_step bit for bit.
 #define PAIS_RING_EMPTY 0xFFFFFFFFu
-#ifndef PAIS_RING_SPIN_LIMIT
-#define PAIS_RING_SPIN_LIMIT 1000000
-#endif
+static_assert(PAIS_WG_WAVES == 1, "k_pso_ring: the swarm step (pso_step_wave) synchronises with workgroup barriers inside wave-divergent "
+                                  "control flow, which is only a wave barrier while a workgroup is ONE wave");
 #define PAIS_RINGS 8 // one ring per XCD (workgroup b runs on XCD b % 8): a ring's counters and its candidates' state stay in one L2
 struct RingCtl { unsigned head, tail, done, total, error, pad[11]; }; // one 64-byte line per ring
 
@@ -1364,7 +1369,8 @@ __global__ __launch_bounds__(256) void k_ring_init(unsigned char *states, int n,
 template <int NS, bool BYTES, bool ACCR>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax,
                                                 const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win, unsigned *ringAll,
-                                                unsigned segWords, RingCtl *ctlAll, int *arrive, unsigned long long *stat, size_t ldsPerWave)
+                                                unsigned segWords, RingCtl *ctlAll, int *arrive, unsigned long long *stat, size_t ldsPerWave,
+                                                unsigned long long timeoutTicks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
     unsigned char *smem = smem0 + (threadIdx.x >> 6) * ldsPerWave; // wave-private scratch (evaluation; the step reuses it)
@@ -1387,16 +1393,19 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
         if (idx >= cap) break;
         unsigned e = PAIS_RING_EMPTY;
+        unsigned long long t0 = 0;
         for (int spins = 0;; ++spins) {
             e = __hip_atomic_load(&ring[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (e != PAIS_RING_EMPTY) break;
             if ((spins & 7) == 7) { // (the shared words are looked at now and then: thousands of idle waves poll)
                 if (__hip_atomic_load(&ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break; // every run of this ring has ended
                 if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            }
-            if (spins > PAIS_RING_SPIN_LIMIT) {
-                if (lane == 0) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (spins == 7) t0 = now;
+                if (now - t0 >= timeoutTicks) { // nobody has published this entry for `timeoutTicks` of wall time
+                    if (lane == 0) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
             __builtin_amdgcn_s_sleep(32);
         }
@@ -1944,7 +1953,7 @@ size_t ring_words(int n, int Nmax, int maxIt) { return ring_seg_words(n, Nmax, m
 template <int NS, bool BYTES, bool ACCR>
 static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
                                   const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive,
-                                  unsigned long long *stat, int waves, int phase, hipStream_t stream)
+                                  unsigned long long *stat, int waves, int phase, unsigned long long timeoutTicks, hipStream_t stream)
 {
     static LdsAttr attr;
     size_t per = eval_lds_bytes(NS, Kmax, ACCR);
@@ -1971,14 +1980,14 @@ static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, u
     int grid = (int)(tasks < waves ? tasks : waves);
     grid = (grid + PAIS_RINGS - 1) / PAIS_RINGS * PAIS_RINGS;
     hipLaunchKernelGGL((k_pso_ring<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, recs, states, n, Nmax, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win, ring, (unsigned)seg, (RingCtl *)ctl, arrive, stat, per);
+                       eval_block_bytes(Kmax), (const WinPix *)win, ring, (unsigned)seg, (RingCtl *)ctl, arrive, stat, per, timeoutTicks);
     return hipGetLastError();
 }
 hipError_t pso_ring(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
                     const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive, unsigned long long *stat,
-                    int waves, int phase, hipStream_t stream)
+                    int waves, int phase, unsigned long long timeoutTicks, hipStream_t stream)
 {
-    PAIS_SHAPE_DISPATCH(pso_ring_launch, sc, recs, states, n, Nmax, Kmax, maxIt, evalBlocks, win, ring, ctl, arrive, stat, waves, phase, stream);
+    PAIS_SHAPE_DISPATCH(pso_ring_launch, sc, recs, states, n, Nmax, Kmax, maxIt, evalBlocks, win, ring, ctl, arrive, stat, waves, phase, timeoutTicks, stream);
 }
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
                     unsigned long long *stat, hipStream_t stream)

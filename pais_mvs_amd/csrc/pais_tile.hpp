@@ -278,12 +278,16 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                                                         //  window row CAN map onto one image column)
                 th = y1 - y0 + 1;
             }
-            const int sz = tw * th;
+            // (a footprint is bounded only by its level -- up to 65535^2 bytes -- and the scan below adds 64 of them: sizes are
+            //  saturated at halfBytes + 1, so that neither the product nor the sum can wrap; every camera from the first one
+            //  that does not fit on is uniformly "not staged")
+            const int szFull = (th > 0 && tw > (halfBytes + 1) / th) ? halfBytes + 1 : tw * th;
+            const int sz = min(szFull, halfBytes + 1);
             int incl = sz;
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) {
                 const int up = __shfl_up(incl, m, 64);
-                incl += (lane >= m) ? up : 0;
+                incl = min(incl + ((lane >= m) ? up : 0), halfBytes + 1);
             }
             const int off = half * halfBytes + incl - sz;
             const bool fits = sz > 0 && incl <= halfBytes;
