@@ -381,7 +381,11 @@ static int ctx_init_work(pais_ctx *ctx)
     if (const char *e = getenv("PAIS_PSO_RING")) ctx->ringMode = atoi(e);
     if (const char *e = getenv("PAIS_RING_PER_CAM")) ctx->ringPerCam = atof(e);
     if (const char *e = getenv("PAIS_RING_TIMEOUT_MS")) ctx->ringTimeoutMs = atof(e);
-    ctx->ringSeedAbove = ctx->splitAbove / 2;
+    // (0 = never, the default: measured on the pawn bench, profiles/r04_seed_ring_ab.txt -- the first pass of the 200 seeds as one
+    //  ring launch costs +3.5 ms per reconstruction against k_pso_iter's 2 x 62 launches: with 2N = 30 particles the one-wave
+    //  swarm step is a long serial chain between two evaluations of a candidate, and 6000 tasks per iteration are two residency
+    //  passes, so the chain of 61 iterations -- not the throughput -- bounds the launch)
+    ctx->ringSeedAbove = 0;
     if (const char *e = getenv("PAIS_RING_SEED_ABOVE")) ctx->ringSeedAbove = atol(e);
     if (const char *e = getenv("PAIS_RING_MAX_MB")) { long v = atol(e); if (v > 0) ctx->ringMaxBytes = (size_t)v << 20; }
     HIPCHK(hipMalloc(&ctx->d_ringCtl, 64 * 8));

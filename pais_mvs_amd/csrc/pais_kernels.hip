@@ -1307,6 +1307,22 @@ __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c,
     }
     return 0;
 }
+// the step as k_pso_ring calls it.  PAIS_RING_STEP_CALL 1: a real function call, so that the step's registers are not part of
+// the evaluation loop's allocation problem.  Measured and NOT kept (profiles/r04_ring_step_call_ab.txt):
+// pawn 85.8-88.1 ms against 82.1-82.5 ms inlined -- the call's frame (368-416 B of scratch per lane: the ABI's callee-saved
+// registers) costs more than the 96 B of the inlined build, whose scratch accesses all sit outside the tap loops (entry: 14
+// stores of kernel arguments; ~7 reloads per evaluation next to ~3 000 VALU instructions; the rest inside the step itself)
+#ifndef PAIS_RING_STEP_CALL
+#define PAIS_RING_STEP_CALL 0
+#endif
+#if PAIS_RING_STEP_CALL
+__attribute__((noinline))
+#endif
+__device__ int pso_step_wave_ring(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax, unsigned char *smem,
+                                  unsigned long long *stat, int lane)
+{
+    return pso_step_wave<true>(sc, recs, c, hd, Nmax, smem, stat, lane);
+}
 // the step kernel of large batches: one wave per candidate
 __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result *recs, unsigned char *states, int n,
                                                  int Nmax, unsigned long long *stat)
@@ -1435,7 +1451,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         __builtin_amdgcn_s_setprio(3); // the step sits on the candidate's critical path
         if (lane == 0) cstore(&arrive[c], 0);
         wave_sync();
-        const int cont = pso_step_wave<true>(sc, recs, c, hd, Nmax, smem, stat, lane);
+        const int cont = pso_step_wave_ring(sc, recs, c, hd, Nmax, smem, stat, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every lane's part of the new swarm (and the counter reset) is out
         wave_sync();
         if (__builtin_amdgcn_readfirstlane(cont)) {

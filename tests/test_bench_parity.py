@@ -62,3 +62,34 @@ def test_bench_line_carries_the_committed_hash():
     c = line["config"]
     assert c["cloud_sha1"] == GOLD["cloud_sha1"] and c["cloud_sha1_expected"] == GOLD["cloud_sha1"] and c["cloud_matches_oracle_golden"] is True
     assert c["patches_per_step"] == GOLD["patches_per_step"] and c["accepted_patches"] == GOLD["accepted_patches"]
+
+
+# ---- the full-size scenes (BASELINE.json configs[2] / configs[4]), bounded to their first rounds -----------------------
+# tests/golden/bench_cloud_ring_r3.json / bench_cloud_dome_r2.json were made by the ORACLE on the GPU box's host cores
+# (tests/golden/make_bench_golden.py --device 0: scenes rendered on the GPU as bench.py does, edge maps for the oracle
+# built next to the pyramids); `bench.py --scene ring --max-rounds 3` / `--scene dome --max-rounds 2` check themselves
+# against them.  The dome's rounds see up to 44 cameras: the one-pixel instantiation of the LDS-tile kernel (K > 32).
+FULL = [("ring", 3, "bench_cloud_ring_r3.json"), ("dome", 2, "bench_cloud_dome_r2.json")]
+
+
+@pytest.mark.parametrize("scene,rounds,name", FULL)
+def test_full_size_golden_files_name_the_bench_workloads(scene, rounds, name):
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+    import bench
+    sys.argv = ["bench.py", "--scene", scene, "--max-rounds", str(rounds)]
+    a = bench.parse()
+    assert (g["scene"], g["parents_per_round"], g["max_rounds"], g["pso_seed"]) == (a.scene, a.parents_per_round, a.max_rounds, 42)
+    assert g["seeds"] == max(a.seeds, 400) and len(g["cloud_sha1"]) == 40 and g["accepted_patches"] > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,rounds,name", FULL)
+def test_full_size_bench_lines_carry_the_oracles_hash(scene, rounds, name):
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", scene, "--max-rounds", str(rounds), "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    c = json.loads(out.stdout.strip().splitlines()[-1])["config"]
+    assert c["cloud_sha1"] == g["cloud_sha1"] and c["cloud_matches_oracle_golden"] is True, (c["cloud_sha1"], g["cloud_sha1"])
+    assert c["patches_per_step"] == g["patches_per_step"] and c["accepted_patches"] == g["accepted_patches"]
+    assert c["speculative_extra_refines_per_step"] == g["speculative_extra_refines"]

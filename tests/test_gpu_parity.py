@@ -16,6 +16,8 @@ Two oracle modes are used (oracle/pais_oracle.h, po_scene.detMath/treeSum):
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -932,7 +934,35 @@ def test_dome_full_size_bounded_rounds(monkeypatch):
         assert len(set(p.cams())) == p.num_cam and p.ref_cam in p.cams()
     assert _surface_error(scene, ps, max(1, len(ps) // 200)) < 2e-3
     sha_tile = m.cloud_sha1()
+    got = [(list(p.center[:]), list(p.normalS[:]), p.cams(), p.fitness, p.correlation) for p in ps]
     m.close()
+    # ... against the ORACLE on this box's host cores, every accepted patch in order, same bits, same camera sets (round 4:
+    # before, the K > 32 instantiation of the tile kernel was only compared with the one-wave kernels).  The oracle reads edge
+    # maps (camera.cpp:72-77): built here by its own C statement over the same levels, a level per thread.
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import po
+    from pais_mvs_amd.mvs import patches_sha1
+    L = po.lib()
+    L.po_sobel_magnitude_normalised.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.po_sobel_magnitude_normalised.restype = None
+
+    def edge(level):
+        out = np.empty(level.shape, dtype=np.float64)
+        L.po_sobel_magnitude_normalised(level.ctypes.data, level.shape[1], level.shape[0], out.ctypes.data)
+        return out
+    with ThreadPoolExecutor(max_workers=min(128, os.cpu_count() or 8)) as ex:
+        jobs = [[ex.submit(edge, np.ascontiguousarray(l, dtype=np.uint8)) for l in cam.pyramid] for cam in scene.cameras]
+        for cam, js in zip(scene.cameras, jobs):
+            cam.edge_pyramid = [j.result() for j in js]
+    want, calls, accepted, spec = common.oracle_reconstruct(cfg, scene, 1024, 2, parallel=True)
+    for cam in scene.cameras:
+        cam.edge_pyramid = []          # (the library below evaluates them on the fly again)
+    assert st.seeds_refined + st.candidates_effective == calls and len(got) == accepted, (calls, accepted, len(got))
+    assert st.candidates_refined - st.candidates_effective == spec
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, (i, a, b)
+    assert sha_tile == patches_sha1(want)
     # the same reconstruction through the one-wave-per-evaluation kernels: the LDS-tile kernel (pais_tile.hpp; K up to 44 here:
     # its one-pixel instantiation for the rounds, the two-pixel one for the seeds) must not change a bit of the cloud
     monkeypatch.setenv("PAIS_TILE", "0")
@@ -1154,8 +1184,77 @@ def test_task_ring_pass_is_the_launch_per_iteration_pass(request, scene_name, mo
 
     ref, _ = run({})                                                       # small batch: k_pso_iter
     ring, ks = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "1", "PAIS_RING_PER_CAM": "0"})   # (no size threshold: this batch is small)
-    assert ks.eval2_launches == 1, ks.eval2_launches                        # one launch for the whole pass
+    assert ks.eval2_launches == 1 and ks.ring_launches == 1 and ks.ring_fallbacks == 0, (ks.eval2_launches, ks.ring_launches)
+    assert ks.ring_evals == ks.eval2_evals > 0
     launches, ks2 = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "0"})
-    assert ks2.eval2_launches > 10
+    assert ks2.eval2_launches > 10 and ks2.ring_launches == 0
     assert ring == launches == ref
+    # a ring pass that does not complete (here: no patience at all -- the first wave that has to wait for an entry raises the
+    # error word) is re-run through the per-iteration launches: the same records, and the re-run is counted
+    for k in ("PAIS_RING_TIMEOUT_MS",):
+        monkeypatch.delenv(k, raising=False)
+    fb, ks3 = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "1", "PAIS_RING_PER_CAM": "0", "PAIS_RING_TIMEOUT_MS": "0"})
+    monkeypatch.delenv("PAIS_RING_TIMEOUT_MS", raising=False)
+    assert ks3.ring_fallbacks == 1 and ks3.eval2_launches > 10, (ks3.ring_fallbacks, ks3.eval2_launches)
+    assert fb == ref
     S.close()
+
+
+@pytest.mark.gpu
+def test_seed_batches_and_device_pointer_batches_through_the_task_ring(pawn_small, monkeypatch):
+    """Round 4: k_pso_ring also runs the passes of SEED batches (2N particles, several dependent passes: the later ones hold
+    only the seeds that lost cameras) and batches on device pointers (pais_refine_batch_device: what a multi-GPU shard is).
+    Records equal the default pipelines' byte for byte; a failing ring pass of a seed batch re-runs the whole batch."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import Context
+    from pais_mvs_amd.mvs import MVS
+    cfg = readme_config()
+    S = common.oracle_scene(cfg, pawn_small)
+    _, seeds = common.seed_candidates(S, pawn_small)
+
+    def run(env):
+        for k in ("PAIS_RING_SEED_ABOVE", "PAIS_PSO_RING", "PAIS_RING_TIMEOUT_MS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = Context(cfg, pawn_small.cameras, device=0, seed=42)
+        out = bytes(c.refine_batch(seeds))
+        ks = c.kernel_stats()
+        c.close()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        return out, ks
+
+    ref, ks0 = run({"PAIS_PSO_RING": "0"})
+    ring, ks1 = run({"PAIS_RING_SEED_ABOVE": "1"})                 # every pass of the seed loop as one ring launch
+    assert ks0.ring_launches == 0 and ks1.ring_launches >= 2 and ks1.ring_fallbacks == 0, (ks1.ring_launches, ks1.ring_fallbacks)
+    assert ring == ref
+    fb, ks2 = run({"PAIS_RING_SEED_ABOVE": "1", "PAIS_RING_TIMEOUT_MS": "0"})
+    assert ks2.ring_fallbacks >= 1 and fb == ref
+    S.close()
+    # device-pointer batches: the sharded code path with a world of one rank (RCCL communicator attached) refines every round
+    # through pais_refine_batch_device; with no size threshold each round is one ring launch
+    def cloud(env):
+        import ctypes as C
+        from pais_mvs_amd import _lib
+        from pais_mvs_amd.mvs import get_unique_id
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = MVS(cfg, pawn_small.cameras, device=0, seed=42)
+        m.comm_init_rccl(0, 1, get_unique_id())
+        m.set_replicate_below(0)                                   # every batch takes the sharded (device-pointer) path
+        for X, vis in pawn_small.seeds:
+            m.add_seed(X, vis)
+        m.refineSeedPatches()
+        m.expansionPatches(64, 6)
+        sha, st = m.cloud_sha1(), m.stats()
+        ks = _lib.KernelStats()
+        m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
+        m.close()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        return sha, st, ks
+    a, sta, ksa = cloud({"PAIS_PSO_RING": "0"})
+    b, stb, ksb = cloud({"PAIS_SPLIT_ABOVE": "1", "PAIS_RING_PER_CAM": "0", "PAIS_RING_SEED_ABOVE": "1"})
+    assert a == b and sta.batches_sharded == stb.batches_sharded > 3
+    assert ksa.ring_launches == 0 and ksb.ring_launches >= sta.batches_sharded and ksb.ring_fallbacks == 0, (ksb.ring_launches, sta.batches_sharded)
