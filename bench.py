@@ -40,6 +40,12 @@ def parse():
     ap.add_argument("--seeds", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", default="", help="e.g. 2,4,8: after the normal line's measurements, run ONE rank of a world of N "
+                    "on this GPU through the real sharded code path (include/pais_mvs.h pais_mvs_emulate: the other ranks' blocks are "
+                    "replayed from a recorded single-rank run) and print measured T_rank(N) next to the model (config.emulated_speedup_at)")
+    ap.add_argument("--emulate-ranks", default="ends", choices=["ends", "all"], help="which ranks of each emulated world are run: "
+                    "the first and the last (default) or every one; T(N) = the slowest")
+    ap.add_argument("--emulate-steps", type=int, default=2)
     return ap.parse_args()
 
 
@@ -310,8 +316,54 @@ def main():
     m.L.pais_ctx_set_fine_timing(m.ctx_handle, 0)
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
 
+    scaling_model = None
     if rank == 0:
         scaling_model = predicted_speedup(m.round_log(), cfg.particleNum, (ks.pso_algorithmic_bytes / ks.pso_evals) if ks.pso_evals else 23000.0)
+    round_log_1 = m.round_log() if rank == 0 else None
+    last_1 = last
+    emulated = None
+    if rank == 0 and world == 1 and args.emulate_world:
+        # One-GPU MEASUREMENT of the sharded path: record a single-rank run, then be rank r of a world of N.
+        worlds = [int(x) for x in args.emulate_world.split(",") if x.strip()]
+        t1 = dt / max(args.steps, 1) * 1e3
+        m.emulate(1)
+        step()
+        fence()
+        ref_sha = m.cloud_sha1()
+        emulated = {"ms_at_1": t1, "ms_at": {}, "ranks_run": {}, "cloud_matches_single_rank": True,
+                    "streamed_rounds_at": {}, "exchange_ms_at": {}, "batches_sharded_at": {},
+                    "note": "measured on ONE GPU: rank r of a world of N runs the real sharded code path (shard refined by the kernels, "
+                            "packed, status header, copy down, unpack, replicated commit; thin batches replicated; rounds streamed) with the "
+                            "other ranks' blocks replayed from a recorded single-rank run in place of ncclAllGather (bytes arrive over "
+                            "PCIe, + %s us of modelled collective latency); T(N) = slowest emulated rank, host time spent preparing the "
+                            "replayed blocks subtracted (emu_replay_ms); speed-up = ms_per_step of this line / T(N).  Not measured: link "
+                            "contention and rank skew." % os.environ.get("PAIS_EMU_LATENCY_US", "25")}
+        for N in worlds:
+            ranks = list(range(N)) if args.emulate_ranks == "all" else sorted(set([0, N - 1]))
+            worst, worst_st = 0.0, None
+            for r in ranks:
+                m.emulate(2, r, N)
+                step()                                   # (buffers of this world size grow here)
+                fence()
+                t0e = time.perf_counter()
+                replay = 0.0
+                for _ in range(max(args.emulate_steps, 1)):
+                    ste = step()
+                    replay += ste.emu_replay_ms
+                fence()
+                te = ((time.perf_counter() - t0e) * 1e3 - replay) / max(args.emulate_steps, 1)
+                if m.cloud_sha1() != ref_sha:
+                    emulated["cloud_matches_single_rank"] = False
+                if te > worst:
+                    worst, worst_st = te, ste
+            emulated["ms_at"][str(N)] = worst
+            emulated[str(N)] = t1 / worst if worst > 0 else None
+            emulated["ranks_run"][str(N)] = ranks
+            emulated["streamed_rounds_at"][str(N)] = int(worst_st.rounds_streamed)
+            emulated["exchange_ms_at"][str(N)] = float(worst_st.exchange_ms)
+            emulated["batches_sharded_at"][str(N)] = int(worst_st.batches_sharded)
+        m.emulate(0)
+    if rank == 0:
         gold_sha, gold_ok = None, None
         try:
             # (bounded workloads of the full-size scenes carry their round count in the name: bench_cloud_ring_r3.json)
@@ -375,6 +427,7 @@ def main():
                        "exchange_ms_per_step": float(last.exchange_ms) if last else 0.0,
                        "exchange_bytes_per_step": int(last.exchange_bytes) if last else 0,
                        "predicted_speedup_at": scaling_model,
+                       "emulated_speedup_at": emulated,
                        "parallelism": "1 process per GPU, candidates of a round sharded over %d GPU(s), one ncclAllGather of the "
                                       "records per sharded round (thin rounds replicated)" % world},
             "roofline": {"bound": "hbm",

@@ -245,6 +245,24 @@ int  pais_pack_records(int n, const pais_patch_result *recs, int max_num_cam, vo
 int  pais_unpack_records(int n, const void *wire, int max_num_cam, pais_patch_result *recs);
 int  pais_pack_records_device(pais_ctx *ctx, int n, const pais_patch_result *d_recs, int max_num_cam, void *d_wire);
 
+/* ---- ADVANCED: what a multi-GPU driver needs to keep ONE synchronisation per sharded batch (the drivers of
+ * include/pais_mvs.h use them; a maintainer who binds those drivers never calls them) ----
+ * pais_refine_batch_device_async: pais_refine_batch_device that never waits for a pure expansion batch, also when its PSO
+ * pass runs as k_pso_ring (whose completion words pais_refine_batch_device reads before it returns).
+ * pais_wire_header_device: the 64-byte status header of this rank's block of the exchange, written on the device behind the
+ * batch's launches: uint32 {PAIS_WIRE_MAGIC, rc, count, rank, 0 x 12}; rc = host_rc if non-zero, PAIS_WIRE_RC_RING_RETRY if
+ * the batch's ring pass did not complete, else 0.
+ * pais_ctx_batch_status: after the caller synchronised with the stream: 0 = the last _async batch is complete; 1 = its ring
+ * pass did not complete: the records are invalid and the caller refines the same batch again (that batch then takes one
+ * launch per iteration).  Every rank reads every header, so all ranks agree on a second exchange. */
+#define PAIS_WIRE_MAGIC 0x50414953u
+#define PAIS_WIRE_RC_RING_RETRY 1
+#define PAIS_WIRE_HEADER_BYTES 64
+int  pais_refine_batch_device_async(pais_ctx *ctx, int n, const pais_candidate *d_cands,
+                                    pais_patch_result *d_out, int max_num_cam, int has_seeds);
+int  pais_wire_header_device(pais_ctx *ctx, int rank, int count, int host_rc, void *d_header);
+int  pais_ctx_batch_status(pais_ctx *ctx);
+
 /* The HIP stream (hipStream_t) all work of this context is enqueued on. */
 void *pais_ctx_stream(pais_ctx *ctx);
 int  pais_ctx_synchronize(pais_ctx *ctx);

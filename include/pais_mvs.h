@@ -52,6 +52,8 @@ typedef struct pais_mvs_stats {
     int64_t rounds_streamed;      /* rounds whose work list went to the GPU in two parts (the second enumerated, the first
                                    * committed, while the other was being refined); host_enumerate_ms / host_commit_ms then
                                    * include host work that ran under the GPU's, gpu_refine_ms only what the host waited for */
+    double  emu_replay_ms;        /* pais_mvs_emulate mode 2: host time spent packing the OTHER ranks' blocks from the recorded
+                                   * run -- work a real rank does not have; bench.py subtracts it from the emulated rank's time */
 } pais_mvs_stats;
 
 /* One entry per GPU batch of the last reconstruction (the seed batch first, then one per expansion round with
@@ -129,6 +131,14 @@ int  pais_mvs_create_ranked(const pais_config *cfg, int num_cams, const pais_cam
  * pointers; returns 0 on success.  The driver stages the records through pinned host memory around the call. */
 typedef int (*pais_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
 int  pais_mvs_comm_init_callback(pais_mvs *m, int rank, int world, pais_allgather_fn fn, void *user);
+/* MEASUREMENT AID: one rank of a larger world on ONE GPU (bench.py --emulate-world).  mode 1 on a single-rank driver records
+ * the records of every batch, keyed by candidate; mode 2 then makes this driver rank `rank` of `world`: every sharded batch
+ * runs the real sharded code path (shard refined on the GPU, packed, status header, copy down, unpack, replicated commit;
+ * thin batches replicated; large rounds streamed) with the other ranks' blocks replayed from the recorded run in place of the
+ * ncclAllGather -- the bytes arrive over PCIe instead of xGMI, plus PAIS_EMU_LATENCY_US (25) of modelled collective launch
+ * latency.  mode 0 switches it off.  What it measures: T_rank(world) on this GPU; what it cannot: link contention and the
+ * wait for the slowest rank (bench.py takes the maximum over the ranks it emulates). */
+int  pais_mvs_emulate(pais_mvs *m, int mode, int rank, int world);
 /* Evaluation waves per iteration below which a multi-rank batch is replicated instead of sharded (default
  * PAIS_REPLICATE_BELOW_WAVES; 0 = always shard).  Must be the same on every rank. */
 int  pais_mvs_set_replicate_below(pais_mvs *m, int waves);

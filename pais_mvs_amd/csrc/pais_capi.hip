@@ -154,6 +154,8 @@ struct pais_ctx {
     size_t arriveBytes = 0;
     bool ringUsed = false;              // by the open batch (its error words are read when the batch ends)
     bool ringSuppressed = false;        // while a batch whose ring pass failed is re-run
+    bool ringSuppressOnce = false;      // the next device batch is such a re-run (pais_ctx_batch_status returned 1)
+    int ringPendingN = 0;               // > 0: candidates of the pais_refine_batch_device_async batch whose ring status has not been read yet
     double ringTimeoutMs = 10000.0;     // PAIS_RING_TIMEOUT_MS: longest wait of a k_pso_ring wave for a ring entry (wall time, s_memrealtime)
     long ringSeedAbove = 0;             // PAIS_RING_SEED_ABOVE: evaluation waves per iteration from which a pass of a SEED batch takes the ring
     size_t ringMaxBytes = (size_t)512 << 20; // PAIS_RING_MAX_MB: batches whose ring would be larger keep the per-iteration launches
@@ -900,11 +902,16 @@ static int ring_failed(pais_ctx *ctx, int n)
 }
 
 // one batch on device pointers, start to end; returns 1 if a ring pass failed (the caller runs it again with the ring off)
-static int refine_device_once(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out, int max_num_cam, int has_seeds)
+// defer: an expansion batch whose pass ran as k_pso_ring returns without waiting for it -- the error words are looked at by
+// the wire header the caller asks for next (pais_wire_header_device) and by pais_ctx_batch_status after the caller's own
+// synchronisation
+static int refine_device_once(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out, int max_num_cam, int has_seeds,
+                              bool defer = false)
 {
     PassPlan &P = ctx->plan;
     P.hostBatch = false;
     ctx->ringUsed = false;
+    ctx->ringPendingN = 0;
     int rc = batch_setup(ctx, P, n, d_cands, d_out, max_num_cam, has_seeds);
     int againCount = 0; // seeds that lost cameras in the previous pass and run another PSO (patch.cpp:140-175)
     const int maxPass = has_seeds ? (PAIS_MAX_VIS + 2) : 1;
@@ -913,6 +920,7 @@ static int refine_device_once(pais_ctx *ctx, int n, const pais_candidate *d_cand
         if ((rc = pass_iterations(ctx, P, P.maxIt + 1)) != 0) { (void)pass_join(ctx, P); break; }
         if ((rc = pass_close(ctx, P)) != 0) break;
         if (!has_seeds && !ctx->ringUsed) break; // (asynchronous at return)
+        if (!has_seeds && defer) { ctx->ringPendingN = n; break; } // (asynchronous too: the ring's status is read later)
         if (has_seeds) HIPCHK(hipMemcpyAsync(ctx->h_counters, P.cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ring_failed(ctx, n)) { ctx->roundHint = 0; return 1; }
@@ -941,6 +949,55 @@ extern "C" int pais_refine_batch_device(pais_ctx *ctx, int n, const pais_candida
         ctx->ringSuppressed = false;
     }
     return rc;
+}
+
+// pais_refine_batch_device that never waits for an expansion batch (a batch with seeds is refined before it returns, as ever)
+extern "C" int pais_refine_batch_device_async(pais_ctx *ctx, int n, const pais_candidate *d_cands, pais_patch_result *d_out,
+                                              int max_num_cam, int has_seeds)
+{
+    if (!ctx || n < 0) return fail_msg("pais_refine_batch_device_async: bad argument");
+    if (n == 0) return 0;
+    if (!d_cands || !d_out) return fail_msg("pais_refine_batch_device_async: null pointer");
+    if (ctx->openBatch >= 0) return fail_msg("pais_refine_batch_device_async: a batch is open on this context");
+    const int hint = ctx->roundHint;
+    const bool suppress = ctx->ringSuppressOnce;
+    ctx->ringSuppressOnce = false;
+    if (suppress) ctx->ringSuppressed = true;
+    int rc = refine_device_once(ctx, n, d_cands, d_out, max_num_cam, has_seeds, true);
+    if (rc == 1) { // (seeds: a pass's ring did not complete)
+        ctx->ringSuppressed = true;
+        ctx->roundHint = hint;
+        rc = refine_device_once(ctx, n, d_cands, d_out, max_num_cam, has_seeds, true);
+    }
+    ctx->ringSuppressed = false;
+    return rc;
+}
+
+// After the caller has synchronised with the context's stream: 0 = the last pais_refine_batch_device_async batch is complete;
+// 1 = its k_pso_ring pass did not complete -- the records are NOT valid, the caller refines the same batch again (the next
+// batch of this context then takes the per-iteration launches).
+extern "C" int pais_ctx_batch_status(pais_ctx *ctx)
+{
+    if (!ctx) return fail_msg("pais_ctx_batch_status: bad argument");
+    if (ctx->ringPendingN <= 0) return 0;
+    const int n = ctx->ringPendingN;
+    ctx->ringPendingN = 0;
+    ctx->countersDirty = false;
+    if (!ring_failed(ctx, n)) return 0;
+    ctx->countersDirty = true;
+    ctx->ringSuppressOnce = true;
+    return 1;
+}
+
+// 64-byte header of a rank's block in the exchange of a sharded batch, written ON THE DEVICE behind the batch's launches:
+// {magic 'PAIS', rc, count, rank, 0...}; rc = host_rc if that is non-zero, else PAIS_WIRE_RC_RING_RETRY when the batch's
+// k_pso_ring pass did not complete (read from the ring's own words: no host round trip before the exchange), else 0.
+extern "C" int pais_wire_header_device(pais_ctx *ctx, int rank, int count, int host_rc, void *d_header)
+{
+    if (!ctx || !d_header) return fail_msg("pais_wire_header_device: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(pais_launch::wire_header(d_header, ctx->ringPendingN > 0 ? ctx->d_ringCtl : nullptr, ctx->ringPendingN, rank, count, host_rc, ctx->stream));
+    return 0;
 }
 
 extern "C" int pais_ctx_set_round_hint(pais_ctx *ctx, int n_round)

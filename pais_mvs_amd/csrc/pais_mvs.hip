@@ -254,12 +254,33 @@ struct pais_mvs {
     int replicateBelow = PAIS_REPLICATE_BELOW_WAVES;
     pais_record_source_fn recordSource = nullptr;
     void *recordUser = nullptr;
-    pais_candidate *d_shardC = nullptr, *h_shardC = nullptr;       // this rank's shard of a batch (device / pinned)
-    pais_patch_result *d_shardR = nullptr;
-    size_t shardCap = 0;
-    void *d_wireS = nullptr, *d_wireAll = nullptr;                 // wire slots: this rank's (header + shard), all ranks'
-    unsigned char *h_wireAll = nullptr, *h_hdr = nullptr;          // pinned
-    size_t wireCap = 0;
+    // a sharded batch in flight (two at most: the parts of a streamed round): this rank's shard on the device, its wire block,
+    // every rank's blocks as the exchange delivers them
+    struct ShardBufs {
+        pais_candidate *d_shardC = nullptr, *h_shardC = nullptr;   // this rank's shard of a batch (device / pinned)
+        pais_patch_result *d_shardR = nullptr;
+        size_t shardCap = 0;
+        void *d_wireS = nullptr, *d_wireAll = nullptr;             // wire slots: this rank's (header + shard), all ranks'
+        unsigned char *h_wireAll = nullptr;                        // pinned
+        size_t wireCap = 0;
+        hipEvent_t packed = nullptr, done = nullptr;
+    } sb[2];
+    struct ShardXfer {
+        ShardBufs *B = nullptr;
+        pais_ctx *lane = nullptr;
+        const pais_candidate *c = nullptr;
+        int n = 0, per = 0, lo = 0, cnt = 0, Kb = 1, Kmax = 1, hasSeeds = 0, localRc = 0;
+        size_t WB = 0, slot = 0;
+        double t0 = 0;
+        bool sharded = false, open = false;                        // sharded: device path + exchange; else replicated on `lane` (host batch)
+    } sx[2];
+    int *d_hs = nullptr, *d_hsAll = nullptr, *h_hs = nullptr;      // growth handshake of the sharded path (4 bytes per rank)
+    // one-GPU emulation of a rank of a larger world (pais_mvs_emulate): the sharded code path with the other ranks' blocks
+    // replayed from the records of a single-rank run of the same workload
+    int emuMode = 0;                                               // 0 off, 1 record (single rank), 2 emulate
+    std::unordered_map<uint64_t, uint32_t> emuIndex;               // candidate key -> position in emuRecs
+    std::vector<pais_patch_result> emuRecs;
+    double emuLatencyUs = 25.0;                                    // PAIS_EMU_LATENCY_US: modelled launch latency of the collective
     std::vector<pais_patch_result> sendBuf;
     std::vector<unsigned char> wireSend, wireAll;
     std::vector<HostCamera> cams;
@@ -313,6 +334,7 @@ struct pais_mvs {
     double prevHostMs = 0, prevGpuMs = 0;
     size_t streamAbove = 192;          // PAIS_STREAM_ABOVE: active parents from which a round is streamed
     double streamSplit = 0.5;          // PAIS_STREAM_SPLIT: share of the active parents in the first part
+    bool streamSharded = true;         // PAIS_STREAM_SHARDED=0: rounds of the multi-GPU path are never streamed (round 3's behaviour)
     int streamHead = 4, streamStep = 2; // PAIS_STREAM_HEAD / _STEP: PSO iterations of a part enqueued when it is opened / per turn after that
     const std::function<int(const pais_candidate *, int)> *onFirstPart = nullptr; // set by the streamed driver for one round_begin
     int firstPart = -1;                // candidates of the first part of the current round (-1: the round is one batch)
@@ -328,8 +350,13 @@ struct pais_mvs {
                 std::string e;
                 if (rccl::Api *a = rccl::api(e)) a->commDestroy(nccl);
             }
-            (void)hipFree(d_shardC); (void)hipFree(d_shardR); (void)hipFree(d_wireS); (void)hipFree(d_wireAll);
-            (void)hipHostFree(h_shardC); (void)hipHostFree(h_wireAll); (void)hipHostFree(h_hdr);
+            for (ShardBufs &b : sb) {
+                (void)hipFree(b.d_shardC); (void)hipFree(b.d_shardR); (void)hipFree(b.d_wireS); (void)hipFree(b.d_wireAll);
+                (void)hipHostFree(b.h_shardC); (void)hipHostFree(b.h_wireAll);
+                if (b.packed) (void)hipEventDestroy(b.packed);
+                if (b.done) (void)hipEventDestroy(b.done);
+            }
+            (void)hipFree(d_hs); (void)hipFree(d_hsAll); (void)hipHostFree(h_hs);
         }
         if (ctx) pais_ctx_destroy(ctx);
     }
@@ -728,6 +755,7 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
     if (const char *e = getenv("PAIS_STREAM_HOST_MS")) m->streamHostMs = atof(e);
     if (const char *e = getenv("PAIS_STREAM_HOST_SHARE")) m->streamHostShare = atof(e);
     if (const char *e = getenv("PAIS_STREAM_HEAD")) m->streamHead = std::max(1, atoi(e));
+    if (const char *e = getenv("PAIS_STREAM_SHARDED")) m->streamSharded = atoi(e) != 0;
     if (const char *e = getenv("PAIS_STREAM_STEP")) m->streamStep = std::max(1, atoi(e));
     if (const char *e = getenv("PAIS_STREAM_SPLIT")) { const double v = atof(e); if (v > 0 && v < 1) m->streamSplit = v; }
     memset(&m->st, 0, sizeof(m->st));
@@ -934,6 +962,223 @@ static int all_gather_host(pais_mvs *m, const void *send, void *recv, size_t byt
     return 0;
 }
 
+// ------------------------------------------------------------ sharded batches ---
+// A batch of n candidates over `world` ranks: contiguous count-balanced shards, every rank refines its own on its GPU
+// (records stay in HBM), packs them into wire slots behind a 64-byte status header WRITTEN ON THE DEVICE
+// (pais_wire_header_device: the header of a rank whose refinement failed -- or whose k_pso_ring pass did not complete -- says
+// so), one ncclAllGather, one copy down, ONE host synchronisation per batch.  Every rank reads every header: all return an
+// error together, or all agree on a second exchange after the ranks whose ring pass failed have refined their shard again.
+// Split in submit / finish so that two batches -- the parts of a streamed round -- can be in flight: both exchanges are
+// enqueued on the driver's own stream in submission order (one communicator, one stream, one order on every rank); the
+// second part is refined on a lane and the exchange waits for its pack through an event.
+struct WireHeader { uint32_t magic; int32_t rc; int32_t count; int32_t rank; };
+static bool sharded_transport(const pais_mvs *m) { return m->ctx && (m->nccl || m->emuMode == 2); }
+
+// every rank grows its buffers for the same batches (sizes follow from the replicated candidate list); a rank that cannot
+// must not leave the others in the collective that follows: the outcome of a growth is agreed on first, 4 bytes per rank
+static int shard_growth_handshake(pais_mvs *m, int localRc)
+{
+    if (m->emuMode == 2 || !m->nccl) return localRc;
+    hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
+    std::string err;
+    rccl::Api *a = rccl::api(err);
+    if (!a || !m->d_hs) return localRc ? localRc : -2;
+    m->h_hs[0] = localRc;
+    if (hipMemcpyAsync(m->d_hs, m->h_hs, sizeof(int), hipMemcpyHostToDevice, xs) != hipSuccess) return -2;
+    if (a->allGather(m->d_hs, m->d_hsAll, sizeof(int), rccl::kInt8, m->nccl, xs) != 0) return -3;
+    if (hipMemcpyAsync(m->h_hs, m->d_hsAll, sizeof(int) * (size_t)m->world, hipMemcpyDeviceToHost, xs) != hipSuccess) return -2;
+    if (hipStreamSynchronize(xs) != hipSuccess) return -2;
+    for (int r = 0; r < m->world; ++r)
+        if (m->h_hs[r] != 0) {
+            if (!localRc) g_mvs_err = "sharded batch: rank " + std::to_string(r) + " could not grow its exchange buffers";
+            return m->h_hs[r] < 0 ? m->h_hs[r] : -2;
+        }
+    return 0;
+}
+
+static int shard_ensure(pais_mvs *m, pais_mvs::ShardBufs &B, size_t per, size_t slot)
+{
+    const int world = m->world;
+    const bool growShard = per > B.shardCap, growWire = slot * (size_t)world > B.wireCap;
+    if (!growShard && !growWire && B.packed) return 0;
+    hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
+    int rc = 0;
+    auto ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) { rc = -2; g_mvs_err = std::string(what) + ": " + hipGetErrorString(e); }
+        return e == hipSuccess;
+    };
+    ok(hipSetDevice(m->device), "hipSetDevice");
+    ok(hipDeviceSynchronize(), "hipDeviceSynchronize"); // (rare: buffers of batches in flight on either lane are about to be replaced)
+    if (!B.packed) {
+        ok(hipEventCreateWithFlags(&B.packed, hipEventDisableTiming), "hipEventCreate");
+        ok(hipEventCreateWithFlags(&B.done, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (growShard && !rc) {
+        (void)hipFree(B.d_shardC); (void)hipFree(B.d_shardR); (void)hipHostFree(B.h_shardC);
+        B.d_shardC = nullptr; B.d_shardR = nullptr; B.h_shardC = nullptr; B.shardCap = 0;
+        const size_t cap = per + per / 2 + 64;
+        if (ok(hipMalloc((void **)&B.d_shardC, sizeof(pais_candidate) * cap), "hipMalloc(shard candidates)") &&
+            ok(hipMalloc((void **)&B.d_shardR, sizeof(pais_patch_result) * cap), "hipMalloc(shard records)") &&
+            ok(hipHostMalloc((void **)&B.h_shardC, sizeof(pais_candidate) * cap, hipHostMallocDefault), "hipHostMalloc(shard candidates)"))
+            B.shardCap = cap;
+    }
+    if (growWire && !rc) {
+        (void)hipFree(B.d_wireS); (void)hipFree(B.d_wireAll); (void)hipHostFree(B.h_wireAll);
+        B.d_wireS = nullptr; B.d_wireAll = nullptr; B.h_wireAll = nullptr; B.wireCap = 0;
+        const size_t cap = slot * (size_t)world * 3 / 2 + 4096;
+        if (ok(hipMalloc(&B.d_wireS, cap / world + 4096), "hipMalloc(wire block)") && ok(hipMalloc(&B.d_wireAll, cap), "hipMalloc(wire blocks)") &&
+            ok(hipHostMalloc((void **)&B.h_wireAll, cap, hipHostMallocDefault), "hipHostMalloc(wire blocks)"))
+            B.wireCap = cap;
+    }
+    (void)xs;
+    return shard_growth_handshake(m, rc);
+}
+
+// other ranks' blocks of an emulated exchange, from the records of the single-rank run (host, into the pinned staging)
+static int emu_fill_blocks(pais_mvs *m, pais_mvs::ShardXfer &X)
+{
+    const double t0 = now_ms();
+    for (int r = 0; r < m->world; ++r) {
+        if (r == m->rank) continue;
+        unsigned char *blk = X.B->h_wireAll + X.slot * (size_t)r;
+        const int rlo = std::min(r * X.per, X.n), rcnt = std::min(rlo + X.per, X.n) - rlo;
+        WireHeader hd = {PAIS_WIRE_MAGIC, 0, rcnt, r};
+        memset(blk, 0, kWireHeader);
+        memcpy(blk, &hd, sizeof(hd));
+        for (int i = 0; i < rcnt; ++i) {
+            auto it = m->emuIndex.find(X.c[rlo + i].key);
+            if (it == m->emuIndex.end()) return mfail("emulated world: a candidate of this run is not among the recorded run's (another workload?)");
+            if (pais_pack_records(1, &m->emuRecs[it->second], X.Kb, blk + kWireHeader + X.WB * (size_t)i)) return mfail(pais_last_error());
+        }
+    }
+    m->st.emu_replay_ms += now_ms() - t0;
+    return 0;
+}
+
+// the exchange of X's blocks, enqueued on the driver's stream behind X's pack (event), and the copy down
+static int shard_exchange(pais_mvs *m, pais_mvs::ShardXfer &X)
+{
+    hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
+    pais_mvs::ShardBufs &B = *X.B;
+    if (X.lane != m->ctx) MHIP(hipStreamWaitEvent(xs, B.packed, 0));
+    if (m->emuMode == 2) {
+        // the other ranks' blocks arrive from the host (about what the links would deliver), this rank's own from its buffer
+        for (int r = 0; r < m->world; ++r) {
+            unsigned char *dst = (unsigned char *)B.d_wireAll + X.slot * (size_t)r;
+            if (r == m->rank) MHIP(hipMemcpyAsync(dst, B.d_wireS, X.slot, hipMemcpyDeviceToDevice, xs));
+            else MHIP(hipMemcpyAsync(dst, B.h_wireAll + X.slot * (size_t)r, X.slot, hipMemcpyHostToDevice, xs));
+        }
+    } else {
+        std::string err;
+        rccl::Api *a = rccl::api(err);
+        if (!a) return mfail(err.c_str());
+        int nr = a->allGather(B.d_wireS, B.d_wireAll, X.slot, rccl::kInt8, m->nccl, xs);
+        if (nr != 0) { g_mvs_err = std::string("ncclAllGather: ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
+    }
+    MHIP(hipMemcpyAsync(B.h_wireAll, B.d_wireAll, X.slot * (size_t)m->world, hipMemcpyDeviceToHost, xs));
+    MHIP(hipEventRecord(B.done, xs));
+    m->st.exchange_bytes += (int64_t)(X.slot * (size_t)m->world);
+    return 0;
+}
+
+// this rank's shard: candidates up, refined, packed, header (all on X.lane's stream, nothing waited for)
+static void shard_refine_enqueue(pais_mvs *m, pais_mvs::ShardXfer &X)
+{
+    pais_mvs::ShardBufs &B = *X.B;
+    hipStream_t ls = (hipStream_t)pais_ctx_stream(X.lane);
+    int rc = 0;
+    if (X.cnt > 0) {
+        memcpy(B.h_shardC, X.c + X.lo, sizeof(pais_candidate) * (size_t)X.cnt);
+        if (hipMemcpyAsync(B.d_shardC, B.h_shardC, sizeof(pais_candidate) * (size_t)X.cnt, hipMemcpyHostToDevice, ls) != hipSuccess) rc = -2;
+        if (!rc) rc = pais_refine_batch_device_async(X.lane, X.cnt, B.d_shardC, B.d_shardR, X.Kmax, X.hasSeeds);
+        if (rc) g_mvs_err = pais_last_error();
+        else if (pais_pack_records_device(X.lane, X.cnt, B.d_shardR, X.Kb, (unsigned char *)B.d_wireS + kWireHeader)) { rc = -2; g_mvs_err = pais_last_error(); }
+    }
+    X.localRc = rc;
+    // (a rank whose refinement failed still takes part in the collective: its header carries the status)
+    if (pais_wire_header_device(X.lane, m->rank, X.cnt, rc, B.d_wireS)) { if (!X.localRc) X.localRc = -2; g_mvs_err = pais_last_error(); }
+    if (X.lane != m->ctx) (void)hipEventRecord(B.packed, ls);
+}
+
+static int shard_submit(pais_mvs *m, pais_mvs::ShardXfer &X, pais_mvs::ShardBufs &B, pais_ctx *lane, int n, const pais_candidate *c, int has_seeds)
+{
+    const int world = m->world;
+    X.B = &B; X.lane = lane; X.c = c; X.n = n; X.hasSeeds = has_seeds; X.sharded = true; X.open = true;
+    X.per = (n + world - 1) / world;
+    X.lo = std::min(m->rank * X.per, n);
+    X.cnt = std::min(X.lo + X.per, n) - X.lo;
+    // What travels: wire slots (include/pais_hip.h "wire format of a record") sized for the batch's largest camera count --
+    // the same on every rank, the candidate list is replicated
+    X.Kb = 1;
+    for (int i = 0; i < n; ++i) X.Kb = std::max(X.Kb, c[i].num_cam);
+    X.Kmax = 1;
+    for (int i = X.lo; i < X.lo + X.cnt; ++i) X.Kmax = std::max(X.Kmax, c[i].num_cam);
+    X.WB = pais_record_wire_bytes(X.Kb);
+    X.slot = kWireHeader + X.WB * (size_t)X.per;
+    X.t0 = now_ms();
+    int rc = shard_ensure(m, B, (size_t)X.per, X.slot);
+    if (rc) { X.open = false; return rc; }
+    MHIP(hipSetDevice(m->device));
+    if (m->emuMode == 2 && (rc = emu_fill_blocks(m, X)) != 0) { X.open = false; return rc; }
+    shard_refine_enqueue(m, X);
+    rc = shard_exchange(m, X);
+    if (rc) X.open = false;
+    return rc;
+}
+
+// waits for X's exchange, reads every rank's status, unpacks the n records into out
+static int shard_finish(pais_mvs *m, pais_mvs::ShardXfer &X, pais_patch_result *out)
+{
+    if (!X.open) return mfail("sharded batch: nothing in flight");
+    X.open = false;
+    const int world = m->world;
+    pais_mvs::ShardBufs &B = *X.B;
+    for (int attempt = 0;; ++attempt) {
+        MHIP(hipEventSynchronize(B.done));
+        if (m->emuMode == 2 && m->emuLatencyUs > 0) { // modelled launch latency of the collective (the bytes moved for real, over PCIe)
+            const double t1 = now_ms() + m->emuLatencyUs * 1e-3;
+            while (now_ms() < t1) {}
+        }
+        const int mine = X.cnt > 0 ? pais_ctx_batch_status(X.lane) : 0; // (consumes this rank's ring status; the header says the same)
+        bool retry = false;
+        for (int r = 0; r < world; ++r) {
+            WireHeader hd;
+            memcpy(&hd, B.h_wireAll + X.slot * (size_t)r, sizeof(hd));
+            const int rlo = std::min(r * X.per, X.n), rcnt = std::min(rlo + X.per, X.n) - rlo;
+            if (hd.magic != PAIS_WIRE_MAGIC || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
+            if (hd.rc == PAIS_WIRE_RC_RING_RETRY) { retry = true; continue; }
+            if (hd.rc != 0) {
+                if (r != m->rank || g_mvs_err.empty()) g_mvs_err = "sharded batch: rank " + std::to_string(r) + " failed to refine its shard (rc " + std::to_string(hd.rc) + ")";
+                return hd.rc < 0 ? hd.rc : -1;
+            }
+        }
+        if (!retry) break;
+        if (attempt >= 1) return mfail("sharded batch: a shard did not complete twice");
+        // some rank's k_pso_ring pass did not complete: those ranks refine their shard again (one launch per iteration), every
+        // rank sends its block again -- all ranks have read the same headers, so all take this second exchange
+        if (mine == 1) shard_refine_enqueue(m, X);
+        else if (X.lane != m->ctx) MHIP(hipEventRecord(B.packed, (hipStream_t)pais_ctx_stream(X.lane)));
+        int rc = shard_exchange(m, X);
+        if (rc) return rc;
+    }
+    m->st.exchange_ms += now_ms() - X.t0; // (from the submission: refinement of the shard included)
+    for (int r = 0; r < world; ++r) {
+        const int rlo = std::min(r * X.per, X.n), rcnt = std::min(rlo + X.per, X.n) - rlo;
+        if (rcnt > 0 && pais_unpack_records(rcnt, B.h_wireAll + X.slot * (size_t)r + kWireHeader, X.Kb, out + rlo)) return mfail(pais_last_error());
+    }
+    return 0;
+}
+
+static void emu_record(pais_mvs *m, int n, const pais_candidate *c, const pais_patch_result *recs)
+{
+    for (int i = 0; i < n; ++i) {
+        auto it = m->emuIndex.find(c[i].key);
+        if (it != m->emuIndex.end()) { m->emuRecs[it->second] = recs[i]; continue; }
+        m->emuIndex.emplace(c[i].key, (uint32_t)m->emuRecs.size());
+        m->emuRecs.push_back(recs[i]);
+    }
+}
+
 // The batch entry of the drivers: one rank -> pais_refine_batch; several ranks -> shard, refine, all-gather.
 // *view: where the n records are (out, or a pinned staging buffer that stays valid until the next batch)
 static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_result *out, int has_seeds, const pais_patch_result **view)
@@ -941,7 +1186,11 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
     *view = out;
     if (n <= 0) return 0;
     const int world = m->world;
-    if (world <= 1 && !m->nccl && !m->gatherCb) return refine_local(m, n, c, out, has_seeds, view);
+    if (world <= 1 && !m->nccl && !m->gatherCb) {
+        const int rc = refine_local(m, n, c, out, has_seeds, view);
+        if (!rc && m->emuMode == 1) emu_record(m, n, c, *view);
+        return rc;
+    }
     // a batch of fewer than replicateBelow evaluation waves per PSO iteration (candidates x particles; seeds run twice the
     // particles) is latency bound on ONE GPU: its per-iteration launches take one evaluation wave's latency whatever the
     // number of GPUs, so splitting it buys nothing and the exchange costs -- replicated, no collective
@@ -951,90 +1200,42 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
         return refine_local(m, n, c, out, has_seeds, view);
     }
     m->st.batches_sharded++;
+    m->results.resize((size_t)n);
+    if (sharded_transport(m)) {
+        // RCCL (or its one-GPU emulation): records stay in HBM, ONE ncclAllGather on the driver's stream, ONE synchronisation
+        int rc = shard_submit(m, m->sx[0], m->sb[0], m->ctx, n, c, has_seeds);
+        if (!rc) rc = shard_finish(m, m->sx[0], m->results.data());
+        if (rc) return rc;
+        *view = m->results.data();
+        return 0;
+    }
+    // records through host memory: GPU-less driver, or a caller-supplied transport
     const int per = (n + world - 1) / world;
     const int lo = std::min(m->rank * per, n), hi = std::min(lo + per, n), cnt = hi - lo;
-    // What travels: wire slots (include/pais_hip.h "wire format of a record") sized for the batch's largest camera count --
-    // the same on every rank, the candidate list is replicated -- behind a 64-byte header per rank that carries the rank's
-    // status: a rank whose refinement failed still takes part in the collective and every rank returns the error together
-    // (no rank is left waiting in an all-gather the failed one never entered).
     int Kb = 1;
     for (int i = 0; i < n; ++i) Kb = std::max(Kb, c[i].num_cam);
     const size_t WB = pais_record_wire_bytes(Kb), slot = kWireHeader + WB * (size_t)per;
-    struct WireHeader { uint32_t magic; int32_t rc; int32_t count; int32_t rank; };
-    const uint32_t kMagic = 0x50414953u; // "PAIS"
     m->wireAll.resize(slot * (size_t)world);
-    m->results.resize((size_t)n);
     int localRc = 0;
-    if (!m->ctx || !m->nccl) {
-        // records through host memory: GPU-less driver, or a caller-supplied transport
-        m->sendBuf.assign((size_t)per, pais_patch_result());
-        if (cnt > 0) localRc = refine_local(m, cnt, c + lo, m->sendBuf.data(), has_seeds);
-        m->wireSend.assign(slot, 0);
-        WireHeader hd = {kMagic, localRc, cnt, m->rank};
-        memcpy(m->wireSend.data(), &hd, sizeof(hd));
-        if (!localRc && pais_pack_records(cnt, m->sendBuf.data(), Kb, m->wireSend.data() + kWireHeader)) localRc = -1;
+    m->sendBuf.assign((size_t)per, pais_patch_result());
+    if (cnt > 0) localRc = refine_local(m, cnt, c + lo, m->sendBuf.data(), has_seeds);
+    m->wireSend.assign(slot, 0);
+    WireHeader hd0 = {PAIS_WIRE_MAGIC, localRc, cnt, m->rank};
+    memcpy(m->wireSend.data(), &hd0, sizeof(hd0));
+    if (!localRc && pais_pack_records(cnt, m->sendBuf.data(), Kb, m->wireSend.data() + kWireHeader)) localRc = -1;
+    {
         const double t0 = now_ms();
         int rc = all_gather_host(m, m->wireSend.data(), m->wireAll.data(), slot);
         m->st.exchange_ms += now_ms() - t0;
         m->st.exchange_bytes += (int64_t)(slot * (size_t)world);
         if (rc) return rc;
-    } else {
-        // RCCL: candidates up, records stay in HBM, packed by a kernel, ONE ncclAllGather on the context's stream, slots down
-        MHIP(hipSetDevice(m->device));
-        hipStream_t st = (hipStream_t)pais_ctx_stream(m->ctx);
-        if ((size_t)per > m->shardCap) {
-            MHIP(hipStreamSynchronize(st));
-            (void)hipFree(m->d_shardC); (void)hipFree(m->d_shardR); (void)hipHostFree(m->h_shardC);
-            m->d_shardC = nullptr; m->d_shardR = nullptr; m->h_shardC = nullptr;
-            const size_t cap = (size_t)per + (size_t)per / 2 + 64;
-            MHIP(hipMalloc((void **)&m->d_shardC, sizeof(pais_candidate) * cap));
-            MHIP(hipMalloc((void **)&m->d_shardR, sizeof(pais_patch_result) * cap));
-            MHIP(hipHostMalloc((void **)&m->h_shardC, sizeof(pais_candidate) * cap, hipHostMallocDefault));
-            m->shardCap = cap;
-        }
-        if (slot * (size_t)world > m->wireCap) {
-            MHIP(hipStreamSynchronize(st));
-            (void)hipFree(m->d_wireS); (void)hipFree(m->d_wireAll); (void)hipHostFree(m->h_wireAll); (void)hipHostFree(m->h_hdr);
-            m->d_wireS = nullptr; m->d_wireAll = nullptr; m->h_wireAll = nullptr; m->h_hdr = nullptr;
-            const size_t cap = slot * (size_t)world * 3 / 2 + 4096;
-            MHIP(hipMalloc((void **)&m->d_wireS, cap / world + 4096));
-            MHIP(hipMalloc((void **)&m->d_wireAll, cap));
-            MHIP(hipHostMalloc((void **)&m->h_wireAll, cap, hipHostMallocDefault));
-            MHIP(hipHostMalloc((void **)&m->h_hdr, kWireHeader, hipHostMallocDefault));
-            m->wireCap = cap;
-        }
-        if (cnt > 0) {
-            int Kmax = 1;
-            for (int i = lo; i < hi; ++i) Kmax = std::max(Kmax, c[i].num_cam);
-            memcpy(m->h_shardC, c + lo, sizeof(pais_candidate) * (size_t)cnt);
-            MHIP(hipMemcpyAsync(m->d_shardC, m->h_shardC, sizeof(pais_candidate) * (size_t)cnt, hipMemcpyHostToDevice, st));
-            localRc = pais_refine_batch_device(m->ctx, cnt, m->d_shardC, m->d_shardR, Kmax, has_seeds);
-            if (localRc) g_mvs_err = pais_last_error();
-            else if (pais_pack_records_device(m->ctx, cnt, m->d_shardR, Kb, (unsigned char *)m->d_wireS + kWireHeader)) { localRc = -2; g_mvs_err = pais_last_error(); }
-        }
-        MHIP(hipStreamSynchronize(st)); // (h_hdr of the previous batch has been consumed; the seed loop is synchronous anyway)
-        WireHeader hd = {kMagic, localRc, cnt, m->rank};
-        memset(m->h_hdr, 0, kWireHeader);
-        memcpy(m->h_hdr, &hd, sizeof(hd));
-        MHIP(hipMemcpyAsync(m->d_wireS, m->h_hdr, kWireHeader, hipMemcpyHostToDevice, st));
-        std::string err;
-        rccl::Api *a = rccl::api(err);
-        if (!a) return mfail(err.c_str());
-        const double t0 = now_ms();
-        int nr = a->allGather(m->d_wireS, m->d_wireAll, slot, rccl::kInt8, m->nccl, st);
-        if (nr != 0) { g_mvs_err = std::string("ncclAllGather: ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
-        MHIP(hipMemcpyAsync(m->h_wireAll, m->d_wireAll, slot * (size_t)world, hipMemcpyDeviceToHost, st));
-        MHIP(hipStreamSynchronize(st));
-        m->st.exchange_ms += now_ms() - t0;
-        m->st.exchange_bytes += (int64_t)(slot * (size_t)world);
-        memcpy(m->wireAll.data(), m->h_wireAll, slot * (size_t)world);
     }
     // every rank reads every rank's status, then the shards in rank order (contiguous, count balanced)
     for (int r = 0; r < world; ++r) {
         WireHeader hd;
         memcpy(&hd, m->wireAll.data() + slot * (size_t)r, sizeof(hd));
         const int rlo = std::min(r * per, n), rcnt = std::min(rlo + per, n) - rlo;
-        if (hd.magic != kMagic || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
+        if (hd.magic != PAIS_WIRE_MAGIC || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
         if (hd.rc != 0) {
             if (r != m->rank || g_mvs_err.empty()) g_mvs_err = "sharded batch: rank " + std::to_string(r) + " failed to refine its shard (rc " + std::to_string(hd.rc) + ")";
             return hd.rc < 0 ? hd.rc : -1;
@@ -1079,6 +1280,31 @@ extern "C" int pais_mvs_comm_init_rccl(pais_mvs *m, int rank, int world, const p
     m->nccl = comm;
     m->rank = rank;
     m->world = world;
+    MHIP(hipMalloc((void **)&m->d_hs, sizeof(int)));
+    MHIP(hipMalloc((void **)&m->d_hsAll, sizeof(int) * (size_t)world));
+    MHIP(hipHostMalloc((void **)&m->h_hs, sizeof(int) * (size_t)std::max(world, 1), hipHostMallocDefault));
+    return 0;
+}
+
+// One-GPU emulation of one rank of a larger world (measurement aid: bench.py --emulate-world).
+//   mode 1 (record; a single-rank driver): the records of every batch are kept, keyed by candidate (they survive pais_mvs_reset);
+//   mode 2 (emulate rank `rank` of `world`): every sharded batch runs the real sharded code path -- this rank's shard refined on
+//           the GPU, packed, header, copy down, unpack, replicated commit, thin batches replicated -- with the other ranks' blocks
+//           packed from the recorded records and copied to the device in place of the ncclAllGather (plus PAIS_EMU_LATENCY_US
+//           of modelled collective launch latency); the host time spent preparing those blocks is accounted in
+//           pais_mvs_stats::emu_replay_ms, work a real rank does not have;
+//   mode 0: off (the recorded records are dropped).
+extern "C" int pais_mvs_emulate(pais_mvs *m, int mode, int rank, int world)
+{
+    if (!m || mode < 0 || mode > 2) return mfail("pais_mvs_emulate: bad argument");
+    if (m->nccl || m->gatherCb) return mfail("pais_mvs_emulate: a communicator is attached");
+    if (mode == 2 && (!m->ctx || world < 1 || rank < 0 || rank >= world)) return mfail("pais_mvs_emulate: bad rank / world, or no GPU");
+    if (mode == 2 && m->emuRecs.empty()) return mfail("pais_mvs_emulate: nothing recorded (run the workload in mode 1 first)");
+    if (const char *e = getenv("PAIS_EMU_LATENCY_US")) m->emuLatencyUs = atof(e);
+    m->emuMode = mode;
+    if (mode == 2) { m->rank = rank; m->world = world; }
+    else { m->rank = 0; m->world = 1; }
+    if (mode == 0) { m->emuIndex.clear(); std::vector<pais_patch_result>().swap(m->emuRecs); }
     return 0;
 }
 
@@ -1696,18 +1922,50 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         const pais_candidate *c;
         const pais_patch_result *recs = m->results.data();
         int n;
-        // one GPU, large round: streamed (see pais_mvs::lane1)
-        const bool canStream = m->ctx && m->world <= 1 && !m->nccl && !m->gatherCb &&
+        // large round: streamed (see pais_mvs::lane1) -- on one GPU, and (round 4) on the sharded path: each part is a sharded
+        // batch of its own, the two exchanges enqueued on the driver's stream in part order (shard_submit / shard_finish)
+        const bool oneGpu = m->ctx && m->world <= 1 && !m->nccl && !m->gatherCb && m->emuMode != 2;
+        const bool shardStream = sharded_transport(m) && m->streamSharded;
+        const bool canStream = (oneGpu || shardStream) && m->emuMode != 1 &&
                                (m->streamRounds >= 2 ||
                                 (m->streamRounds == 1 && m->prevHostMs >= m->streamHostMs && m->prevHostMs >= m->streamHostShare * m->prevGpuMs));
         int beginRc = 0;
         double tFirst = 0;
         double enqueueMs = 0; // host time of the first part's enqueue: inside round_begin, but not enumeration
+        // a part of a streamed round on the sharded path: a sharded batch (device path + exchange), or -- too thin to split --
+        // replicated on its lane as a host batch
+        auto part_submit = [&](int idx, pais_ctx *lane, int np, const pais_candidate *cc, int nRound) -> int {
+            pais_mvs::ShardXfer &X = m->sx[idx];
+            if ((long)np * m->cfg.particleNum >= (long)m->replicateBelow) {
+                m->st.batches_sharded++;
+                (void)pais_ctx_set_round_hint(lane, (nRound + m->world - 1) / m->world);
+                return shard_submit(m, X, m->sb[idx], lane, np, cc, 0);
+            }
+            m->st.batches_replicated++;
+            X.sharded = false; X.lane = lane; X.n = np; X.open = true;
+            (void)pais_ctx_set_round_hint(lane, nRound);
+            const int rc = pais_refine_batch_begin(lane, np, cc);
+            if (rc) { g_mvs_err = pais_last_error(); X.open = false; }
+            return rc;
+        };
+        auto part_finish = [&](int idx, pais_patch_result *out, const pais_patch_result **view) -> int {
+            pais_mvs::ShardXfer &X = m->sx[idx];
+            if (!X.open) return 0;
+            if (X.sharded) { *view = out; return shard_finish(m, X, out); }
+            X.open = false;
+            const int rc = pais_refine_batch_end(X.lane, view);
+            if (rc) g_mvs_err = pais_last_error();
+            return rc;
+        };
         const std::function<int(const pais_candidate *, int)> firstPart = [&](const pais_candidate *cc, int n0) {
             tFirst = now_ms();
-            (void)pais_ctx_set_round_hint(m->ctx, (int)((double)n0 / m->streamSplit)); // the round's size, as far as it is known
-            beginRc = pais_refine_batch_open(m->ctx, n0, cc, m->streamHead); // the head of its launch chain; the rest below
-            if (beginRc) g_mvs_err = pais_last_error();
+            if (shardStream) {
+                beginRc = part_submit(0, m->ctx, n0, cc, (int)((double)n0 / m->streamSplit));
+            } else {
+                (void)pais_ctx_set_round_hint(m->ctx, (int)((double)n0 / m->streamSplit)); // the round's size, as far as it is known
+                beginRc = pais_refine_batch_open(m->ctx, n0, cc, m->streamHead); // the head of its launch chain; the rest below
+                if (beginRc) g_mvs_err = pais_last_error();
+            }
             enqueueMs = now_ms() - tFirst;
             return beginRc;
         };
@@ -1718,11 +1976,49 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         m->st.host_enumerate_ms -= enqueueMs;
         if (rc < 0) {
             const pais_patch_result *dummy;
-            if (m->firstPart > 0 && !beginRc) (void)pais_refine_batch_end(m->ctx, &dummy); // nothing stays open behind an error
+            if (m->firstPart > 0 && !beginRc) { // nothing stays open behind an error
+                if (shardStream) { m->results.resize((size_t)std::max(m->firstPart, 1)); (void)part_finish(0, m->results.data(), &dummy); }
+                else (void)pais_refine_batch_end(m->ctx, &dummy);
+            }
             m->firstPart = -1;
             return beginRc ? beginRc : rc;
         }
         if (rc == 1) break;
+        if (m->firstPart >= 0 && shardStream) {
+            const int n0 = m->firstPart, n1 = n - n0;
+            const double enumMs = m->lastEnumerateMs;
+            int kmax = 1;
+            for (int i = 0; i < n; ++i) kmax = std::max(kmax, c[i].num_cam);
+            m->results.resize((size_t)std::max(n, 1));
+            const pais_patch_result *v0 = nullptr, *v1 = nullptr;
+            if (n1 > 0) {
+                if (!m->lane1 && pais_ctx_fork_lane(m->ctx, &m->lane1)) { g_mvs_err = pais_last_error(); (void)part_finish(0, m->results.data(), &v0); return -2; }
+                if (n0 == 0) tFirst = now_ms();
+                if (part_submit(1, m->lane1, n1, c + n0, n)) { (void)part_finish(0, m->results.data(), &v0); return -2; }
+            }
+            double commitMs = 0;
+            if (n0 > 0) {
+                if (part_finish(0, m->results.data(), &v0)) { (void)part_finish(1, m->results.data() + n0, &v1); return -2; }
+                const double t1 = now_ms();
+                commit_records(m, v0, 0, n0);
+                commitMs += now_ms() - t1;
+            }
+            if (n1 > 0 && part_finish(1, m->results.data() + n0, &v1)) return -2;
+            const double t2 = now_ms();
+            if (n1 > 0) commit_records(m, v1, n0, n);
+            rc = commit_finish(m, n);
+            commitMs += now_ms() - t2;
+            m->st.host_commit_ms += commitMs;
+            if (rc) return rc;
+            const double tRef = n > 0 ? std::max(0.0, (now_ms() - tFirst) - commitMs) : 0.0;
+            m->st.gpu_refine_ms += tRef;
+            m->st.rounds_streamed++;
+            if (n > 0) m->roundLog.push_back(pais_round_log{n, 0, 1, kmax, tRef, enumMs, commitMs});
+            m->prevHostMs = enumMs + commitMs;
+            m->prevGpuMs = tRef + commitMs;
+            if (max_rounds > 0 && ++rounds >= max_rounds) break;
+            continue;
+        }
         if (m->firstPart >= 0) {
             const int n0 = m->firstPart, n1 = n - n0;
             const double enumMs = m->lastEnumerateMs;

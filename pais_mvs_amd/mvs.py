@@ -19,7 +19,7 @@ class MvsStats(C.Structure):
                 ("parents_popped", C.c_int64), ("pso_evals_effective", C.c_int64),
                 ("host_enumerate_ms", C.c_double), ("host_commit_ms", C.c_double), ("gpu_refine_ms", C.c_double),
                 ("batches_sharded", C.c_int64), ("batches_replicated", C.c_int64), ("exchange_ms", C.c_double),
-                ("exchange_bytes", C.c_int64), ("rounds_streamed", C.c_int64)]
+                ("exchange_bytes", C.c_int64), ("rounds_streamed", C.c_int64), ("emu_replay_ms", C.c_double)]
 
 
 class RoundLog(C.Structure):
@@ -82,6 +82,7 @@ def _bind(L):
     L.pais_mvs_comm_init_callback.argtypes = [vp, C.c_int, C.c_int, ALLGATHER_FN, vp]
     L.pais_mvs_set_replicate_below.argtypes = [vp, C.c_int]
     L.pais_mvs_set_record_source.argtypes = [vp, RECORD_SOURCE_FN, vp]
+    L.pais_mvs_emulate.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L._mvs_bound = True
 
 
@@ -207,6 +208,10 @@ class MVS:
                 return 1
         self._gather_cb = ALLGATHER_FN(cb)       # keep the trampoline alive
         self._check(self.L.pais_mvs_comm_init_callback(self.h, rank, world, self._gather_cb, None), "pais_mvs_comm_init_callback")
+
+    def emulate(self, mode: int, rank: int = 0, world: int = 1):
+        """include/pais_mvs.h pais_mvs_emulate: 1 record a single-rank run, 2 be rank `rank` of `world` on this one GPU, 0 off."""
+        self._check(self.L.pais_mvs_emulate(self.h, int(mode), int(rank), int(world)), "pais_mvs_emulate")
 
     def set_replicate_below(self, per_rank: int):
         self._check(self.L.pais_mvs_set_replicate_below(self.h, int(per_rank)), "pais_mvs_set_replicate_below")

@@ -1258,3 +1258,58 @@ def test_seed_batches_and_device_pointer_batches_through_the_task_ring(pawn_smal
     b, stb, ksb = cloud({"PAIS_SPLIT_ABOVE": "1", "PAIS_RING_PER_CAM": "0", "PAIS_RING_SEED_ABOVE": "1"})
     assert a == b and sta.batches_sharded == stb.batches_sharded > 3
     assert ksa.ring_launches == 0 and ksb.ring_launches >= sta.batches_sharded and ksb.ring_fallbacks == 0, (ksb.ring_launches, sta.batches_sharded)
+
+
+@pytest.mark.gpu
+def test_emulated_ranks_of_a_larger_world_rebuild_the_single_rank_cloud(pawn_small, monkeypatch):
+    """include/pais_mvs.h pais_mvs_emulate (round 4): rank r of a world of N on ONE GPU -- the real sharded code path (shard
+    refined by the kernels, packed, device-written status header, copy down, unpack, replicated commit), the other ranks'
+    blocks replayed from a recorded single-rank run.  Every rank of a world of 2 and of 3 (ragged shards) rebuilds the
+    single-rank cloud bit for bit: with rounds as one sharded batch, with every round streamed in two sharded parts (two
+    exchanges ordered on one stream), and when this rank's k_pso_ring pass does not complete (status header -> second
+    exchange after the per-iteration re-run)."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    cfg = readme_config(particleNum=8, maxIteration=12)
+
+    def run(env, worlds):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = MVS(cfg, pawn_small.cameras, device=0, seed=42)
+        m.set_replicate_below(0)                                   # (test-size batches are thin: shard every one of them)
+
+        def step():
+            m.reset()
+            for X, vis in pawn_small.seeds:
+                m.add_seed(X, vis)
+            m.refineSeedPatches()
+            m.expansionPatches(4096, 10)
+            return m.cloud_sha1(), m.stats()
+        ref, st0 = step()
+        m.emulate(1)
+        rec, _ = step()
+        assert rec == ref
+        out = []
+        for N in worlds:
+            for r in range(N):
+                m.emulate(2, r, N)
+                sha, st = step()
+                assert sha == ref, (env, N, r)
+                assert st.batches_sharded > 3 and st.exchange_bytes > 0 and st.candidates_refined == st0.candidates_refined
+                out.append(st)
+        import ctypes as C
+        from pais_mvs_amd import _lib
+        ks = _lib.KernelStats()
+        m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
+        m.emulate(0)
+        m.close()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        return out, ks
+
+    sts, _ = run({"PAIS_STREAM_ROUNDS": "0"}, (2, 3))
+    assert all(s.rounds_streamed == 0 for s in sts)
+    sts, _ = run({"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_SPLIT": "0.4"}, (2, 3))
+    assert all(s.rounds_streamed > 0 for s in sts)
+    sts, ks = run({"PAIS_STREAM_ROUNDS": "0", "PAIS_SPLIT_ABOVE": "1", "PAIS_RING_PER_CAM": "0", "PAIS_RING_TIMEOUT_MS": "0"}, (2,))
+    assert ks.ring_fallbacks > 0, ks.ring_fallbacks
