@@ -920,7 +920,11 @@ void po_pso_run(int dim, const double *rangeL_, const double *rangeU_,
         }                                                                  \
     }                                                                      \
     gSig = (gSig ^ (uint64_t)(gIdx + 1)) * 1099511628211ULL; /* which particle owns gBest, iteration by iteration */
+    /* (diagnosis only, not part of the reference) gSig folds EVERY discrete decision of the run: the owner of gBest after each
+     * updateGbest, which particles improved their pBest in each updateFitness (:128), every particle's lBest and per-dimension
+     * nBest selection in moveParticles (:151-218), the iteration count.  Two runs with equal signatures differ by rounding only. */
     uint64_t gSig = 1469598103934665603ULL;
+    unsigned char improved[PO_PSO_MAXN];
     UPDATE_GBEST();
 
     int iteration;
@@ -968,14 +972,17 @@ void po_pso_run(int dim, const double *rangeL_, const double *rangeU_,
                 }
                 double minFitness = DBL_MAX;
                 const double *lBest = pp;
+                int lSel = i;
                 for (int k = 0; k < localK; k++) {
                     const po_particle *q = &P[cont[k].idx];
                     if (q->pBestFitness < minFitness) {
                         minFitness = q->pBestFitness;
                         lBest = q->pBest;
+                        lSel = cont[k].idx;
                     }
                 }
                 p->lBest = lBest;
+                gSig = (gSig ^ (uint64_t)(lSel + 1)) * 1099511628211ULL;
             }
             /* setNearNeighborBest(i) :193-218 */
             {
@@ -984,14 +991,17 @@ void po_pso_run(int dim, const double *rangeL_, const double *rangeU_,
                 double *nBest = P[i].nBest;
                 for (int d = 0; d < dim; d++) {
                     double maxFDR = -DBL_MAX;
+                    int nSel = -1;
                     for (int k = 0; k < particleNum; k++) {
                         if (k == i) continue;
                         double FDR = (fitness - P[k].pBestFitness) / fabs(ppos[d] - P[k].pBest[d]);
                         if (FDR > maxFDR) {
                             maxFDR = FDR;
                             nBest[d] = P[k].pBest[d];
+                            nSel = k;
                         }
                     }
+                    gSig = (gSig ^ (uint64_t)(nSel + 2)) * 1099511628211ULL;
                 }
             }
             for (int d = 0; d < dim; d++) {
@@ -1011,12 +1021,15 @@ void po_pso_run(int dim, const double *rangeL_, const double *rangeU_,
         for (int i = 0; i < particleNum; i++) {
             po_particle *p = &P[i];
             p->fitness = fn(p->pos, obj);
+            improved[i] = 0;
             if (p->fitness < p->pBestFitness) {
                 p->pBestFitness = p->fitness;
                 for (int d = 0; d < dim; d++) p->pBest[d] = p->pos[d];
+                improved[i] = 1;
             }
         }
         evals += particleNum;
+        for (int i = 0; i < particleNum; i++) gSig = (gSig ^ (uint64_t)(improved[i] + 1)) * 1099511628211ULL;
         UPDATE_GBEST();
 
         iw = (iw - 1.0 / maxIteration) > minIw ? (iw - 1.0 / maxIteration) : minIw; /* :304 */
