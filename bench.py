@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--emulate-ranks", default="ends", choices=["ends", "all"], help="which ranks of each emulated world are run: "
                     "the first and the last (default) or every one; T(N) = the slowest")
     ap.add_argument("--emulate-steps", type=int, default=2)
+    ap.add_argument("--no-emulate", action="store_true", help="the default pawn line emulates ranks of worlds of 2 / 4 / 8 on this GPU "
+                    "(a few hundred ms); this switches that off")
     return ap.parse_args()
 
 
@@ -71,7 +73,7 @@ def build_scene(args, device):
     return cfg, scene, name
 
 
-def cpu_baseline(cfg, scene, budget_s: float, n_seed_units: int, n_expand_units: int):
+def cpu_baseline(cfg, scene, budget_s: float, n_seed_units=None, n_expand_units=None):
     """Oracle (CPU restatement, reference OpenMP structure: particles in parallel, patches sequential) timed on
     a bounded sample of the same workload: some seeds, then first-ring expansion candidates of those seeds.
     Seeds (2x particles, 2x iterations, several PSO runs) cost far more than expansion candidates and are 1-2 % of
@@ -151,6 +153,17 @@ def cpu_baseline(cfg, scene, budget_s: float, n_seed_units: int, n_expand_units:
                                         (C.c_int * (MAXV * m_par))(*ci[:MAXV * m_par]), (C.c_uint64 * m_par)(*ks[:m_par]))
         pp_value = m_par / (time.perf_counter() - t2)
     L.po_mvs_destroy(mo)
+    sample = dict(t_seed=t_seed, t_exp=t_exp, n_seed=n_seed, n_exp=n_exp, nthr=nthr, ncores=ncores, pp_value=pp_value, m_par=m_par,
+                  cpu_s=time.perf_counter() - t0)
+    if n_seed_units is None:
+        return sample          # (the leg runs BEFORE the GPU legs; the workload's mix of units is known after them)
+    return cpu_baseline_finish(sample, n_seed_units, n_expand_units)
+
+
+def cpu_baseline_finish(sample, n_seed_units: int, n_expand_units: int):
+    t_seed, t_exp, n_seed, n_exp, nthr, ncores = (sample[k] for k in ("t_seed", "t_exp", "n_seed", "n_exp", "nthr", "ncores"))
+    pp_value, m_par = sample["pp_value"], sample["m_par"]
+    t0 = time.perf_counter() - sample["cpu_s"]
     total_s = n_seed_units * t_seed + n_expand_units * t_exp
     return {"value": (n_seed_units + n_expand_units) / total_s if total_s > 0 else 0.0, "unit": "patches/s", "cores": nthr,
             "kind": "port, extrapolated from sample",
@@ -265,6 +278,12 @@ def main():
     torch.cuda.set_device(local)
 
     cfg, scene, wname = build_scene(args, local)
+    if not args.emulate_world and not args.no_emulate and args.scene == "pawn" and not args.max_rounds and args.gpus == 1 and not force_dist:
+        args.emulate_world = "2,4,8"
+    # the CPU leg first (rank 0, one GPU, the scene that carries host data for the oracle): the GPU legs then run back to back
+    cpu_sample = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.scene == "pawn":
+        cpu_sample = cpu_baseline(cfg, scene, args.cpu_seconds)
     m = MVS(cfg, scene.cameras, device=local, seed=42)
     if world > 1 or force_dist:
         D.attach(m, job, transport=os.environ.get("PAIS_DIST_TRANSPORT", "rccl"))
@@ -382,6 +401,7 @@ def main():
         # THIS workload (profiles/pmc_traffic_by_scene.json, written by scripts/make_profiles.sh); a figure taken on another
         # scene or workload is never printed
         traffic, traffic_all = None, None
+        pj = None
         tnote = "no PMC pass of this scene / workload under profiles/"
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_by_scene.json"))).get(args.scene)
@@ -389,13 +409,53 @@ def main():
                 traffic = pj.get("eval2_hbm_read_bytes_per_launch")
                 traffic_all = pj.get("eval_hbm_read_bytes_per_launch")
                 tnote = pj.get("note", "")
+            else:
+                pj = None
         except Exception:
-            pass
+            pj = None
         # the dominant kernel ALONE: k_pso_eval2 (the throughput-bound launches of the large batches); the k_pso_iter launches
         # of small batches are latency bound and reported next to it, never mixed into `achieved`
-        e2_ms, e2_n = ks.eval2_ms, max(int(ks.eval2_launches), 1)
-        e2_gbs = (ks.eval2_algorithmic_bytes / 1e9) / (e2_ms / 1e3) if e2_ms > 0 else 0.0
+        # Three kernels can carry the large batches; `roofline` describes ONE of them, alone:
+        #   k_pso_ring  whole PSO passes as one launch          -> ring_* figures of pais_kernel_stats
+        #   k_pso_tile  (+ its pending-only k_pso_eval2 launch) -> the eval2_* aggregate of a many-camera scene
+        #   k_pso_eval2 per-iteration launches (parts of streamed rounds, PAIS_PSO_RING=0) -> eval2_* minus ring_*
+        ring_n = int(ks.ring_launches)
+        if ks.tile_launches * 2 > max(int(ks.eval2_launches), 1):
+            dom = "tile"
+        elif ring_n > 0 and ks.ring_ms * 2 >= ks.eval2_ms:
+            dom = "ring"
+        else:
+            dom = "eval2"
+        if dom == "ring":
+            e2_ms, e2_n, e2_bytes, e2_evals = ks.ring_ms, max(ring_n, 1), ks.ring_algorithmic_bytes, int(ks.ring_evals)
+            o_ms, o_n, o_bytes, o_evals = ks.eval2_ms - ks.ring_ms, int(ks.eval2_launches) - ring_n, ks.eval2_algorithmic_bytes - ks.ring_algorithmic_bytes, int(ks.eval2_evals - ks.ring_evals)
+            traffic = pj.get("ring_hbm_read_bytes_per_launch") if pj else None
+        elif dom == "eval2":
+            e2_ms, e2_n = ks.eval2_ms - ks.ring_ms, max(int(ks.eval2_launches) - ring_n, 1)
+            e2_bytes, e2_evals = ks.eval2_algorithmic_bytes - ks.ring_algorithmic_bytes, int(ks.eval2_evals - ks.ring_evals)
+            o_ms, o_n, o_bytes, o_evals = ks.ring_ms, ring_n, ks.ring_algorithmic_bytes, int(ks.ring_evals)
+            traffic = pj.get("eval2_only_hbm_read_bytes_per_launch") if pj else None
+        else:
+            e2_ms, e2_n, e2_bytes, e2_evals = ks.eval2_ms, max(int(ks.eval2_launches), 1), ks.eval2_algorithmic_bytes, int(ks.eval2_evals)
+            o_ms, o_n, o_bytes, o_evals = 0.0, 0, 0.0, 0
+        e2_gbs = (e2_bytes / 1e9) / (e2_ms / 1e3) if e2_ms > 0 else 0.0
         evals_per_s = evals_eff / dt if dt > 0 else 0.0
+        literal_gate = None
+        try:   # north_star's gate against the reference's LITERAL arithmetic, as measured on this workload (tests/golden/, made by
+               # tests/test_gpu_parity.py::test_literal_gate_on_expansion_candidates_of_the_bench_workload): printed, not re-measured
+            lg = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_gate_bench_workload.json")))
+            if args.scene == "pawn":
+                literal_gate = {"candidates": lg["candidates"], "on_the_literal_trajectory": lg["candidates"] - lg["branched"],
+                                "branched": lg["branched"], "branched_fraction": lg["branched_fraction"],
+                                "centre_rel_l2_max_on_trajectory": lg["same_trajectory_centre_max"],
+                                "normal_rel_l2_max_on_trajectory": lg["same_trajectory_normal_max"],
+                                "discrete_mismatches_on_trajectory": lg["set_mismatch_on_the_same_trajectory"],
+                                "discrete_mismatches_among_branched": lg["set_mismatch_among_branched"],
+                                "note": "HIP records vs the oracle in the reference's literal arithmetic, expansion candidates of rounds 5..25 of "
+                                        "this workload; 'branched' = some fitness comparison of the chaotic, unconverged PSO decided the other way "
+                                        "by a last-bit cost difference (DESIGN.md 5.3)"}
+        except Exception:
+            pass
         mb = None
         try:   # saturated rate of the same evaluation code (scripts/microbench_eval.py under profiles/)
             mb = json.load(open(os.path.join(ROOT, "profiles", "microbench_eval.json")))["evals_per_s"]
@@ -426,28 +486,36 @@ def main():
                        "batches_replicated_per_step": int(last.batches_replicated) if last else 0,
                        "exchange_ms_per_step": float(last.exchange_ms) if last else 0.0,
                        "exchange_bytes_per_step": int(last.exchange_bytes) if last else 0,
+                       "stream_rounds_mode": os.environ.get("PAIS_STREAM_ROUNDS", "1 (adaptive: a round is streamed when the previous round's host "
+                                                                                       "work was >= 0.9 ms and >= 4 % of its GPU time)"),
+                       "literal_gate": literal_gate,
                        "predicted_speedup_at": scaling_model,
                        "emulated_speedup_at": emulated,
                        "parallelism": "1 process per GPU, candidates of a round sharded over %d GPU(s), one ncclAllGather of the "
                                       "records per sharded round (thin rounds replicated)" % world},
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_pso_tile (PAIS::getFitness, one workgroup per candidate x 8 particles, camera footprints staged in LDS; "
-                                    "%d of the %d evaluation launches of the large batches, the rest k_pso_eval2)" % (int(ks.tile_launches), e2_n))
-                         if ks.tile_launches * 2 > e2_n else
-                         ("k_pso_ring (PAIS::getFitness + PsoSolver::run of a large batch as ONE launch: resident waves pop (candidate, particle) "
-                          "evaluation tasks from per-XCD rings; %d of the %d evaluation launches of the large batches)" % (int(ks.ring_launches), e2_n))
-                         if ks.ring_launches * 2 > e2_n else
-                         "k_pso_eval2 (PAIS::getFitness, one wave per candidate x particle; the launches of the large batches)",
+                         "kernel": {"tile": "k_pso_tile (PAIS::getFitness, one workgroup per candidate x 8 particles, camera footprints staged in LDS; "
+                                            "%d of the %d evaluation launches of the large batches, the rest its pending-only k_pso_eval2 launches)"
+                                            % (int(ks.tile_launches), e2_n),
+                                    "ring": "k_pso_ring ALONE (PAIS::getFitness + PsoSolver::run of a large batch as ONE launch: resident waves pop "
+                                            "(candidate, particle) evaluation tasks from per-XCD rings); the other large-batch launches of the step are "
+                                            "under other_large_batch_launches",
+                                    "eval2": "k_pso_eval2 ALONE (PAIS::getFitness, one wave per candidate x particle, one launch per PSO iteration)"}[dom],
                          "achieved": e2_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": e2_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": e2_n, "avg_launch_ms": e2_ms / e2_n,
-                         # the launches overlap on two sub-streams (each is stretched by its neighbour): the same bytes over
-                         # the time during which at least one of them was running (union of their HIP-event intervals)
+                         "algorithmic_bytes_per_launch": e2_bytes / e2_n,
+                         "evals": e2_evals,
+                         "algorithmic_bytes_per_eval": (e2_bytes / e2_evals) if e2_evals else 0,
+                         # the large-batch evaluation launches of the step that are NOT the kernel above (per-iteration k_pso_eval2
+                         # launches of a streamed round next to the ring launches, or the reverse)
+                         "other_large_batch_launches": {"launches": o_n, "ms": o_ms, "evals": o_evals,
+                                                        "achieved": ((o_bytes / 1e9) / (o_ms / 1e3)) if o_ms > 0 else None},
+                         # all large-batch launches together: they overlap on sub-streams / lanes (each is stretched by its neighbour):
+                         # their bytes over the time during which at least one of them was running (union of their HIP-event intervals)
                          "busy_ms": ks.eval2_busy_ms,
                          "achieved_over_busy_time": ((ks.eval2_algorithmic_bytes / 1e9) / (ks.eval2_busy_ms / 1e3)) if ks.eval2_busy_ms > 0 else None,
                          "frac_over_busy_time": ((ks.eval2_algorithmic_bytes / 1e9) / (ks.eval2_busy_ms / 1e3) / HBM_PEAK_GBS) if ks.eval2_busy_ms > 0 else None,
-                         "algorithmic_bytes_per_launch": ks.eval2_algorithmic_bytes / e2_n,
-                         "evals": int(ks.eval2_evals),
-                         "algorithmic_bytes_per_eval": (ks.eval2_algorithmic_bytes / ks.eval2_evals) if ks.eval2_evals else 0,
+                         "ring_fallbacks": int(ks.ring_fallbacks),
                          # every cost-evaluation launch of the step (k_pso_eval2 + the latency-bound k_pso_iter launches of
                          # seeds and thin rounds): the figure rounds 1 and 2 printed as `frac`
                          "all_evaluation_launches": {"achieved": pso_gbs, "frac": pso_gbs / HBM_PEAK_GBS, "launches": k_launches,
@@ -466,8 +534,8 @@ def main():
                                    "host_enumerate": last.host_enumerate_ms if last else 0,
                                    "host_commit": last.host_commit_ms if last else 0},
         }
-        if world == 1 and not args.no_cpu_baseline and args.scene == "pawn":   # the extra scenes carry no host edge maps for the oracle
-            out["cpu_baseline"] = cpu_baseline(cfg, scene, args.cpu_seconds, int(last.seeds_refined), int(last.candidates_effective))
+        if cpu_sample is not None:   # (the extra scenes carry no host edge maps for the oracle)
+            out["cpu_baseline"] = cpu_baseline_finish(cpu_sample, int(last.seeds_refined), int(last.candidates_effective))
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     m.close()
     job.close()

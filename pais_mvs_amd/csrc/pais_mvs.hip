@@ -38,6 +38,7 @@
 #include "../../include/pais_seed.h"
 #include "pais_dev.hpp"
 
+#define PAIS_MAX_STREAM_PARTS 8 // parts of a streamed round on the sharded path (each on a lane of its own)
 namespace {
 
 inline int cv_round_h(double v) { return (int)lrint(v); }            // cvRound
@@ -264,7 +265,7 @@ struct pais_mvs {
         unsigned char *h_wireAll = nullptr;                        // pinned
         size_t wireCap = 0;
         hipEvent_t packed = nullptr, done = nullptr;
-    } sb[2];
+    } sb[PAIS_MAX_STREAM_PARTS];
     struct ShardXfer {
         ShardBufs *B = nullptr;
         pais_ctx *lane = nullptr;
@@ -273,7 +274,7 @@ struct pais_mvs {
         size_t WB = 0, slot = 0;
         double t0 = 0;
         bool sharded = false, open = false;                        // sharded: device path + exchange; else replicated on `lane` (host batch)
-    } sx[2];
+    } sx[PAIS_MAX_STREAM_PARTS];
     int *d_hs = nullptr, *d_hsAll = nullptr, *h_hs = nullptr;      // growth handshake of the sharded path (4 bytes per rank)
     // one-GPU emulation of a rank of a larger world (pais_mvs_emulate): the sharded code path with the other ranks' blocks
     // replayed from the records of a single-rank run of the same workload
@@ -338,6 +339,15 @@ struct pais_mvs {
     int streamHead = 4, streamStep = 2; // PAIS_STREAM_HEAD / _STEP: PSO iterations of a part enqueued when it is opened / per turn after that
     const std::function<int(const pais_candidate *, int)> *onFirstPart = nullptr; // set by the streamed driver for one round_begin
     int firstPart = -1;                // candidates of the first part of the current round (-1: the round is one batch)
+    // the sharded path streams a round in up to streamParts parts (round 4): with N GPUs the GPU's share of a round shrinks N-fold
+    // and the replicated host work does not, so more of it has to run under the GPU's -- part p is on the GPU while the host lists
+    // part p + 1, and is committed while the later parts are still being refined; what stays exposed is the listing of the first
+    // part and the commit of the last
+    int streamParts = 4;               // PAIS_STREAM_PARTS
+    double streamFirst = 0.0;          // PAIS_STREAM_FIRST: share of the round's parents in the first part (0: an equal share)
+    const std::function<int(int, const pais_candidate *, int)> *onPart = nullptr; // (part index, its candidates, their number)
+    std::vector<int> partEnd;          // candidates listed when part p was handed out (parts 0 .. size-1; the last part is the rest)
+    std::vector<pais_ctx *> partLanes; // lanes of parts 1 .. (owned by ctx)
     std::string err;
 
     ~pais_mvs()
@@ -756,6 +766,8 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
     if (const char *e = getenv("PAIS_STREAM_HOST_SHARE")) m->streamHostShare = atof(e);
     if (const char *e = getenv("PAIS_STREAM_HEAD")) m->streamHead = std::max(1, atoi(e));
     if (const char *e = getenv("PAIS_STREAM_SHARDED")) m->streamSharded = atoi(e) != 0;
+    if (const char *e = getenv("PAIS_STREAM_FIRST")) m->streamFirst = std::max(0.0, std::min(0.9, atof(e)));
+    if (const char *e = getenv("PAIS_STREAM_PARTS")) m->streamParts = std::max(2, std::min(atoi(e), PAIS_MAX_STREAM_PARTS));
     if (const char *e = getenv("PAIS_STREAM_STEP")) m->streamStep = std::max(1, atoi(e));
     if (const char *e = getenv("PAIS_STREAM_SPLIT")) { const double v = atof(e); if (v > 0 && v < 1) m->streamSplit = v; }
     memset(&m->st, 0, sizeof(m->st));
@@ -1624,12 +1636,30 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
     for (size_t k = 0; m->deepPrefetch && k < 2 && k < nAct; ++k) prefetchEntries(k, true);
     size_t actIdx = 0;
     m->firstPart = -1;
+    m->partEnd.clear();
     const size_t splitAt = (m->onFirstPart && nAct >= m->streamAbove && !thin) ? (size_t)((double)nAct * m->streamSplit) : (size_t)-1;
+    // (sharded path: streamParts parts of equal numbers of parents)
+    const int nParts = (m->onPart && nAct >= m->streamAbove && !thin) ? std::max(2, std::min(m->streamParts, PAIS_MAX_STREAM_PARTS)) : 1;
+    // split points: the first part holds streamFirst of the parents (its listing is the part of the round's host work that no
+    // GPU work can cover, so it is the smallest), the others share the rest equally
+    auto splitPoint = [&](int k) -> size_t { // parents listed before part k begins, k = 1 .. nParts - 1
+        const double f = m->streamFirst > 0 ? m->streamFirst : 1.0 / nParts;
+        const double at = f + (1.0 - f) * (double)(k - 1) / (double)(nParts - 1);
+        return std::max((size_t)1, std::min(nAct - 1, (size_t)((double)nAct * at)));
+    };
+    size_t nextSplit = nParts > 1 ? splitPoint(1) : (size_t)-1;
     for (Active &a : m->active) {
         if (actIdx == splitAt) {
             // streamed round: what has been listed so far goes to the GPU now (the callback copies the candidates)
             m->firstPart = (int)m->candRecs.size();
             if (m->firstPart > 0 && (*m->onFirstPart)(m->candRecs.data(), m->firstPart)) return -2;
+        }
+        if (actIdx == nextSplit && actIdx > 0) {
+            const int done = m->partEnd.empty() ? 0 : m->partEnd.back(), now = (int)m->candRecs.size();
+            const int part = (int)m->partEnd.size();
+            m->partEnd.push_back(now);
+            if (now > done && (*m->onPart)(part, m->candRecs.data() + done, now - done)) return -2;
+            nextSplit = part + 2 >= nParts ? (size_t)-1 : std::max(actIdx + 1, splitPoint(part + 2)); // (the last part is handed out by the caller)
         }
         prefetchRecord(actIdx + 16);
         prefetchCells(actIdx + 8);
@@ -1959,53 +1989,84 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         };
         const std::function<int(const pais_candidate *, int)> firstPart = [&](const pais_candidate *cc, int n0) {
             tFirst = now_ms();
-            if (shardStream) {
-                beginRc = part_submit(0, m->ctx, n0, cc, (int)((double)n0 / m->streamSplit));
-            } else {
-                (void)pais_ctx_set_round_hint(m->ctx, (int)((double)n0 / m->streamSplit)); // the round's size, as far as it is known
-                beginRc = pais_refine_batch_open(m->ctx, n0, cc, m->streamHead); // the head of its launch chain; the rest below
-                if (beginRc) g_mvs_err = pais_last_error();
-            }
+            (void)pais_ctx_set_round_hint(m->ctx, (int)((double)n0 / m->streamSplit)); // the round's size, as far as it is known
+            beginRc = pais_refine_batch_open(m->ctx, n0, cc, m->streamHead); // the head of its launch chain; the rest below
+            if (beginRc) g_mvs_err = pais_last_error();
             enqueueMs = now_ms() - tFirst;
             return beginRc;
         };
-        m->onFirstPart = canStream ? &firstPart : nullptr;
+        // sharded path: part p of the round on lane p (lane 0 = the driver's own context)
+        auto part_lane = [&](int p) -> pais_ctx * {
+            if (p == 0) return m->ctx;
+            while ((int)m->partLanes.size() < p) {
+                pais_ctx *l = nullptr;
+                if (pais_ctx_fork_lane(m->ctx, &l)) { g_mvs_err = pais_last_error(); return nullptr; }
+                m->partLanes.push_back(l);
+            }
+            return m->partLanes[p - 1];
+        };
+        int partsOut = 0; // parts handed out so far
+        const std::function<int(int, const pais_candidate *, int)> onPart = [&](int part, const pais_candidate *cc, int np) {
+            const double t = now_ms();
+            if (partsOut == 0) tFirst = t;
+            pais_ctx *lane = part_lane(part);
+            // (the round's size as far as it is known: parts of equal numbers of parents)
+            beginRc = lane ? part_submit(part, lane, np, cc, np * std::max(2, std::min(m->streamParts, PAIS_MAX_STREAM_PARTS))) : -2;
+            partsOut = part + 1;
+            enqueueMs += now_ms() - t;
+            return beginRc;
+        };
+        m->onFirstPart = (canStream && !shardStream) ? &firstPart : nullptr;
+        m->onPart = (canStream && shardStream) ? &onPart : nullptr;
         rc = pais_mvs_round_begin(m, B, &c, &n);
         m->onFirstPart = nullptr;
+        m->onPart = nullptr;
         m->lastEnumerateMs -= enqueueMs;
         m->st.host_enumerate_ms -= enqueueMs;
+        // (every part in flight is waited for, in order; records of parts that cannot be used any more are dropped)
+        auto drain_parts = [&](int from, int to) {
+            const pais_patch_result *dummy;
+            m->results.resize((size_t)std::max(std::max(n, 1), (int)m->candRecs.size()));
+            for (int p = from; p < to; ++p) (void)part_finish(p, m->results.data(), &dummy);
+        };
         if (rc < 0) {
             const pais_patch_result *dummy;
-            if (m->firstPart > 0 && !beginRc) { // nothing stays open behind an error
-                if (shardStream) { m->results.resize((size_t)std::max(m->firstPart, 1)); (void)part_finish(0, m->results.data(), &dummy); }
-                else (void)pais_refine_batch_end(m->ctx, &dummy);
-            }
+            if (shardStream) drain_parts(0, partsOut);
+            else if (m->firstPart > 0 && !beginRc) (void)pais_refine_batch_end(m->ctx, &dummy); // nothing stays open behind an error
             m->firstPart = -1;
             return beginRc ? beginRc : rc;
         }
-        if (rc == 1) break;
-        if (m->firstPart >= 0 && shardStream) {
-            const int n0 = m->firstPart, n1 = n - n0;
+        if (rc == 1) { if (shardStream) drain_parts(0, partsOut); break; }
+        if (shardStream && !m->partEnd.empty()) {
+            // streamed round on the sharded path: parts 0 .. P-2 are on the GPU already, the rest of the list is the last part
             const double enumMs = m->lastEnumerateMs;
             int kmax = 1;
             for (int i = 0; i < n; ++i) kmax = std::max(kmax, c[i].num_cam);
             m->results.resize((size_t)std::max(n, 1));
-            const pais_patch_result *v0 = nullptr, *v1 = nullptr;
-            if (n1 > 0) {
-                if (!m->lane1 && pais_ctx_fork_lane(m->ctx, &m->lane1)) { g_mvs_err = pais_last_error(); (void)part_finish(0, m->results.data(), &v0); return -2; }
-                if (n0 == 0) tFirst = now_ms();
-                if (part_submit(1, m->lane1, n1, c + n0, n)) { (void)part_finish(0, m->results.data(), &v0); return -2; }
+            std::vector<int> ends(m->partEnd);
+            ends.push_back(n);
+            const int P = (int)ends.size();
+            for (int p = 0; p < P; ++p) m->sx[p].c = c + (p ? ends[p - 1] : 0); // (the candidate list may have moved since the part was handed out)
+            {
+                const int lo = ends[P - 2], np = n - lo;
+                if (np > 0) {
+                    if (partsOut == 0) tFirst = now_ms();
+                    pais_ctx *lane = part_lane(P - 1);
+                    if (!lane || part_submit(P - 1, lane, np, c + lo, n)) { drain_parts(0, partsOut); return -2; }
+                    partsOut = P;
+                }
             }
             double commitMs = 0;
-            if (n0 > 0) {
-                if (part_finish(0, m->results.data(), &v0)) { (void)part_finish(1, m->results.data() + n0, &v1); return -2; }
+            for (int p = 0; p < P; ++p) {
+                const int lo = p ? ends[p - 1] : 0, np = ends[p] - lo;
+                if (np <= 0) continue;
+                const pais_patch_result *v = nullptr;
+                if (part_finish(p, m->results.data() + lo, &v)) { drain_parts(p + 1, P); return -2; }
                 const double t1 = now_ms();
-                commit_records(m, v0, 0, n0);
+                commit_records(m, v, lo, ends[p]);
                 commitMs += now_ms() - t1;
             }
-            if (n1 > 0 && part_finish(1, m->results.data() + n0, &v1)) return -2;
             const double t2 = now_ms();
-            if (n1 > 0) commit_records(m, v1, n0, n);
             rc = commit_finish(m, n);
             commitMs += now_ms() - t2;
             m->st.host_commit_ms += commitMs;

@@ -44,9 +44,13 @@ if f:
             return (tot*1024.0/nl if nl else None), nl
         raw_all,nl_all=per_launch(lambda k: k.startswith("k_pso_iter") or k.startswith("k_pso_eval") or k.startswith("k_pso_ring"))
         raw_e2,nl_e2=per_launch(lambda k: k.startswith("k_pso_eval") or k.startswith("k_pso_tile") or k.startswith("k_pso_ring"))
+        raw_ring,nl_ring=per_launch(lambda k: k.startswith("k_pso_ring"))
+        raw_eo,nl_eo=per_launch(lambda k: k.startswith("k_pso_eval"))
         if nl_all:
             json.dump({"$SCENE": {"seeds": $SEEDS, "parents_per_round": $PPR, "max_rounds": $MAXR,
                        "eval2_hbm_read_bytes_per_launch": (2.0*raw_e2 if raw_e2 else None), "eval2_launches": nl_e2,
+                       "ring_hbm_read_bytes_per_launch": (2.0*raw_ring if raw_ring else None), "ring_launches": nl_ring,
+                       "eval2_only_hbm_read_bytes_per_launch": (2.0*raw_eo if raw_eo else None), "eval2_only_launches": nl_eo,
                        "eval_hbm_read_bytes_per_launch": 2.0*raw_all, "launches": nl_all, "tag": "$tag",
                        "note": "rocprofv3 --pmc FETCH_SIZE (KiB) summed over the dispatches of the kernel in 'bench.py --steps 1 --warmup 0 $*' / its launches, x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B; calibrated for wide coalesced reads only, so an upper bound for these 2- / 8-byte gathers)"}},
                       open("gpurun_out/${tag}_pmc_traffic.json","w"), indent=1)

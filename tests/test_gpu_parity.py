@@ -1309,7 +1309,9 @@ def test_emulated_ranks_of_a_larger_world_rebuild_the_single_rank_cloud(pawn_sma
 
     sts, _ = run({"PAIS_STREAM_ROUNDS": "0"}, (2, 3))
     assert all(s.rounds_streamed == 0 for s in sts)
-    sts, _ = run({"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_SPLIT": "0.4"}, (2, 3))
+    sts, _ = run({"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_PARTS": "2"}, (2, 3))
+    assert all(s.rounds_streamed > 0 for s in sts)
+    sts, _ = run({"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_PARTS": "4"}, (2, 3))   # four parts, four lanes
     assert all(s.rounds_streamed > 0 for s in sts)
     sts, ks = run({"PAIS_STREAM_ROUNDS": "0", "PAIS_SPLIT_ABOVE": "1", "PAIS_RING_PER_CAM": "0", "PAIS_RING_TIMEOUT_MS": "0"}, (2,))
     assert ks.ring_fallbacks > 0, ks.ring_fallbacks
