@@ -113,6 +113,8 @@ struct pais_ctx {
     int psoStreams = 2;
     int tileStrip2 = 14, tileStrip1 = 24; // 64-pixel steps per strip of the two instantiations (PAIS_TILE_STRIP2 / PAIS_TILE_STRIP1)
     int tileForceNs1 = 0;               // PAIS_TILE_FORCE_NS1 (tests): the one-pixel instantiation also for batches of <= 32 cameras
+    unsigned char *d_tileH = nullptr;   // homography scratch of the tile kernel (pais_tile.hpp PAIS_TILE_SCALAR_H): 16 regions of tileHSlice bytes
+    size_t tileHBytes = 0, tileHSlice = 0;
     bool tileVerify = false;            // PAIS_TILE_VERIFY=1: every particle is ALSO walked by k_pso_eval2 and the two values compared (diagnosis)
     bool tileDebug = false;             // PAIS_TILE_DEBUG=1: counters of the tile kernel (printed by pais_get_kernel_stats)
     int tileMode = 1;                   // PAIS_TILE: 0 many-camera batches keep the one-wave-per-evaluation kernels; 1 the tile kernel for
@@ -443,7 +445,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     for (auto ev : ctx->subDone) (void)hipEventDestroy(ev);
     if (ctx->forkEv) (void)hipEventDestroy(ctx->forkEv);
     if (ctx->refEv) (void)hipEventDestroy(ctx->refEv);
-    (void)hipFree(ctx->d_ring); (void)hipFree(ctx->d_ringCtl); (void)hipFree(ctx->d_arrive);
+    (void)hipFree(ctx->d_ring); (void)hipFree(ctx->d_ringCtl); (void)hipFree(ctx->d_arrive); (void)hipFree(ctx->d_tileH);
     if (ctx->h_ringCtl) (void)hipHostFree(ctx->h_ringCtl);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_imgF); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
     (void)hipFree(ctx->d_cands); (void)hipFree(ctx->d_recs); (void)hipFree(ctx->d_hp);
@@ -712,6 +714,11 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
         if (grow(ctx, ctx->d_ring, ctx->ringBytes, ringNeed)) return -2;
         if (grow(ctx, ctx->d_arrive, ctx->arriveBytes, sizeof(int) * (size_t)n)) return -2;
     }
+    if (P.useTile) { // homography scratch of the tile kernel's waves: a region per slice, 1024 workgroups' worth each
+        const size_t slice = sizeof(double) * 10 * (size_t)PAIS_MAX_VIS * 8 * (PAIS_TILE_SCALAR_H ? 1024 : 1); // (unused unless the variant is built)
+        if (grow(ctx, ctx->d_tileH, ctx->tileHBytes, slice * 16)) return -2;
+        ctx->tileHSlice = slice;
+    }
     // k_pso_iter works on the compacted list of candidates that run a PSO in this pass (k_pso_init);
     // its length is n at most in the first pass and exactly the "again" count afterwards
     const int nRun = P.useIter ? (pass == 0 ? n : againCount) : n;
@@ -782,9 +789,11 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
                                              ctx->d_stat, it, 0, q.parts, ctx->d_evalBlocks, ctx->d_win, q.st));
             else if (P.useTile) {
                 // many cameras: footprints staged in LDS (pais_tile.hpp); the particles it flags take the checked walk
+                // (each slice's launches have their own region of the homography scratch: the slices run at the same time)
                 HIPCHK(pais_launch::pso_tile(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
                                              ctx->d_win + P.WB * (size_t)q.lo, ctx->tileStrip2, ctx->tileStrip1, ctx->tileForceNs1,
-                                             ctx->tileDebug ? ctx->d_stat + 8 : nullptr, q.st));
+                                             ctx->tileDebug ? ctx->d_stat + 8 : nullptr,
+                                             (double *)((unsigned char *)ctx->d_tileH + ctx->tileHSlice * (size_t)k), ctx->tileHSlice, q.st));
                 HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
                                              ctx->d_win + P.WB * (size_t)q.lo, ctx->tileVerify ? 2 : 1, ctx->d_stat + 18, q.st));
             } else

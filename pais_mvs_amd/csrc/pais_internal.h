@@ -63,6 +63,11 @@ struct DevScene {
     int pad;
 };
 
+// where the LDS-tile kernel's walk reads a wave's homographies from (pais_tile.hpp): 0 LDS (default), 1 / 2 the scalar cache
+#ifndef PAIS_TILE_SCALAR_H
+#define PAIS_TILE_SCALAR_H 0
+#endif
+
 namespace pais_launch {
 // evaluation block of a PSO run (pais_eval.hpp): EvalPatch + EvalCam[Kmax] bytes per candidate, and the reference window
 size_t eval_block_bytes_host(int Kmax);
@@ -83,7 +88,8 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
                     int pendingOnly, unsigned long long *verify, hipStream_t stream);
 bool tile_eligible(int Kmax);
 hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int strip2, int strip1, int forceNs1, unsigned long long *dbg, hipStream_t stream);
+                    int strip2, int strip1, int forceNs1, unsigned long long *dbg, double *hscr, size_t hscrBytes, hipStream_t stream);
+                    // hscr: per-launch scratch for the waves' homographies (pais_tile.hpp PAIS_TILE_SCALAR_H), hscrBytes of it
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                     int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream);

@@ -1927,7 +1927,7 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
 bool tile_eligible(int Kmax) { return eval_shape(Kmax) == 2 && Kmax <= TILE_MAX_CAMS; }
 template <int NS, int NP>
 static hipError_t pso_tile_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
-                                  const void *win, int stripSteps, unsigned long long *dbg, hipStream_t stream)
+                                  const void *win, int stripSteps, unsigned long long *dbg, double *hscr, size_t hscrBytes, hipStream_t stream)
 {
     static LdsAttr attr;
     const size_t lds = 160 * 1024, fixed = tile_fixed_lds_bytes(Kmax);
@@ -1936,18 +1936,24 @@ static hipError_t pso_tile_launch(const DevScene &sc, unsigned char *states, int
     const int groups = (Nmax + TILE_WAVES - 1) / TILE_WAVES;
     long grid = (long)n * groups;
     if (grid > 65536) grid = 65536;
+    // one slot of the homography scratch per wave of the grid (pais_tile.hpp PAIS_TILE_SCALAR_H); a workgroup takes the whole LDS
+    // of a CU, so a grid of a few workgroups per CU (grid-stride over the tasks) loses nothing
+    const long slots = (long)(hscrBytes / (sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE_WAVES));
+    if (slots < 1) return hipErrorInvalidValue;
+    if (grid > slots) grid = slots;
     hipLaunchKernelGGL((k_pso_tile<NS, NP>), dim3((unsigned)grid), dim3(64 * TILE_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win, getenv("PAIS_TILE_NOTILES") ? 0 : (int)(lds - fixed), groups, stripSteps, dbg);
+                       eval_block_bytes(Kmax), (const WinPix *)win, getenv("PAIS_TILE_NOTILES") ? 0 : (int)(lds - fixed), groups, stripSteps, dbg,
+                       hscr);
     return hipGetLastError();
 }
 hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int strip2, int strip1, int forceNs1, unsigned long long *dbg, hipStream_t stream)
+                    int strip2, int strip1, int forceNs1, unsigned long long *dbg, double *hscr, size_t hscrBytes, hipStream_t stream)
 {
     // two pixels per lane while the colours of 2 x 32 cameras fit the registers; one pixel per lane beyond.  Strip lengths
     // swept on the full-size dome (profiles/r03_dome_tile_sweep.txt): 14 / 24 steps; longer strips = fewer barriers, until the
     // tiles of a strip stop fitting the tile area (cameras then tap global memory)
-    if (Kmax <= 32 && !forceNs1) return pso_tile_launch<2, 16>(sc, states, n, Nmax, Kmax, evalBlocks, win, (strip2 + 1) & ~1, dbg, stream);
-    return pso_tile_launch<1, 32>(sc, states, n, Nmax, Kmax, evalBlocks, win, strip1, dbg, stream);
+    if (Kmax <= 32 && !forceNs1) return pso_tile_launch<2, 16>(sc, states, n, Nmax, Kmax, evalBlocks, win, (strip2 + 1) & ~1, dbg, hscr, hscrBytes, stream);
+    return pso_tile_launch<1, 32>(sc, states, n, Nmax, Kmax, evalBlocks, win, strip1, dbg, hscr, hscrBytes, stream);
 }
 template <int P, int NS, bool BYTES, bool ACCR>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,

@@ -58,9 +58,25 @@ __host__ __device__ inline size_t tile_fixed_lds_bytes(int Kmax)
 
 // one camera group of the lane's two window pixels from the tiles: the statements of tap_group<G, 1, false, true> per
 // pixel, with LDS rows
-template <int G, int NS>
+// PAIS_TILE_SCALAR_H (round 4): where a wave's homographies come from in the walk.
+//   0  LDS (ds_read_b128 x 5 per camera and trip: wave-uniform operands, 1 KB through the LDS data path each);
+//   1  the one-pixel instantiation reads them through the SCALAR cache: every wave also writes its homographies to a slot of
+//      a global scratch, and the walk loads them with s_load (constant address space: SGPR operands of the fma's, no LDS
+//      cycles); only the camera's tile word (8 bytes, rewritten per strip) stays an LDS read.  The LDS pipe, shared by the
+//      CU's four SIMDs, is what the one-pixel walk saturates (one homography read per camera and PIXEL there);
+//   2  both instantiations.
+// MEASURED (round 4, profiles/r04_tile_scalar_h_ab.txt; dome seeds + 10 rounds, one box, alternating; same cloud hash, the
+// verify mode of test_dome_radius25_many_cameras green): 1 is SLOWER -- 2 797 / 2 801 ms against 2 409 / 2 407 ms per
+// reconstruction (-14 %).  The LDS reads do disappear (ISA of the one-pixel kernel: 16 ds_read_b128 left of 180, 66
+// s_load_dwordx16 + 72 s_load_dwordx2 instead), but a wave re-reads its 34-43 homographies (2.7-3.4 KB) once per 64-pixel
+// step, eight waves of a workgroup hold 22-27 KB of them, and the scalar data cache is 16 KB: the loads go to L2 on every step,
+// and the constant-bus limit of gfx9 (one SGPR operand per VALU instruction) costs ~9 v_mov per camera.  Default 0; the
+// variant stays selectable (-DPAIS_TILE_SCALAR_H=1).  (PAIS_TILE_SCALAR_H itself is defined in pais_internal.h: the host
+// only allocates the scratch when it is on.)
+typedef const double __attribute__((address_space(4))) *TileHS;
+template <int G, int NS, bool SH>
 __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam *cams, const unsigned char *tiles,
-                                               const double *Hbuf, int c0, double *x, double *y, double (*col)[NS], double *sum)
+                                               const double *Hbuf, TileHS hs, int c0, double *x, double *y, double (*col)[NS], double *sum)
 {
 #pragma unroll
     for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
@@ -68,8 +84,15 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
     int tbase[G], ttw[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
-        const double2 ha = H2[0], hb = H2[1], hc = H2[2], hd = H2[3], he = H2[4];
+        double2 ha, hb, hc, hd, he;
+        if (SH) {
+            TileHS h = hs + PAIS_H_STRIDE * (c0 + u); // wave-uniform address in the constant address space: s_load
+            ha.x = h[0]; ha.y = h[1]; hb.x = h[2]; hb.y = h[3]; hc.x = h[4]; hc.y = h[5]; hd.x = h[6]; hd.y = h[7]; he.x = h[8];
+            he.y = Hbuf[PAIS_H_STRIDE * (c0 + u) + 9]; // the tile word of this strip: one 8-byte LDS read
+        } else {
+            const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
+            ha = H2[0]; hb = H2[1]; hc = H2[2]; hd = H2[3]; he = H2[4];
+        }
         // (the camera's tile rides in the padding of its homography record: no read of its own)
         tbase[u] = __double2loint(he.y);
         ttw[u] = __builtin_amdgcn_readfirstlane(__double2hiint(he.y));
@@ -150,10 +173,14 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
 template <int NS, int NP>
 __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                                                 const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
-                                                                int tileBytes, int groups, int stripSteps, unsigned long long *dbg)
+                                                                int tileBytes, int groups, int stripSteps, unsigned long long *dbg,
+                                                                double *hscr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool SH = (PAIS_TILE_SCALAR_H == 2) || (PAIS_TILE_SCALAR_H == 1 && NS == 1);
+    // this wave's slot of the homography scratch (SH): Kmax records of PAIS_H_STRIDE doubles
+    double *hslot = hscr + ((size_t)blockIdx.x * TILE_WAVES + (size_t)wave) * (size_t)Kmax * PAIS_H_STRIDE;
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     size_t o = eval_block_bytes(Kmax);
@@ -219,6 +246,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                         mul33(Mc, invH, H);
                     }
                     for (int q = 0; q < 9; ++q) Hbuf[cc * PAIS_H_STRIDE + q] = H[q];
+                    if (SH)
+                        for (int q = 0; q < 9; ++q) hslot[cc * PAIS_H_STRIDE + q] = H[q];
                 }
                 wave_sync();
                 if (!corners_inside(ep, cams, Hbuf, S, lane)) state = 2;
@@ -233,6 +262,20 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
         __syncthreads();
         if (!flags[0]) continue; // nobody walks the tiles (uniform)
 
+        // SH: the homographies this wave has just stored are read back through the scalar cache.  They are at the device's L2
+        // once the stores have been acknowledged (vmcnt); lines of this slot that the scalar cache still holds from the
+        // previous task are dropped (s_dcache_inv); the pointer is re-defined opaquely so that no load through it can be moved
+        // above this point (loads from the constant address space are otherwise free to move over stores)
+        TileHS hs = nullptr;
+        if (SH) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_dcache_inv();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)hslot & 0xffffffffu));
+            unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)hslot >> 32));
+            asm volatile("" : "+s"(lo), "+s"(hi)::"memory");
+            hs = (TileHS)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+        }
         const double a0 = ep->a0, b0 = ep->b0;
         const double invDiffW = 1.0 / sc.cfg.diffWeighting;
         const bool useDiff = sc.cfg.adaptiveDifferenceEnable != 0;
@@ -381,14 +424,14 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                     for (int q = 0; q < NS; ++q) t3[0][q] = t3[1][q] = t3[2][q] = 0;
 #pragma unroll
                     for (int u = 0; u < NP; ++u) {
-                        if (u < nPairs) tile_tap_group<2, NS>(sc, cams, tiles, Hbuf, 2 * u, x, y, &col[2 * u], sum);
+                        if (u < nPairs) tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, &col[2 * u], sum);
                         else {
 #pragma unroll
                             for (int q = 0; q < NS; ++q) col[2 * u][q] = col[2 * u + 1][q] = 0;
                         }
                     }
-                    if (nTail == 3) tile_tap_group<3, NS>(sc, cams, tiles, Hbuf, tail0, x, y, t3, sum);
-                    else if (nTail == 1) tile_tap_group<1, NS>(sc, cams, tiles, Hbuf, tail0, x, y, t3, sum);
+                    if (nTail == 3) tile_tap_group<3, NS, SH>(sc, cams, tiles, Hbuf, hs, tail0, x, y, t3, sum);
+                    else if (nTail == 1) tile_tap_group<1, NS, SH>(sc, cams, tiles, Hbuf, hs, tail0, x, y, t3, sum);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) {
                         if (st + q >= s1) break; // uniform: the strip (the window) has no such step
