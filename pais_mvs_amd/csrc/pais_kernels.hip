@@ -1938,9 +1938,11 @@ static hipError_t pso_tile_launch(const DevScene &sc, unsigned char *states, int
     if (grid > 65536) grid = 65536;
     // one slot of the homography scratch per wave of the grid (pais_tile.hpp PAIS_TILE_SCALAR_H); a workgroup takes the whole LDS
     // of a CU, so a grid of a few workgroups per CU (grid-stride over the tasks) loses nothing
-    const long slots = (long)(hscrBytes / (sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE_WAVES));
-    if (slots < 1) return hipErrorInvalidValue;
-    if (grid > slots) grid = slots;
+    if (PAIS_TILE_SCALAR_H) {
+        const long slots = (long)(hscrBytes / (sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE_WAVES));
+        if (slots < 1) return hipErrorInvalidValue;
+        if (grid > slots) grid = slots;
+    }
     hipLaunchKernelGGL((k_pso_tile<NS, NP>), dim3((unsigned)grid), dim3(64 * TILE_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
                        eval_block_bytes(Kmax), (const WinPix *)win, getenv("PAIS_TILE_NOTILES") ? 0 : (int)(lds - fixed), groups, stripSteps, dbg,
                        hscr);
