@@ -11,9 +11,13 @@ SCENE=${SCENE:-pawn}; SEEDS=${SEEDS:-200}; PPR=${PPR:-4096}; MAXR=${MAXR:-0}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 2 --warmup 1 --cpu-seconds 4 "$@" > $out/bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 2 --warmup 1 --cpu-seconds 4 --no-emulate "$@" > $out/bench.log 2>&1
 grep '^{"metric"' $out/bench.log | tail -1 > gpurun_out/${tag}_bench_under_rocprof.json
 python scripts/rocprof_summary.py $(ls $out/kt/*.db | head -1) gpurun_out/${tag}_kernel_stats.txt gpurun_out/${tag}_bench_under_rocprof.json "python bench.py --steps 2 --warmup 1 ($tag)" > /dev/null
+# per-round table of one reconstruction (warm-up, timed, roofline step: scripts/rounds_table.py reads the middle one)
+timeout 600 rocprofv3 --kernel-trace -d $out/kr -o kr -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-emulate "$@" > $out/rounds.log 2>&1
+python scripts/rounds_table.py $(ls $out/kr/*.db | head -1) > gpurun_out/${tag}_rounds.txt 2>&1
+rm -rf $out/kr
 i=0
 : > gpurun_out/${tag}_pmc.txt
 echo "# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of: python bench.py --steps 1 --warmup 0 --no-cpu-baseline" >> gpurun_out/${tag}_pmc.txt
@@ -24,7 +28,7 @@ for set in \
  "FETCH_SIZE" \
  "WRITE_SIZE" ; do
   i=$((i+1))
-  timeout 900 rocprofv3 --kernel-trace --pmc $set -d $out/p$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/p$i.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $set -d $out/p$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-emulate "$@" > $out/p$i.log 2>&1
   python - >> gpurun_out/${tag}_pmc.txt << PY
 import sqlite3,glob,json
 f=glob.glob("$out/p$i/*.db")
