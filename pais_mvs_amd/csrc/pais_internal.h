@@ -68,6 +68,11 @@ struct DevScene {
 #define PAIS_TILE_SCALAR_H 0
 #endif
 
+// control words of one task ring of k_pso_ring (pais_kernels.hip RingCtl): head | tail, done, total, error
+#define PAIS_RING_CTL_BYTES 128
+#define PAIS_RING_CTL_DONE_WORD 17
+#define PAIS_RING_CTL_ERROR_WORD 19
+
 namespace pais_launch {
 // evaluation block of a PSO run (pais_eval.hpp): EvalPatch + EvalCam[Kmax] bytes per candidate, and the reference window
 size_t eval_block_bytes_host(int Kmax);

@@ -1361,7 +1361,10 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
 static_assert(PAIS_WG_WAVES == 1, "k_pso_ring: the swarm step (pso_step_wave) synchronises with workgroup barriers inside wave-divergent "
                                   "control flow, which is only a wave barrier while a workgroup is ONE wave");
 #define PAIS_RINGS 8 // one ring per XCD (workgroup b runs on XCD b % 8): a ring's counters and its candidates' state stay in one L2
-struct RingCtl { unsigned head, tail, done, total, error, pad[11]; }; // one 64-byte line per ring
+// two 64-byte lines per ring: the head counter (one atomic per task, from every wave) alone on the first; what publishers and
+// idle waves touch (tail, done, error) on the second -- polling waves do not pull the line the poppers serialise on
+struct RingCtl { unsigned head, pad0[15]; unsigned tail, done, total, error, pad1[12]; };
+static_assert(sizeof(RingCtl) == PAIS_RING_CTL_BYTES, "RingCtl layout (pais_internal.h)");
 
 // candidates c with c % PAIS_RINGS == r belong to ring r; its segment of the ring memory starts at r * segWords
 // tasks of iteration 0 (the initial swarm); candidates whose refinement ended in k_begin count as done
