@@ -392,10 +392,10 @@ static int ctx_init_work(pais_ctx *ctx)
     ctx->ringSeedAbove = 0;
     if (const char *e = getenv("PAIS_RING_SEED_ABOVE")) ctx->ringSeedAbove = atol(e);
     if (const char *e = getenv("PAIS_RING_MAX_MB")) { long v = atol(e); if (v > 0) ctx->ringMaxBytes = (size_t)v << 20; }
-    HIPCHK(hipMalloc(&ctx->d_ringCtl, PAIS_RING_CTL_BYTES * 8));
-    HIPCHK(hipMemset(ctx->d_ringCtl, 0, PAIS_RING_CTL_BYTES * 8));
-    HIPCHK(hipHostMalloc((void **)&ctx->h_ringCtl, PAIS_RING_CTL_BYTES * 8, hipHostMallocDefault));
-    memset(ctx->h_ringCtl, 0, PAIS_RING_CTL_BYTES * 8);
+    HIPCHK(hipMalloc(&ctx->d_ringCtl, PAIS_RING_CTL_BYTES * PAIS_RINGS));
+    HIPCHK(hipMemset(ctx->d_ringCtl, 0, PAIS_RING_CTL_BYTES * PAIS_RINGS));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_ringCtl, PAIS_RING_CTL_BYTES * PAIS_RINGS, hipHostMallocDefault));
+    memset(ctx->h_ringCtl, 0, PAIS_RING_CTL_BYTES * PAIS_RINGS);
     if (const char *e = getenv("PAIS_TILE")) ctx->tileMode = atoi(e);
     if (const char *e = getenv("PAIS_TILE_DEBUG")) ctx->tileDebug = atoi(e) != 0;
     if (const char *e = getenv("PAIS_TILE_VERIFY")) ctx->tileVerify = atoi(e) != 0;
@@ -767,7 +767,7 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
             HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
                                          ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 1, ticks, ctx->stream));
             if (te.end()) return -2;
-            HIPCHK(hipMemcpyAsync(ctx->h_ringCtl, ctx->d_ringCtl, PAIS_RING_CTL_BYTES * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(ctx->h_ringCtl, ctx->d_ringCtl, PAIS_RING_CTL_BYTES * PAIS_RINGS, hipMemcpyDeviceToHost, ctx->stream));
             ctx->ringUsed = true;
             ctx->evalLaunches++;
             ctx->eval2Launches++;
@@ -902,7 +902,7 @@ static int ring_failed(pais_ctx *ctx, int n)
     if (!ctx->ringUsed) return 0;
     ctx->ringUsed = false;
     unsigned done = 0, err = 0;
-    for (int r = 0; r < 8; ++r) { done += ctx->h_ringCtl[(PAIS_RING_CTL_BYTES / 4) * r + PAIS_RING_CTL_DONE_WORD]; err |= ctx->h_ringCtl[(PAIS_RING_CTL_BYTES / 4) * r + PAIS_RING_CTL_ERROR_WORD]; }
+    for (int r = 0; r < PAIS_RINGS; ++r) { done += ctx->h_ringCtl[(PAIS_RING_CTL_BYTES / 4) * r + PAIS_RING_CTL_DONE_WORD]; err |= ctx->h_ringCtl[(PAIS_RING_CTL_BYTES / 4) * r + PAIS_RING_CTL_ERROR_WORD]; }
     if (err == 0 && done == (unsigned)n) return 0;
     ctx->ringFallbacks++;
     if (getenv("PAIS_RING_VERBOSE"))

@@ -69,6 +69,9 @@ struct DevScene {
 #endif
 
 // control words of one task ring of k_pso_ring (pais_kernels.hip RingCtl): head | tail, done, total, error
+#ifndef PAIS_RINGS
+#define PAIS_RINGS 8 // (16 and 32 rings -- two / four per XCD -- measured: no gain, profiles/r04_ring_count_ab.txt)
+#endif
 #define PAIS_RING_CTL_BYTES 128
 #define PAIS_RING_CTL_DONE_WORD 17
 #define PAIS_RING_CTL_ERROR_WORD 19

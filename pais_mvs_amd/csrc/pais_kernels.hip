@@ -1360,7 +1360,8 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
 #define PAIS_RING_EMPTY 0xFFFFFFFFu
 static_assert(PAIS_WG_WAVES == 1, "k_pso_ring: the swarm step (pso_step_wave) synchronises with workgroup barriers inside wave-divergent "
                                   "control flow, which is only a wave barrier while a workgroup is ONE wave");
-#define PAIS_RINGS 8 // one ring per XCD (workgroup b runs on XCD b % 8): a ring's counters and its candidates' state stay in one L2
+// PAIS_RINGS (pais_internal.h): a multiple of 8 -- workgroup b runs on XCD b % 8 and works ring b % PAIS_RINGS, so a ring's
+// counters and its candidates' state stay in one XCD's L2
 // two 64-byte lines per ring: the head counter (one atomic per task, from every wave) alone on the first; what publishers and
 // idle waves touch (tail, done, error) on the second -- polling waves do not pull the line the poppers serialise on
 struct RingCtl { unsigned head, pad0[15]; unsigned tail, done, total, error, pad1[12]; };
