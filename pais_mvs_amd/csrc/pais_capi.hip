@@ -712,7 +712,7 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
     P.ringCUs = ctx->numCUs;
     if (P.useRing) {
         if (grow(ctx, ctx->d_ring, ctx->ringBytes, ringNeed)) return -2;
-        if (grow(ctx, ctx->d_arrive, ctx->arriveBytes, sizeof(int) * (size_t)n)) return -2;
+        if (grow(ctx, ctx->d_arrive, ctx->arriveBytes, sizeof(int) * PAIS_ARRIVE_STRIDE * (size_t)n)) return -2;
     }
     if (P.useTile) { // homography scratch of the tile kernel's waves: a region per slice, 1024 workgroups' worth each
         const size_t slice = sizeof(double) * 10 * (size_t)PAIS_MAX_VIS * 8 * (PAIS_TILE_SCALAR_H ? 1024 : 1); // (unused unless the variant is built)

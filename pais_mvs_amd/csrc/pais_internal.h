@@ -72,6 +72,11 @@ struct DevScene {
 #ifndef PAIS_RINGS
 #define PAIS_RINGS 8 // (16 and 32 rings -- two / four per XCD -- measured: no gain, profiles/r04_ring_count_ab.txt)
 #endif
+// a candidate's arrival counter (one atomic per delivered evaluation) on a cache line of its own: neighbouring candidates belong
+// to other rings, i.e. other XCDs
+#ifndef PAIS_ARRIVE_STRIDE
+#define PAIS_ARRIVE_STRIDE 16
+#endif
 #define PAIS_RING_CTL_BYTES 128
 #define PAIS_RING_CTL_DONE_WORD 17
 #define PAIS_RING_CTL_ERROR_WORD 19

@@ -1447,13 +1447,13 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         if (lane == 0) {
             cstore(&A.fit[i], st ? DBL_MAX : combine_parts(f4, w4));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the fitness is at the coherence point before it is counted
-            old = __hip_atomic_fetch_add(&arrive[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __hip_atomic_fetch_add(&arrive[(size_t)c * PAIS_ARRIVE_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         old = __builtin_amdgcn_readfirstlane(old);
         if (old != N - 1) continue;
         // this wave completed the candidate's iteration: its swarm step, then the next iteration's tasks (or the result)
         __builtin_amdgcn_s_setprio(3); // the step sits on the candidate's critical path
-        if (lane == 0) cstore(&arrive[c], 0);
+        if (lane == 0) cstore(&arrive[(size_t)c * PAIS_ARRIVE_STRIDE], 0);
         wave_sync();
         const int cont = pso_step_wave_ring(sc, recs, c, hd, Nmax, smem, stat, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every lane's part of the new swarm (and the counter reset) is out
@@ -2019,7 +2019,7 @@ static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, u
         if (e != hipSuccess) return e;
         e = hipMemsetAsync(ctl, 0, sizeof(RingCtl) * PAIS_RINGS, stream);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(arrive, 0, sizeof(int) * (size_t)n, stream);
+        e = hipMemsetAsync(arrive, 0, sizeof(int) * PAIS_ARRIVE_STRIDE * (size_t)n, stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_ring_init, dim3((n + 255) / 256), dim3(256), 0, stream, states, n, Nmax, ring, (unsigned)seg, (RingCtl *)ctl);
         return hipGetLastError();
