@@ -250,8 +250,10 @@ int  pais_pack_records_device(pais_ctx *ctx, int n, const pais_patch_result *d_r
  * pais_refine_batch_device_async: pais_refine_batch_device that never waits for a pure expansion batch, also when its PSO
  * pass runs as k_pso_ring (whose completion words pais_refine_batch_device reads before it returns).
  * pais_wire_header_device: the 64-byte status header of this rank's block of the exchange, written on the device behind the
- * batch's launches: uint32 {PAIS_WIRE_MAGIC, rc, count, rank, 0 x 12}; rc = host_rc if non-zero, PAIS_WIRE_RC_RING_RETRY if
- * the batch's ring pass did not complete, else 0.
+ * batch's launches: uint32 {PAIS_WIRE_MAGIC, rc, count, rank, user_word, 0 x 11}; rc = host_rc if non-zero,
+ * PAIS_WIRE_RC_RING_RETRY if the batch's ring pass did not complete, else 0; user_word travels as given (the drivers of
+ * include/pais_mvs.h carry rank 0's timing-driven scheduling choice for the next round in it, so that every rank takes the
+ * same one).
  * pais_ctx_batch_status: after the caller synchronised with the stream: 0 = the last _async batch is complete; 1 = its ring
  * pass did not complete: the records are invalid and the caller refines the same batch again (that batch then takes one
  * launch per iteration).  Every rank reads every header, so all ranks agree on a second exchange. */
@@ -260,7 +262,7 @@ int  pais_pack_records_device(pais_ctx *ctx, int n, const pais_patch_result *d_r
 #define PAIS_WIRE_HEADER_BYTES 64
 int  pais_refine_batch_device_async(pais_ctx *ctx, int n, const pais_candidate *d_cands,
                                     pais_patch_result *d_out, int max_num_cam, int has_seeds);
-int  pais_wire_header_device(pais_ctx *ctx, int rank, int count, int host_rc, void *d_header);
+int  pais_wire_header_device(pais_ctx *ctx, int rank, int count, int host_rc, uint32_t user_word, void *d_header);
 int  pais_ctx_batch_status(pais_ctx *ctx);
 
 /* The HIP stream (hipStream_t) all work of this context is enqueued on. */

@@ -999,13 +999,13 @@ extern "C" int pais_ctx_batch_status(pais_ctx *ctx)
 }
 
 // 64-byte header of a rank's block in the exchange of a sharded batch, written ON THE DEVICE behind the batch's launches:
-// {magic 'PAIS', rc, count, rank, 0...}; rc = host_rc if that is non-zero, else PAIS_WIRE_RC_RING_RETRY when the batch's
+// {magic 'PAIS', rc, count, rank, user_word, 0...}; rc = host_rc if that is non-zero, else PAIS_WIRE_RC_RING_RETRY when the batch's
 // k_pso_ring pass did not complete (read from the ring's own words: no host round trip before the exchange), else 0.
-extern "C" int pais_wire_header_device(pais_ctx *ctx, int rank, int count, int host_rc, void *d_header)
+extern "C" int pais_wire_header_device(pais_ctx *ctx, int rank, int count, int host_rc, uint32_t user_word, void *d_header)
 {
     if (!ctx || !d_header) return fail_msg("pais_wire_header_device: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(pais_launch::wire_header(d_header, ctx->ringPendingN > 0 ? ctx->d_ringCtl : nullptr, ctx->ringPendingN, rank, count, host_rc, ctx->stream));
+    HIPCHK(pais_launch::wire_header(d_header, ctx->ringPendingN > 0 ? ctx->d_ringCtl : nullptr, ctx->ringPendingN, rank, count, host_rc, user_word, ctx->stream));
     return 0;
 }
 

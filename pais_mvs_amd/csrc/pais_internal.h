@@ -93,7 +93,7 @@ hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *
 hipError_t expand_image(const uint8_t *img, PaisImgT *out, size_t n, hipStream_t stream);
 hipError_t level_edge_minmax(const uint8_t *img, int w, int h, unsigned long long *minmax, hipStream_t stream);
 hipError_t pack_records(const pais_patch_result *recs, int n, int Kw, void *wire, hipStream_t stream);
-hipError_t wire_header(void *header, const unsigned *ringCtl, int ringN, int rank, int count, int hostRc, hipStream_t stream);
+hipError_t wire_header(void *header, const unsigned *ringCtl, int ringN, int rank, int count, int hostRc, uint32_t userWord, hipStream_t stream);
 size_t pso_state_bytes_host(int Nmax);
 hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
                     int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);

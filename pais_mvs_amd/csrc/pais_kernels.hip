@@ -1668,7 +1668,7 @@ __global__ __launch_bounds__(256) void k_pack_records(const pais_patch_result *r
 // float2 tap copy of the byte blob (pais_internal.h PaisImgT): one thread per pixel, coalesced
 // header of a rank's block in a sharded batch's exchange (include/pais_hip.h pais_wire_header): the ring's own words decide
 // whether the pass completed, so that the status travels with the records without a host round trip before the collective
-__global__ __launch_bounds__(64) void k_wire_header(uint32_t *hdr, const RingCtl *ctl, int ringN, int rank, int count, int hostRc)
+__global__ __launch_bounds__(64) void k_wire_header(uint32_t *hdr, const RingCtl *ctl, int ringN, int rank, int count, int hostRc, uint32_t userWord)
 {
     if (threadIdx.x >= 16) return;
     int rc = hostRc;
@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(64) void k_wire_header(uint32_t *hdr, const RingCtl
         if (err != 0 || done != (unsigned)ringN) rc = PAIS_WIRE_RC_RING_RETRY;
     }
     const uint32_t w[4] = {PAIS_WIRE_MAGIC, (uint32_t)rc, (uint32_t)count, (uint32_t)rank};
-    hdr[threadIdx.x] = threadIdx.x < 4 ? w[threadIdx.x] : 0u;
+    hdr[threadIdx.x] = threadIdx.x < 4 ? w[threadIdx.x] : (threadIdx.x == 4 ? userWord : 0u);
 }
 
 __global__ __launch_bounds__(256) void k_expand_image(const uint8_t *img, PaisImgT *out, size_t n)
@@ -1890,9 +1890,9 @@ hipError_t pack_records(const pais_patch_result *recs, int n, int Kw, void *wire
     return hipGetLastError();
 }
 
-hipError_t wire_header(void *header, const unsigned *ringCtl, int ringN, int rank, int count, int hostRc, hipStream_t stream)
+hipError_t wire_header(void *header, const unsigned *ringCtl, int ringN, int rank, int count, int hostRc, uint32_t userWord, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_wire_header, dim3(1), dim3(64), 0, stream, (uint32_t *)header, (const RingCtl *)ringCtl, ringN, rank, count, hostRc);
+    hipLaunchKernelGGL(k_wire_header, dim3(1), dim3(64), 0, stream, (uint32_t *)header, (const RingCtl *)ringCtl, ringN, rank, count, hostRc, userWord);
     return hipGetLastError();
 }
 

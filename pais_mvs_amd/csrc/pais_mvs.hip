@@ -335,6 +335,11 @@ struct pais_mvs {
     double prevHostMs = 0, prevGpuMs = 0;
     size_t streamAbove = 192;          // PAIS_STREAM_ABOVE: active parents from which a round is streamed
     double streamSplit = 0.5;          // PAIS_STREAM_SPLIT: share of the active parents in the first part
+    // Whether a round is streamed is a TIMING-driven choice (below), and on the sharded path every rank must take the same one
+    // (a streamed round is several collectives, an unstreamed one a single larger one): each rank writes its own wish for the
+    // next round into the status header of its block (streamWish), and rank 0's word, which every rank reads, decides
+    // (streamAgreed) -- no collective of its own.
+    bool streamWish = false, streamAgreed = false;
     bool streamSharded = true;         // PAIS_STREAM_SHARDED=0: rounds of the multi-GPU path are never streamed (round 3's behaviour)
     int streamHead = 4, streamStep = 2; // PAIS_STREAM_HEAD / _STEP: PSO iterations of a part enqueued when it is opened / per turn after that
     const std::function<int(const pais_candidate *, int)> *onFirstPart = nullptr; // set by the streamed driver for one round_begin
@@ -833,6 +838,7 @@ extern "C" int pais_mvs_reset(pais_mvs *m)
     memset(&m->st, 0, sizeof(m->st));
     m->roundLog.clear();
     m->prevHostMs = m->prevGpuMs = 0;
+    m->streamWish = m->streamAgreed = false;
     return 0;
 }
 extern "C" pais_ctx *pais_mvs_ctx(pais_mvs *m) { return m ? m->ctx : nullptr; }
@@ -983,7 +989,7 @@ static int all_gather_host(pais_mvs *m, const void *send, void *recv, size_t byt
 // Split in submit / finish so that two batches -- the parts of a streamed round -- can be in flight: both exchanges are
 // enqueued on the driver's own stream in submission order (one communicator, one stream, one order on every rank); the
 // second part is refined on a lane and the exchange waits for its pack through an event.
-struct WireHeader { uint32_t magic; int32_t rc; int32_t count; int32_t rank; };
+struct WireHeader { uint32_t magic; int32_t rc; int32_t count; int32_t rank; uint32_t user; };
 static bool sharded_transport(const pais_mvs *m) { return m->ctx && (m->nccl || m->emuMode == 2); }
 
 // every rank grows its buffers for the same batches (sizes follow from the replicated candidate list); a rank that cannot
@@ -1054,7 +1060,7 @@ static int emu_fill_blocks(pais_mvs *m, pais_mvs::ShardXfer &X)
         if (r == m->rank) continue;
         unsigned char *blk = X.B->h_wireAll + X.slot * (size_t)r;
         const int rlo = std::min(r * X.per, X.n), rcnt = std::min(rlo + X.per, X.n) - rlo;
-        WireHeader hd = {PAIS_WIRE_MAGIC, 0, rcnt, r};
+        WireHeader hd = {PAIS_WIRE_MAGIC, 0, rcnt, r, m->streamWish ? 1u : 0u}; // (every emulated rank decides as this one does)
         memset(blk, 0, kWireHeader);
         memcpy(blk, &hd, sizeof(hd));
         for (int i = 0; i < rcnt; ++i) {
@@ -1108,7 +1114,7 @@ static void shard_refine_enqueue(pais_mvs *m, pais_mvs::ShardXfer &X)
     }
     X.localRc = rc;
     // (a rank whose refinement failed still takes part in the collective: its header carries the status)
-    if (pais_wire_header_device(X.lane, m->rank, X.cnt, rc, B.d_wireS)) { if (!X.localRc) X.localRc = -2; g_mvs_err = pais_last_error(); }
+    if (pais_wire_header_device(X.lane, m->rank, X.cnt, rc, m->streamWish ? 1u : 0u, B.d_wireS)) { if (!X.localRc) X.localRc = -2; g_mvs_err = pais_last_error(); }
     if (X.lane != m->ctx) (void)hipEventRecord(B.packed, ls);
 }
 
@@ -1156,6 +1162,7 @@ static int shard_finish(pais_mvs *m, pais_mvs::ShardXfer &X, pais_patch_result *
         for (int r = 0; r < world; ++r) {
             WireHeader hd;
             memcpy(&hd, B.h_wireAll + X.slot * (size_t)r, sizeof(hd));
+            if (r == 0 && hd.magic == PAIS_WIRE_MAGIC) m->streamAgreed = (hd.user & 1u) != 0; // rank 0's choice binds every rank
             const int rlo = std::min(r * X.per, X.n), rcnt = std::min(rlo + X.per, X.n) - rlo;
             if (hd.magic != PAIS_WIRE_MAGIC || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
             if (hd.rc == PAIS_WIRE_RC_RING_RETRY) { retry = true; continue; }
@@ -1232,7 +1239,7 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
     m->sendBuf.assign((size_t)per, pais_patch_result());
     if (cnt > 0) localRc = refine_local(m, cnt, c + lo, m->sendBuf.data(), has_seeds);
     m->wireSend.assign(slot, 0);
-    WireHeader hd0 = {PAIS_WIRE_MAGIC, localRc, cnt, m->rank};
+    WireHeader hd0 = {PAIS_WIRE_MAGIC, localRc, cnt, m->rank, 0u};
     memcpy(m->wireSend.data(), &hd0, sizeof(hd0));
     if (!localRc && pais_pack_records(cnt, m->sendBuf.data(), Kb, m->wireSend.data() + kWireHeader)) localRc = -1;
     {
@@ -1956,9 +1963,10 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         // batch of its own, the two exchanges enqueued on the driver's stream in part order (shard_submit / shard_finish)
         const bool oneGpu = m->ctx && m->world <= 1 && !m->nccl && !m->gatherCb && m->emuMode != 2;
         const bool shardStream = sharded_transport(m) && m->streamSharded;
+        const bool timingSaysStream = m->streamRounds == 1 && m->prevHostMs >= m->streamHostMs && m->prevHostMs >= m->streamHostShare * m->prevGpuMs;
+        m->streamWish = timingSaysStream; // (travels in this rank's header with the next sharded batch)
         const bool canStream = (oneGpu || shardStream) && m->emuMode != 1 &&
-                               (m->streamRounds >= 2 ||
-                                (m->streamRounds == 1 && m->prevHostMs >= m->streamHostMs && m->prevHostMs >= m->streamHostShare * m->prevGpuMs));
+                               (m->streamRounds >= 2 || (shardStream ? (m->streamRounds == 1 && m->streamAgreed) : timingSaysStream));
         int beginRc = 0;
         double tFirst = 0;
         double enqueueMs = 0; // host time of the first part's enqueue: inside round_begin, but not enumeration
