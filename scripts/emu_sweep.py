@@ -40,7 +40,7 @@ def main():
         sha = m.cloud_sha1()
         if os.environ.get("EMU_TABLE"):
             import bisect
-            edges = [0, 68, 200, 500, 1000, 2000, 4000, 8000, 16000, 1 << 30]
+            edges = [0, 30, 68, 120, 200, 300, 500, 700, 1000, 1500, 2000, 4000, 8000, 16000, 1 << 30]
             t = [[0, 0.0, 0.0, 0.0] for _ in edges]
             for l in m.round_log():
                 b = bisect.bisect_right(edges, l.n) - 1
@@ -58,7 +58,7 @@ def main():
                  st.host_enumerate_ms, st.host_commit_ms, st.gpu_refine_ms, st.emu_replay_ms, ok), flush=True)
         if os.environ.get("EMU_TABLE"):
             import bisect
-            edges = [0, 68, 200, 500, 1000, 2000, 4000, 8000, 16000, 1 << 30]
+            edges = [0, 30, 68, 120, 200, 300, 500, 700, 1000, 1500, 2000, 4000, 8000, 16000, 1 << 30]
             def table(log):
                 t = [[0, 0.0, 0.0, 0.0] for _ in edges]
                 for l in log:
