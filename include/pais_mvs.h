@@ -108,10 +108,12 @@ int  pais_mvs_set_thin_front(pais_mvs *m, int thin_front);
 /* ---- multi-GPU: one process per GPU, replicated driver, sharded refinement ----
  * Every rank creates the same driver on its own GPU (same cameras, config, seeds, pso_seed) and joins a
  * communicator.  From then on pais_mvs_refine_seed_patches / pais_mvs_expansion_patches split every batch of
- * candidates into `world` contiguous, count-balanced shards; a rank refines its shard (pais_refine_batch_device,
- * records stay in HBM) and the fixed-size pais_patch_result records are exchanged with ONE all-gather per batch --
- * ncclAllGather (RCCL over xGMI) on the context's stream -- after which every rank replays the identical
- * host bookkeeping.  Batches of fewer than PAIS_REPLICATE_BELOW_WAVES evaluation waves per PSO iteration (candidates x
+ * candidates into `world` contiguous, count-balanced shards; a rank refines its shard (pais_refine_batch_device_async,
+ * records stay in HBM) and the records -- packed into fixed-size wire slots behind a 64-byte status header that is written on
+ * the device -- are exchanged with ONE all-gather per batch -- ncclAllGather (RCCL over xGMI) on the context's stream, ONE host
+ * synchronisation per batch -- after which every rank replays the identical host bookkeeping.  Large rounds are streamed in
+ * PAIS_STREAM_PARTS (4) sharded parts on lanes, so that the replicated host work runs under the GPUs' work; whether a round
+ * is streamed is rank 0's timing-driven choice, carried in the headers, so that every rank issues the same collectives.  Batches of fewer than PAIS_REPLICATE_BELOW_WAVES evaluation waves per PSO iteration (candidates x
  * particles) are latency bound on one GPU already -- their launches take one wave's latency however many GPUs share
  * them -- so every rank refines all of them itself (the refinement is deterministic: the replicas agree bit for bit) and
  * no collective is issued.  The cloud is identical for every world size.
