@@ -1078,7 +1078,11 @@ static int shard_exchange(pais_mvs *m, pais_mvs::ShardXfer &X)
 {
     hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
     pais_mvs::ShardBufs &B = *X.B;
-    if (X.lane != m->ctx) MHIP(hipStreamWaitEvent(xs, B.packed, 0));
+    // (a HIP error on this rank before the collective must not keep it out of the collective -- the others would wait in it
+    // for ever: it is noted, the all-gather is entered regardless, and the error is returned afterwards; the garbage this rank
+    // may have sent fails the header check of the others)
+    hipError_t pre = hipSuccess;
+    if (X.lane != m->ctx) pre = hipStreamWaitEvent(xs, B.packed, 0);
     if (m->emuMode == 2) {
         // the other ranks' blocks arrive from the host (about what the links would deliver), this rank's own from its buffer
         for (int r = 0; r < m->world; ++r) {
@@ -1093,6 +1097,7 @@ static int shard_exchange(pais_mvs *m, pais_mvs::ShardXfer &X)
         int nr = a->allGather(B.d_wireS, B.d_wireAll, X.slot, rccl::kInt8, m->nccl, xs);
         if (nr != 0) { g_mvs_err = std::string("ncclAllGather: ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
     }
+    if (pre != hipSuccess) { g_mvs_err = std::string("hipStreamWaitEvent: ") + hipGetErrorString(pre); return -2; }
     MHIP(hipMemcpyAsync(B.h_wireAll, B.d_wireAll, X.slot * (size_t)m->world, hipMemcpyDeviceToHost, xs));
     MHIP(hipEventRecord(B.done, xs));
     m->st.exchange_bytes += (int64_t)(X.slot * (size_t)m->world);
