@@ -12,6 +12,7 @@
 //     deletion -- the reference scans a vector<int> per pop (O(n^2), mvs.cpp:656-693);
 //     ties resolve to the earliest queued id exactly as its strict '<' scan does.
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -86,46 +87,62 @@ struct CellEntry { int id, next; };
 class CellMap {
 public:
     static constexpr int kTile = 32, kShift = 5, kTileCells = kTile * kTile;
+    // a cell: the head of its list in the shared pool, and (round 4) what makes MVS::skipNeighborCell's answer "skip" without a
+    // look at the list: the earliest expansion round in which a live patch of correlation > minCorrelation landed in the cell
+    // (kNoBlock: none).  17.5 M of those tests run per reconstruction of the ring scene and seven in eight hit a cell that has
+    // held such a patch for rounds -- the answer then costs the tile row alone, not the pool entry and the patch behind it
+    // (two more dependent cache misses into maps far larger than the caches).
+    static constexpr int32_t kNoBlock = INT32_MAX;
+    struct Cell { int32_t head, block; };
     int width = 0, height = 0, tilesX = 0;
-    std::vector<int32_t> tileOf; // tile table: index into `heads` / kTileCells, or -1
-    std::vector<int32_t> heads;
+    std::vector<int32_t> tileOf; // tile table: index into `cells` / kTileCells, or -1
+    std::vector<Cell> cells;
     std::vector<int32_t> claimed; // per cell: the expansion round in which a unit claimed it (R(B), round_begin); -1 never
     void init(int w, int h)
     {
         width = w; height = h;
         tilesX = (w + kTile - 1) >> kShift;
         tileOf.assign((size_t)tilesX * ((h + kTile - 1) >> kShift), -1);
-        heads.clear();
+        cells.clear();
         claimed.clear();
     }
     bool inMap(int x, int y) const { return !(x < 0 || y < 0 || x >= width || y >= height); } // cellmap.cpp:18-23
     bool tileEmpty(int x, int y) const { return tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)] < 0; }
+    // the cell, or nullptr while its tile does not exist
+    const Cell *cell(int x, int y) const
+    {
+        const int32_t t = tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)];
+        return t < 0 ? nullptr : &cells[(size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1))];
+    }
     // first pool entry of the cell, -1 if it is empty
     int32_t first(int x, int y) const
     {
-        const int32_t t = tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)];
-        return t < 0 ? -1 : heads[(size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1))];
+        const Cell *c = cell(x, y);
+        return c ? c->head : -1;
     }
     void prefetch(int x, int y) const
     {
-        const int32_t t = tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)];
-        if (t >= 0) __builtin_prefetch(&heads[(size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1))]);
+        const Cell *c = cell(x, y);
+        if (c) __builtin_prefetch(c);
     }
-    // the cell's head for writing (valid until the next call that allocates a tile)
-    int32_t *slot(int x, int y)
+    // index of the cell in `cells` / `claimed`; its tile is allocated if need be (references into `cells` are valid until the
+    // next call that allocates a tile)
+    size_t index(int x, int y)
     {
         int32_t &t = tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)];
         if (t < 0) {
-            t = (int32_t)(heads.size() / kTileCells);
-            heads.resize(heads.size() + kTileCells, -1);
+            t = (int32_t)(cells.size() / kTileCells);
+            cells.resize(cells.size() + kTileCells, Cell{-1, kNoBlock});
             claimed.resize(claimed.size() + kTileCells, -1);
         }
-        return &heads[(size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1))];
+        return (size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1));
     }
+    // the cell's head for writing
+    int32_t *slot(int x, int y) { return &cells[index(x, y)].head; }
     // first call for this cell in `round`: true (and the cell is marked); later calls of the round: false
     bool claim(int x, int y, int round)
     {
-        const size_t i = (size_t)(slot(x, y) - heads.data());
+        const size_t i = index(x, y);
         if (claimed[i] == round) return false;
         claimed[i] = round;
         return true;
@@ -291,6 +308,9 @@ struct pais_mvs {
     bool trustSceneStage = true;       // PAIS_HOST_SCENE_TEST=1: always evaluate the camera loop of runtimeFiltering on the host
     std::vector<HotPatch> hot;         // hot[id]: dense copy of what skipNeighborCell reads of patches[id]
     std::vector<CellMap> cellMaps;     // mvs.h:88 (empty until setCellMaps)
+    bool blockEnable = true;           // PAIS_CELL_BLOCK=0: skipNeighborCell always walks the lists (A/B, tests)
+    bool blocksValid = false;          // the cells' `block` summaries describe the lists (false while a patch's correlation has changed
+                                       // under existing maps: skipNeighborCell then walks the lists as the reference does)
     std::vector<CellEntry> pool;
     int freeEntry = -1;
     std::priority_queue<QItem, std::vector<QItem>, BestFirst> qBest;
@@ -397,11 +417,23 @@ struct pais_mvs {
         int e;
         if (freeEntry >= 0) { e = freeEntry; freeEntry = pool[e].next; }
         else { e = (int)pool.size(); pool.push_back(CellEntry()); }
-        int32_t *h = m.slot(x, y);
+        CellMap::Cell &c = m.cells[m.index(x, y)];
         pool[e].id = id;
-        pool[e].next = *h;
-        *h = e;
+        pool[e].next = c.head;
+        c.head = e;
+        const HotPatch &hp = hot[id];
+        if (hp.alive && hp.correlation > cfg.minCorrelation && hp.born < c.block) c.block = hp.born;
         return true;
+    }
+    // the cell's summary from its list (after a patch has left it)
+    void cellReblock(CellMap::Cell &c) const
+    {
+        int32_t b = CellMap::kNoBlock;
+        for (int e = c.head; e >= 0; e = pool[e].next) {
+            const HotPatch &hp = hot[pool[e].id];
+            if (hp.alive && hp.correlation > cfg.minCorrelation && hp.born < b) b = hp.born;
+        }
+        c.block = b;
     }
     bool cellDrop(CellMap &m, int x, int y, int id) // cellmap.cpp:31-38
     {
@@ -414,6 +446,7 @@ struct pais_mvs {
                 *link = pool[e].next;
                 pool[e].next = freeEntry;
                 freeEntry = e;
+                cellReblock(m.cells[m.index(x, y)]);
                 return true;
             }
             link = &pool[e].next;
@@ -435,8 +468,12 @@ struct pais_mvs {
     //      (patches inserted during it are ignored; cell-claim rule of R(B))
     bool skipNeighborCell(const CellMap &m, int x, int y, const pais_patch_result &ref, int beforeRound) const
     {
-        const int first = m.first(x, y);
-        if (first < 0) return false;
+        const CellMap::Cell *cl = m.cell(x, y);
+        if (!cl || cl->head < 0) return false;
+        // a live patch of correlation > minCorrelation that was in the cell before the round makes the second loop below return
+        // true (if the count has not done so already): the cell's summary says so without the walk
+        if (blocksValid && (beforeRound >= 0 ? cl->block < beforeRound : cl->block != CellMap::kNoBlock)) return true;
+        const int first = cl->head;
         int pthNum = 0;
         for (int e = first; e >= 0; e = pool[e].next) {
             const HotPatch &p = hot[pool[e].id];
@@ -725,6 +762,7 @@ struct pais_mvs {
             cellBytes += sizeof(int32_t) * (size_t)cellMaps[c].width * cellMaps[c].height;
         }
         deepPrefetch = cellBytes > ((size_t)16 << 20);
+        blocksValid = blockEnable;
         for (auto *p : patches) {
             if (!p) continue;
             for (int i = 0; i < p->r.num_cam; ++i) {
@@ -756,6 +794,7 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
     if (!cfg || !cams || !out || num_cams <= 0) return mfail("pais_mvs_create: bad argument");
     pais_mvs *m = new pais_mvs();
     if (const char *e = getenv("PAIS_HOST_SCENE_TEST")) m->trustSceneStage = atoi(e) == 0;
+    if (const char *e = getenv("PAIS_CELL_BLOCK")) m->blockEnable = atoi(e) != 0;
     if (const char *e = getenv("PAIS_THIN_FRONT")) m->thinFront = atoi(e) < 0 ? 0 : atoi(e); // tuning sweeps (scripts/)
     {
         const unsigned hw = std::thread::hardware_concurrency();
@@ -1409,6 +1448,7 @@ extern "C" int pais_mvs_seed_commit(pais_mvs *m, const pais_patch_result *result
             HotPatch &h = m->hot[id];
             for (int i = 0; i < 3; ++i) { h.center[i] = p->r.center[i]; h.normal[i] = p->r.normal[i]; }
             h.correlation = p->r.correlation;
+            if (!m->cellMaps.empty()) m->blocksValid = false; // (maps built before this refinement: rebuilt by pais_mvs_expansion_begin)
         }
         m->st.seeds_refined++;
         m->st.pso_evals_effective += results[k].pso_evals;
