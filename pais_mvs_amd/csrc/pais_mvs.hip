@@ -628,10 +628,28 @@ struct pais_mvs {
         return new (slot) HostPatch; // default-initialised: the record is assigned by the caller
     }
 
+    // a record into the arena: what is meaningful of it -- the scalars and the first num_cam entries of the two PAIS_MAX_VIS-long
+    // arrays (1 280 of its 1 488 bytes are those arrays; a pawn patch uses 100 of them).  The array tails of an arena record
+    // are unspecified; pais_mvs_get_patch hands out zeros there, which is what the batch calls write.
+    static void copyRecordCompact(pais_patch_result *dst, const pais_patch_result &r)
+    {
+        static_assert(offsetof(pais_patch_result, imgPoint) == 136 && offsetof(pais_patch_result, key) == 1160 &&
+                      offsetof(pais_patch_result, cam_idx) == 1200 && offsetof(pais_patch_result, stage) == 1456 &&
+                      sizeof(pais_patch_result) == 1488, "pais_patch_result layout");
+        const int K = r.num_cam < 0 ? 0 : (r.num_cam > PAIS_MAX_VIS ? PAIS_MAX_VIS : r.num_cam);
+        const unsigned char *s = (const unsigned char *)&r;
+        unsigned char *d = (unsigned char *)dst;
+        memcpy(d, s, 136);
+        memcpy(d + 136, s + 136, sizeof(double) * 2 * (size_t)K);
+        memcpy(d + 1160, s + 1160, 40);
+        memcpy(d + 1200, s + 1200, sizeof(int32_t) * (size_t)K);
+        memcpy(d + 1456, s + 1456, 32);
+    }
+
     int storePatch(const pais_patch_result &r)
     {
         HostPatch *hp = allocPatch();
-        hp->r = r;
+        copyRecordCompact(&hp->r, r);
         hp->id = (int)patches.size();
         hp->expanded = false;
         hp->born = curRound;
@@ -2402,7 +2420,10 @@ extern "C" int pais_mvs_num_slots(const pais_mvs *m) { return m ? (int)m->patche
 extern "C" int pais_mvs_get_patch(const pais_mvs *m, int id, pais_patch_result *out, int *expanded)
 {
     if (!m || id < 0 || id >= (int)m->patches.size() || !m->patches[id]) return 1;
-    if (out) *out = m->patches[id]->r;
+    if (out) {
+        memset(out, 0, sizeof(*out)); // (array tails beyond num_cam: zeros, as the batch calls leave them)
+        pais_mvs::copyRecordCompact(out, m->patches[id]->r);
+    }
     if (expanded) *expanded = m->patches[id]->expanded ? 1 : 0;
     return 0;
 }
