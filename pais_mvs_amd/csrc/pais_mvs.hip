@@ -93,7 +93,7 @@ public:
     // held such a patch for rounds -- the answer then costs the tile row alone, not the pool entry and the patch behind it
     // (two more dependent cache misses into maps far larger than the caches).
     static constexpr int32_t kNoBlock = INT32_MAX;
-    struct Cell { int32_t head, block; };
+    struct Cell { int32_t head, block, count; }; // count: entries of the list (runtimeFiltering's full-cell test, mvs.cpp:872-886, without the walk)
     int width = 0, height = 0, tilesX = 0;
     std::vector<int32_t> tileOf; // tile table: index into `cells` / kTileCells, or -1
     std::vector<Cell> cells;
@@ -132,7 +132,7 @@ public:
         int32_t &t = tileOf[(size_t)(y >> kShift) * tilesX + (x >> kShift)];
         if (t < 0) {
             t = (int32_t)(cells.size() / kTileCells);
-            cells.resize(cells.size() + kTileCells, Cell{-1, kNoBlock});
+            cells.resize(cells.size() + kTileCells, Cell{-1, kNoBlock, 0});
             claimed.resize(claimed.size() + kTileCells, -1);
         }
         return (size_t)t * kTileCells + (size_t)((y & (kTile - 1)) << kShift) + (x & (kTile - 1));
@@ -421,6 +421,7 @@ struct pais_mvs {
         pool[e].id = id;
         pool[e].next = c.head;
         c.head = e;
+        c.count++;
         const HotPatch &hp = hot[id];
         if (hp.alive && hp.correlation > cfg.minCorrelation && hp.born < c.block) c.block = hp.born;
         return true;
@@ -446,7 +447,9 @@ struct pais_mvs {
                 *link = pool[e].next;
                 pool[e].next = freeEntry;
                 freeEntry = e;
-                cellReblock(m.cells[m.index(x, y)]);
+                CellMap::Cell &c = m.cells[m.index(x, y)];
+                c.count--;
+                cellReblock(c);
                 return true;
             }
             link = &pool[e].next;
@@ -598,14 +601,15 @@ struct pais_mvs {
             int cy = (int)(p.imgPoint[i][1] / cfg.cellSize);
             const CellMap &m = cellMaps[p.cam_idx[i]];
             if (!m.inMap(cx, cy)) continue;
+            const CellMap::Cell *cl = m.cell(cx, cy);
+            if (!cl) continue;
+            // (a patch that is being inserted -- id == the next slot -- is in no list yet: only the count matters)
             bool found = false;
-            int n = 0;
-            for (int e = m.first(cx, cy); e >= 0; e = pool[e].next) {
-                ++n;
-                if (pool[e].id == id) found = true;
-            }
+            if (id < (int)patches.size())
+                for (int e = cl->head; e >= 0; e = pool[e].next)
+                    if (pool[e].id == id) { found = true; break; }
             if (found) return true;
-            if (n >= cfg.maxCellPatchNum) ++fullCellCounter;
+            if (cl->count >= cfg.maxCellPatchNum) ++fullCellCounter;
         }
         if (fullCellCounter >= p.num_cam) return false;
         return true;
