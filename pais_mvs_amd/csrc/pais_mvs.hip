@@ -1698,8 +1698,10 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
         for (int j = 0; j < 4; ++j) {
             const int x = cx + dx[j], y = cy + dy[j];
             if (!map.inMap(x, y)) continue;
-            const int e = map.first(x, y);
-            if (e < 0) continue;
+            const CellMap::Cell *cl = map.cell(x, y);
+            if (!cl || cl->head < 0) continue;
+            if (m->blocksValid && cl->block < m->curRound) continue; // (answered from the tile row: the list is not walked)
+            const int e = cl->head;
             if (patch) __builtin_prefetch(&m->hot[m->pool[e].id]);
             else __builtin_prefetch(&m->pool[e]);
         }
