@@ -144,7 +144,8 @@ int  pais_mvs_emulate(pais_mvs *m, int mode, int rank, int world);
 /* Evaluation waves per iteration below which a multi-rank batch is replicated instead of sharded (default
  * PAIS_REPLICATE_BELOW_WAVES; 0 = always shard).  Must be the same on every rank. */
 int  pais_mvs_set_replicate_below(pais_mvs *m, int waves);
-/* A driver created with device < 0 owns no GPU and never computes a record.  This callback lets the owner of the
+/* (GPU-less drivers only -- schedulers under test, a host that keeps the records elsewhere; a driver that owns a GPU context
+ * refuses it.)  A driver created with device < 0 owns no GPU and never computes a record.  This callback lets the owner of the
  * records (a process that has the GPU, a test's checker) feed the monolithic entry points above -- the stepwise
  * entry points below folded into a callback; n candidates in, n records out, host pointers. */
 typedef int (*pais_record_source_fn)(void *user, int n, const pais_candidate *cands, pais_patch_result *out, int has_seeds);

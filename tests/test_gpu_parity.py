@@ -1258,6 +1258,27 @@ def test_seed_batches_and_device_pointer_batches_through_the_task_ring(pawn_smal
     b, stb, ksb = cloud({"PAIS_SPLIT_ABOVE": "1", "PAIS_RING_PER_CAM": "0", "PAIS_RING_SEED_ABOVE": "1"})
     assert a == b and sta.batches_sharded == stb.batches_sharded > 3
     assert ksa.ring_launches == 0 and ksb.ring_launches >= sta.batches_sharded and ksb.ring_fallbacks == 0, (ksb.ring_launches, sta.batches_sharded)
+    # streamed rounds over the REAL RCCL communicator (a world of one rank): four sharded parts per round on four lanes, every
+    # ncclAllGather enqueued on the driver's stream behind an event of the part's lane -- the same cloud as one batch per round
+    def cloud_rounds(env):
+        from pais_mvs_amd.mvs import get_unique_id
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = MVS(cfg, pawn_small.cameras, device=0, seed=42)
+        m.comm_init_rccl(0, 1, get_unique_id())
+        m.set_replicate_below(0)
+        for X, vis in pawn_small.seeds:
+            m.add_seed(X, vis)
+        m.refineSeedPatches()
+        m.expansionPatches(4096, 8)
+        sha, st = m.cloud_sha1(), m.stats()
+        m.close()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        return sha, st
+    c0, st0 = cloud_rounds({"PAIS_STREAM_ROUNDS": "0"})
+    c1, st1 = cloud_rounds({"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_PARTS": "4"})
+    assert c0 == c1 and st0.rounds_streamed == 0 and st1.rounds_streamed > 0 and st1.batches_sharded > st0.batches_sharded
 
 
 @pytest.mark.gpu
