@@ -166,13 +166,16 @@ PAIS_HD double bilinear(const uint8_t *img, int stride, double ix, double iy)
 // Least squares via one-sided Jacobi SVD, all sizes static so everything stays
 // in registers on the GPU.  Pseudo-inverse threshold: 2*DBL_EPSILON*sum(w), as
 // cvSolve(..., CV_SVD) uses.
+#ifndef PAIS_JACOBI_SWEEPS
+#define PAIS_JACOBI_SWEEPS 60
+#endif
 template <int N, int M>
 PAIS_HD void jacobi_lstsq(double (&A)[N][M], const double (&b)[N], double (&x)[M])
 {
     double V[M][M];
     for (int i = 0; i < M; ++i)
         for (int j = 0; j < M; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
+    for (int sweep = 0; sweep < PAIS_JACOBI_SWEEPS; ++sweep) {
         bool changed = false;
 #pragma unroll
         for (int p = 0; p < M - 1; ++p) {
