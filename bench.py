@@ -324,8 +324,16 @@ def main():
     # the cloud of the LAST TIMED step, hashed (outside the timed region): pais_mvs_amd.mvs.patches_sha1 over every
     # accepted patch in id order.  tests/golden/bench_cloud_<scene>.json holds what the ORACLE produces for the default
     # workload (tests/golden/make_bench_golden.py) -- the line checks itself against it.
-    cloud_sha1 = m.cloud_sha1() if rank == 0 else None
+    cloud_sha1 = m.cloud_sha1() if (rank == 0 or world > 1) else None
     accepted = int(m.num_patches())
+    # several ranks: every rank hashes ITS replica of the cloud; rank 0 reports whether they all hold the same one
+    ranks_agree = None
+    if world > 1:
+        try:
+            allsha = job.all_gather_bytes(cloud_sha1.encode("ascii"), 40)
+            ranks_agree = all(allsha[40 * r:40 * (r + 1)] == allsha[:40] for r in range(world))
+        except Exception:
+            ranks_agree = None
     # Roofline leg (not part of `value`): ONE more step of the same workload with every cost-evaluation launch
     # bracketed by HIP events on the stream it is launched on (two overlapping sub-streams by default).
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 1)
@@ -478,6 +486,7 @@ def main():
                        "patches_per_step": units // max(args.steps, 1),
                        "accepted_patches": accepted,
                        "cloud_sha1": cloud_sha1, "cloud_sha1_expected": gold_sha, "cloud_matches_oracle_golden": gold_ok,
+                       "ranks_hold_the_same_cloud": ranks_agree,
                        "speculative_extra_refines_per_step": spec // max(args.steps, 1),
                        "rounds_per_step": int(last.rounds) if last else 0,
                        "rounds_streamed_per_step": int(last.rounds_streamed) if last else 0,

@@ -93,3 +93,21 @@ def test_full_size_bench_lines_carry_the_oracles_hash(scene, rounds, name):
     assert c["cloud_sha1"] == g["cloud_sha1"] and c["cloud_matches_oracle_golden"] is True, (c["cloud_sha1"], g["cloud_sha1"])
     assert c["patches_per_step"] == g["patches_per_step"] and c["accepted_patches"] == g["accepted_patches"]
     assert c["speculative_extra_refines_per_step"] == g["speculative_extra_refines"]
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_on_one_gpu_reports_one_agreed_cloud():
+    """`bench.py --gpus 2` as the driver starts it (bench.py's own spawner here), with the two test hooks a one-GPU box needs:
+    both ranks on device 0 and the records through host memory (RCCL refuses two ranks on one device).  Every rank hashes its
+    replica of the cloud; the line says that they agree, and the cloud is the oracle's golden one."""
+    env = dict(os.environ, PAIS_FORCE_DEVICE="0", PAIS_DIST_TRANSPORT="host", MASTER_PORT="29571")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    c = line["config"]
+    assert line["n_gpus"] == 2 and c["ranks_hold_the_same_cloud"] is True
+    assert c["cloud_sha1"] == GOLD["cloud_sha1"] and c["cloud_matches_oracle_golden"] is True
+    assert c["batches_sharded_per_step"] > 0 and c["exchange_bytes_per_step"] > 0
