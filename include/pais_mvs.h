@@ -133,23 +133,11 @@ int  pais_mvs_create_ranked(const pais_config *cfg, int num_cams, const pais_cam
  * pointers; returns 0 on success.  The driver stages the records through pinned host memory around the call. */
 typedef int (*pais_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
 int  pais_mvs_comm_init_callback(pais_mvs *m, int rank, int world, pais_allgather_fn fn, void *user);
-/* MEASUREMENT AID: one rank of a larger world on ONE GPU (bench.py --emulate-world).  mode 1 on a single-rank driver records
- * the records of every batch, keyed by candidate; mode 2 then makes this driver rank `rank` of `world`: every sharded batch
- * runs the real sharded code path (shard refined on the GPU, packed, status header, copy down, unpack, replicated commit;
- * thin batches replicated; large rounds streamed) with the other ranks' blocks replayed from the recorded run in place of the
- * ncclAllGather -- the bytes arrive over PCIe instead of xGMI, plus PAIS_EMU_LATENCY_US (25) of modelled collective launch
- * latency.  mode 0 switches it off.  What it measures: T_rank(world) on this GPU; what it cannot: link contention and the
- * wait for the slowest rank (bench.py takes the maximum over the ranks it emulates). */
-int  pais_mvs_emulate(pais_mvs *m, int mode, int rank, int world);
 /* Evaluation waves per iteration below which a multi-rank batch is replicated instead of sharded (default
  * PAIS_REPLICATE_BELOW_WAVES; 0 = always shard).  Must be the same on every rank. */
 int  pais_mvs_set_replicate_below(pais_mvs *m, int waves);
-/* (GPU-less drivers only -- schedulers under test, a host that keeps the records elsewhere; a driver that owns a GPU context
- * refuses it.)  A driver created with device < 0 owns no GPU and never computes a record.  This callback lets the owner of the
- * records (a process that has the GPU, a test's checker) feed the monolithic entry points above -- the stepwise
- * entry points below folded into a callback; n candidates in, n records out, host pointers. */
-typedef int (*pais_record_source_fn)(void *user, int n, const pais_candidate *cands, pais_patch_result *out, int has_seeds);
-int  pais_mvs_set_record_source(pais_mvs *m, pais_record_source_fn fn, void *user);
+/* (test / measurement hooks -- pais_mvs_emulate, pais_mvs_set_record_source -- live in include/pais_test_hooks.h: a reference
+ * maintainer binding this library needs neither) */
 
 /* ---- stepwise ---------------------------------------------------------- */
 /* seeds: candidates of all seeds with camNum >= minCamNum (others are deleted) */

@@ -607,9 +607,15 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
         const int cols = cam->width[LOD], rows = cam->height[LOD];
         const double *Hi = f->H + 9 * i;
 
-        w = (Hi[6] * x + Hi[7] * y + Hi[8]);
-        ix = (Hi[0] * x + Hi[1] * y + Hi[2]) / w;
-        iy = (Hi[3] * x + Hi[4] * y + Hi[5]) / w;
+        if (s->literalVariant & 4) { /* control: a * x + b * y + c contracted = fma(b, y, a * x) + c */
+            w = fma(Hi[7], y, Hi[6] * x) + Hi[8];
+            ix = (fma(Hi[1], y, Hi[0] * x) + Hi[2]) / w;
+            iy = (fma(Hi[4], y, Hi[3] * x) + Hi[5]) / w;
+        } else {
+            w = (Hi[6] * x + Hi[7] * y + Hi[8]);
+            ix = (Hi[0] * x + Hi[1] * y + Hi[2]) / w;
+            iy = (Hi[3] * x + Hi[4] * y + Hi[5]) / w;
+        }
 
         if (ix < 2 || ix >= cols - 3 || iy < 2 || iy >= rows - 3 || w == 0) return -1; /* :999 */
         /* (int)NaN is UB in the reference; NaN passes the test above only if w
@@ -621,6 +627,15 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
         px[2] = px[0]; py[2] = py[0] + 1;
         px[3] = px[0] + 1; py[3] = py[0] + 1;
 
+        if (s->literalVariant & 4) { /* control: ((t0 + t1) + t2) + t3 with t = (img * u) * v contracted left to right */
+            const double i0 = (double)img[(size_t)py[0] * cols + px[0]], i1 = (double)img[(size_t)py[1] * cols + px[1]];
+            const double i2 = (double)img[(size_t)py[2] * cols + px[2]], i3 = (double)img[(size_t)py[3] * cols + px[3]];
+            double acc = i0 * (px[1] - ix) * (py[2] - iy);
+            acc = fma(i1 * (ix - px[0]), (py[2] - iy), acc);
+            acc = fma(i2 * (px[1] - ix), (iy - py[0]), acc);
+            acc = fma(i3 * (ix - px[0]), (iy - py[0]), acc);
+            c[i] = acc;
+        } else
         c[i] = (double)img[(size_t)py[0] * cols + px[0]] * (px[1] - ix) * (py[2] - iy) +
                (double)img[(size_t)py[1] * cols + px[1]] * (ix - px[0]) * (py[2] - iy) +
                (double)img[(size_t)py[2] * cols + px[2]] * (px[1] - ix) * (iy - py[0]) +
@@ -830,15 +845,38 @@ double po_get_fitness(const po_scene *s, const po_patch *patch, const double pos
 
     /* the reference's walk: x outer, y inner, sequential sums (patch.cpp:979-1041) */
     const double *it = s->gauss;
+    if (s->literalVariant & 2) {
+        /* CONTROL (not the reference): the same pixels with the same coordinates and weights, accumulated y outer / x inner.
+         * x and y of a pixel are the values the reference's two loops give it (start + k by repeated ++). */
+        const int S = s->cfg.patchSize;
+        double xs[PO_MAX_PATCH_SIZE], ys[PO_MAX_PATCH_SIZE];
+        int nx = 0, ny = 0;
+        for (double x = pt[0] - patchRadius; x <= pt[0] + patchRadius && nx < PO_MAX_PATCH_SIZE; ++x) xs[nx++] = x;
+        for (double y = pt[1] - patchRadius; y <= pt[1] + patchRadius && ny < PO_MAX_PATCH_SIZE; ++y) ys[ny++] = y;
+        /* an overflowing tap makes the whole call DBL_MAX in either order */
+        for (int yi = 0; yi < ny; ++yi)
+            for (int xi = 0; xi < nx; ++xi) {
+                int st = fit_pixel(&fx, xs[xi], ys[yi], it[xi * S + yi], &weight, &avgSad);
+                if (st < 0) return DBL_MAX;
+                if (st == 0) continue;
+                sumWeight += weight;
+                if (s->literalVariant & 4) fitness = fma(weight, avgSad, fitness);
+                else fitness += weight * avgSad;
+            }
+        if (s->literalVariant & 1) return fitness * (1.0 / sumWeight);
+        return fitness / sumWeight;
+    }
     for (double x = pt[0] - patchRadius; x <= pt[0] + patchRadius; ++x) {
         for (double y = pt[1] - patchRadius; y <= pt[1] + patchRadius; ++y, ++it) {
             int st = fit_pixel(&fx, x, y, *it, &weight, &avgSad);
             if (st < 0) return DBL_MAX;
             if (st == 0) continue;
             sumWeight += weight;
-            fitness += weight * avgSad;
+            if (s->literalVariant & 4) fitness = fma(weight, avgSad, fitness); /* control: contracted */
+            else fitness += weight * avgSad;
         }
     }
+    if (s->literalVariant & 1) return fitness * (1.0 / sumWeight); /* control: ONE rounding of the call perturbed */
     return fitness / sumWeight;
 }
 

@@ -37,6 +37,7 @@ extern "C" {
 
 #define PO_MAX_LEVELS 16   /* LOD 0..15 (config maxLOD default 15, TMVS.cpp:42) */
 #define PO_MAX_VIS    64   /* max visible cameras tracked per patch             */
+#define PO_MAX_PATCH_SIZE 129 /* largest window side (2 r + 1) the control variants of the literal cost handle */
 
 #define PO_TYPE_SEED   0   /* patch.h:17 */
 #define PO_TYPE_EXPAND 1   /* patch.h:18 */
@@ -107,6 +108,17 @@ typedef struct po_scene {
     int        windowPerParticle;        /* kernel arithmetic, but the window origin from every particle's own centre
                                           * (patch.cpp:944-952) instead of once per run: separates the two differences
                                           * between the modes in tests/test_oracle_modes.py; the HIP path has no such mode */
+    int        literalVariant;           /* CONTROL experiments on the literal arithmetic (tests/test_cloud_parity.py,
+                                          * tests/golden/make_literal_control.py; 0 = the reference's statements).  Bit flags; each
+                                          * is the same real-number function evaluated with a rounding difference a compiler / a
+                                          * loop order could legitimately produce from the REFERENCE's own source:
+                                          *  1: the final quotient as fitness * (1.0 / sumWeight) -- ONE rounding perturbed;
+                                          *  2: the window's two sums accumulated y outer / x inner (same pixels, same values);
+                                          *  4: the statements of patch.cpp:994-1041 as a contracting compiler emits them
+                                          *     (gcc's default -ffp-contract=fast on an FMA target): fused multiply-adds in the
+                                          *     homography rows, the bilinear sum and the weighted accumulation.
+                                          *  6 = another loop order AND another compiler: the closest like-for-like of what the
+                                          *     kernel arithmetic changes (reduction order, fused multiply-adds). */
 } po_scene;
 
 /* mvs/abstractpatch.h:22-53 + patch.h:19-20 */

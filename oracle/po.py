@@ -46,7 +46,7 @@ class SceneS(C.Structure):
     _fields_ = [
         ("cfg", Config), ("numCams", C.c_int), ("cams", C.POINTER(CameraS)), ("gauss", C.POINTER(C.c_double)),
         ("lodScale", C.c_double * MAX_LEVELS), ("seed", C.c_uint64), ("ompParticles", C.c_int),
-        ("detMath", C.c_int), ("treeSum", C.c_int), ("windowPerParticle", C.c_int),
+        ("detMath", C.c_int), ("treeSum", C.c_int), ("windowPerParticle", C.c_int), ("literalVariant", C.c_int),
     ]
 
 
@@ -323,3 +323,8 @@ class OracleScene:
         off: platform libm + the reference's sequential sums."""
         self.ptr.contents.detMath = 1 if on else 0
         self.ptr.contents.treeSum = 1 if on else 0
+
+    def set_literal_variant(self, v: int):
+        """CONTROL experiments (pais_oracle.h po_scene.literalVariant, bit flags): 0 the reference's statements; 1 one rounding
+        of the call perturbed; 2 y-outer accumulation; 4 contracted (fused) multiply-adds; 6 both.  Literal arithmetic only."""
+        self.ptr.contents.literalVariant = int(v)

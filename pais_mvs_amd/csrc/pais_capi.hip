@@ -384,7 +384,14 @@ static int ctx_init_work(pais_ctx *ctx)
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     if (const char *e = getenv("PAIS_PSO_RING")) ctx->ringMode = atoi(e);
     if (const char *e = getenv("PAIS_RING_PER_CAM")) ctx->ringPerCam = atof(e);
-    if (const char *e = getenv("PAIS_RING_TIMEOUT_MS")) ctx->ringTimeoutMs = atof(e);
+    if (const char *e = getenv("PAIS_RING_TIMEOUT_MS")) {
+        // 0 is the tests' hook (every ring pass "times out" and is re-run launch by launch); anything else must be a finite wait
+        // of at least a millisecond and at most ten minutes -- negative / NaN values are ignored
+        const double v = atof(e);
+        if (v == 0.0 && e[0] == '0') ctx->ringTimeoutMs = 0.0;
+        else if (v >= 1.0 && v <= 600000.0) ctx->ringTimeoutMs = v;
+        else fprintf(stderr, "pais: PAIS_RING_TIMEOUT_MS=%s ignored (0, or 1 .. 600000 ms)\n", e);
+    }
     // (0 = never, the default: measured on the pawn bench, profiles/r04_seed_ring_ab.txt -- the first pass of the 200 seeds as one
     //  ring launch costs +3.5 ms per reconstruction against k_pso_iter's 2 x 62 launches: with 2N = 30 particles the one-wave
     //  swarm step is a long serial chain between two evaluations of a candidate, and 6000 tasks per iteration are two residency
@@ -905,7 +912,8 @@ static int ring_failed(pais_ctx *ctx, int n)
     for (int r = 0; r < PAIS_RINGS; ++r) { done += ctx->h_ringCtl[(PAIS_RING_CTL_BYTES / 4) * r + PAIS_RING_CTL_DONE_WORD]; err |= ctx->h_ringCtl[(PAIS_RING_CTL_BYTES / 4) * r + PAIS_RING_CTL_ERROR_WORD]; }
     if (err == 0 && done == (unsigned)n) return 0;
     ctx->ringFallbacks++;
-    if (getenv("PAIS_RING_VERBOSE"))
+    // one note per context the first time it happens in production (timeout > 0), every time with PAIS_RING_VERBOSE
+    if (getenv("PAIS_RING_VERBOSE") || (ctx->ringFallbacks == 1 && ctx->ringTimeoutMs > 0))
         fprintf(stderr, "[pais] k_pso_ring did not complete (error %u, %u of %d runs ended): the batch is re-run with one launch per iteration\n", err, done, n);
     return 1;
 }
@@ -1072,6 +1080,7 @@ extern "C" int pais_refine_batch_end(pais_ctx *ctx, const pais_patch_result **vi
         PassPlan &P = ctx->plan;
         const int n = P.n;
         ctx->ringSuppressed = true;
+        ctx->countersDirty = true; // (the failed pass's after-stage is not trusted to have left the counter sets clean)
         int rc = batch_setup(ctx, P, n, ctx->d_cands, ctx->d_recs, P.Kmax, 0);
         if (!rc) rc = pass_open(ctx, P, 0, 0);
         if (!rc && (rc = pass_iterations(ctx, P, P.maxIt + 1)) != 0) (void)pass_join(ctx, P);

@@ -919,6 +919,15 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
     }
 }
 
+// MEASUREMENT BUILDS ONLY (scripts/dup_profile.sh): PAIS_EXP_DUP = 1 / 2 / 3 executes one component of k_pso_iter TWICE -- the
+// moveParticles selections / the gBest scan + convergence sums / the cost evaluation -- with identical results, so that the
+// slowdown of the whole reconstruction is that component's share of the critical path (a cycle counter inside one wave is not:
+// DESIGN 4.4).  The library is built with 0.
+#ifndef PAIS_EXP_DUP
+#define PAIS_EXP_DUP 0
+#endif
+__device__ __forceinline__ void exp_opaque(double &v) { asm volatile("" : "+v"(v)); }
+
 // launch L = 0: cost of the initial swarm.  L >= 1: step (L-1) + cost of the moved particle.  finishOnly: one
 // wave per candidate that only replays the step (the launch after the last possible iteration: every run ends).
 // Tasks: positions [listLo, min(listHi, *activeCount)) of the active list written by k_pso_init.
@@ -1021,6 +1030,25 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
                 iw = niw > 0.4 ? niw : 0.4;
                 it = dr.iteration + 1;
             }
+#if PAIS_EXP_DUP == 2
+            { // the scan and the convergence sums once more (idempotent), inputs opaque
+                double pbf2 = pbf, gf2 = gf;
+                exp_opaque(pbf2);
+                int g2 = g;
+                for (int j = 0; j < N; ++j) {
+                    const double v = lane_get(pbf2, j);
+                    if (v <= gf2) { gf2 = v; g2 = j; }
+                }
+                double q0 = pos[0], q1 = pos[1], q2 = pos[2];
+                exp_opaque(q0);
+                const double gB2[3] = {lane_get(pb[0], g2), lane_get(pb[1], g2), lane_get(pb[2], g2)};
+                const double a0 = fabs(q0 - gB2[0]), a1 = fabs(q1 - gB2[1]), a2 = fabs(q2 - gB2[2]);
+                double disp = 0;
+                for (int j = 0; j < N; ++j) { disp += lane_get(a0, j); disp += lane_get(a1, j); disp += lane_get(a2, j); }
+                exp_opaque(disp);
+                exp_opaque(gf2);
+            }
+#endif
             for (int j = 0; j < N; ++j) {
                 const double v = lane_get(pbf, j);
                 if (v <= gf) {
@@ -1090,6 +1118,15 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
             const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
             for (int q = 0; q < 4; ++q) u[q] = uniform_from(streamBase, (uint32_t)runIdx, k0 + q);
             double nP[3], nV[3], nNb[3];
+#if PAIS_EXP_DUP == 1
+            {
+                double t = u[0];
+                exp_opaque(t);
+                const double u2[4] = {t, u[1], u[2], u[3]};
+                pso_move_own(i, N, localK, iw, u2, pos, pb, fitj, pbf, lane, gB, rl, ru, vecI, nbI, nP, nV, nNb);
+                exp_opaque(nP[0]); exp_opaque(nP[1]); exp_opaque(nP[2]); exp_opaque(nV[0]); exp_opaque(nNb[0]);
+            }
+#endif
             pso_move_own(i, N, localK, iw, u, pos, pb, fitj, pbf, lane, gB, rl, ru, vecI, nbI, nP, nV, nNb);
             const double pbI[3] = {lane_get(pb[0], i), lane_get(pb[1], i), lane_get(pb[2], i)};
             const double pbfI = lane_get(pbf, i);
@@ -1121,6 +1158,17 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
         stage_eval_block(smem, src, nwMax, lane, v0, v1); // the run's evaluation block, prepared by k_pso_init
         wave_sync();
         double f4[4], w4[4];
+#if PAIS_EXP_DUP == 3
+        {
+            double t = p0;
+            exp_opaque(t);
+            const int st2 = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, t, p1, p2, lane, part, nparts, f4, w4);
+            exp_opaque(f4[0]); exp_opaque(f4[1]); exp_opaque(f4[2]); exp_opaque(f4[3]);
+            exp_opaque(w4[0]); exp_opaque(w4[1]); exp_opaque(w4[2]); exp_opaque(w4[3]);
+            if (st2 < -5) continue;
+            wave_sync();
+        }
+#endif
         const int st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, part, nparts, f4, w4);
         if (lane == 0) {
             if (nparts == 1) {

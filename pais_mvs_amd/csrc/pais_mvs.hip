@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/pais_mvs.h"
+#include "../../include/pais_test_hooks.h"
 #include "../../include/pais_seed.h"
 #include "pais_dev.hpp"
 
@@ -280,7 +281,8 @@ struct pais_mvs {
         size_t shardCap = 0;
         void *d_wireS = nullptr, *d_wireAll = nullptr;             // wire slots: this rank's (header + shard), all ranks'
         unsigned char *h_wireAll = nullptr;                        // pinned
-        size_t wireCap = 0;
+        size_t wireCap = 0;   // bytes of d_wireAll / h_wireAll (every rank's block)
+        size_t wireSCap = 0;  // bytes of d_wireS (this rank's block): tracked on its own -- a smaller world makes the slot larger
         hipEvent_t packed = nullptr, done = nullptr;
     } sb[PAIS_MAX_STREAM_PARTS];
     struct ShardXfer {
@@ -360,7 +362,10 @@ struct pais_mvs {
     // next round into the status header of its block (streamWish), and rank 0's word, which every rank reads, decides
     // (streamAgreed) -- no collective of its own.
     bool streamWish = false, streamAgreed = false;
-    bool streamSharded = true;         // PAIS_STREAM_SHARDED=0: rounds of the multi-GPU path are never streamed (round 3's behaviour)
+    // rounds of the multi-GPU path streamed in parts (several collectives in flight per round): 1 on, 0 off,
+    // -1 (default) = on in the one-GPU emulation, where it has been measured, OFF over a real RCCL communicator until a run on
+    // >= 2 real GPUs has been green (that path has only ever run against the emulated transport)
+    int streamSharded = -1;
     int streamHead = 4, streamStep = 2; // PAIS_STREAM_HEAD / _STEP: PSO iterations of a part enqueued when it is opened / per turn after that
     const std::function<int(const pais_candidate *, int)> *onFirstPart = nullptr; // set by the streamed driver for one round_begin
     int firstPart = -1;                // candidates of the first part of the current round (-1: the round is one batch)
@@ -831,7 +836,7 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
     if (const char *e = getenv("PAIS_STREAM_HOST_MS")) m->streamHostMs = atof(e);
     if (const char *e = getenv("PAIS_STREAM_HOST_SHARE")) m->streamHostShare = atof(e);
     if (const char *e = getenv("PAIS_STREAM_HEAD")) m->streamHead = std::max(1, atoi(e));
-    if (const char *e = getenv("PAIS_STREAM_SHARDED")) m->streamSharded = atoi(e) != 0;
+    if (const char *e = getenv("PAIS_STREAM_SHARDED")) m->streamSharded = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("PAIS_STREAM_FIRST")) m->streamFirst = std::max(0.0, std::min(0.9, atof(e)));
     if (const char *e = getenv("PAIS_STREAM_PARTS")) m->streamParts = std::max(2, std::min(atoi(e), PAIS_MAX_STREAM_PARTS));
     if (const char *e = getenv("PAIS_STREAM_STEP")) m->streamStep = std::max(1, atoi(e));
@@ -1078,7 +1083,7 @@ static int shard_growth_handshake(pais_mvs *m, int localRc)
 static int shard_ensure(pais_mvs *m, pais_mvs::ShardBufs &B, size_t per, size_t slot)
 {
     const int world = m->world;
-    const bool growShard = per > B.shardCap, growWire = slot * (size_t)world > B.wireCap;
+    const bool growShard = per > B.shardCap, growWire = slot * (size_t)world > B.wireCap || slot > B.wireSCap;
     if (!growShard && !growWire && B.packed) return 0;
     hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
     int rc = 0;
@@ -1103,11 +1108,13 @@ static int shard_ensure(pais_mvs *m, pais_mvs::ShardBufs &B, size_t per, size_t 
     }
     if (growWire && !rc) {
         (void)hipFree(B.d_wireS); (void)hipFree(B.d_wireAll); (void)hipHostFree(B.h_wireAll);
-        B.d_wireS = nullptr; B.d_wireAll = nullptr; B.h_wireAll = nullptr; B.wireCap = 0;
-        const size_t cap = slot * (size_t)world * 3 / 2 + 4096;
-        if (ok(hipMalloc(&B.d_wireS, cap / world + 4096), "hipMalloc(wire block)") && ok(hipMalloc(&B.d_wireAll, cap), "hipMalloc(wire blocks)") &&
-            ok(hipHostMalloc((void **)&B.h_wireAll, cap, hipHostMallocDefault), "hipHostMalloc(wire blocks)"))
+        B.d_wireS = nullptr; B.d_wireAll = nullptr; B.h_wireAll = nullptr; B.wireCap = 0; B.wireSCap = 0;
+        const size_t capS = slot * 3 / 2 + 4096, cap = std::max(capS * (size_t)world, B.wireCap);
+        if (ok(hipMalloc(&B.d_wireS, capS), "hipMalloc(wire block)") && ok(hipMalloc(&B.d_wireAll, cap), "hipMalloc(wire blocks)") &&
+            ok(hipHostMalloc((void **)&B.h_wireAll, cap, hipHostMallocDefault), "hipHostMalloc(wire blocks)")) {
             B.wireCap = cap;
+            B.wireSCap = capS;
+        }
     }
     (void)xs;
     return shard_growth_handshake(m, rc);
@@ -1201,10 +1208,13 @@ static int shard_submit(pais_mvs *m, pais_mvs::ShardXfer &X, pais_mvs::ShardBufs
     X.slot = kWireHeader + X.WB * (size_t)X.per;
     X.t0 = now_ms();
     int rc = shard_ensure(m, B, (size_t)X.per, X.slot);
-    if (rc) { X.open = false; return rc; }
-    MHIP(hipSetDevice(m->device));
+    if (rc) { X.open = false; return rc; } // (agreed on by every rank: shard_growth_handshake)
+    // (from here on a local failure must not keep this rank out of the collective -- the others would wait in it for ever: it
+    //  travels in the status header of the rank's block and fails every rank together)
+    const hipError_t sd = hipSetDevice(m->device);
     if (m->emuMode == 2 && (rc = emu_fill_blocks(m, X)) != 0) { X.open = false; return rc; }
     shard_refine_enqueue(m, X);
+    if (sd != hipSuccess && !X.localRc) { X.localRc = -2; g_mvs_err = std::string("hipSetDevice: ") + hipGetErrorString(sd); }
     rc = shard_exchange(m, X);
     if (rc) X.open = false;
     return rc;
@@ -2031,7 +2041,7 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         // large round: streamed (see pais_mvs::lane1) -- on one GPU, and (round 4) on the sharded path: each part is a sharded
         // batch of its own, the two exchanges enqueued on the driver's stream in part order (shard_submit / shard_finish)
         const bool oneGpu = m->ctx && m->world <= 1 && !m->nccl && !m->gatherCb && m->emuMode != 2;
-        const bool shardStream = sharded_transport(m) && m->streamSharded;
+        const bool shardStream = sharded_transport(m) && (m->streamSharded == 1 || (m->streamSharded < 0 && m->emuMode == 2));
         const bool timingSaysStream = m->streamRounds == 1 && m->prevHostMs >= m->streamHostMs && m->prevHostMs >= m->streamHostShare * m->prevGpuMs;
         m->streamWish = timingSaysStream; // (travels in this rank's header with the next sharded batch)
         const bool canStream = (oneGpu || shardStream) && m->emuMode != 1 &&
@@ -2077,7 +2087,9 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
             if (p == 0) return m->ctx;
             while ((int)m->partLanes.size() < p) {
                 pais_ctx *l = nullptr;
-                if (pais_ctx_fork_lane(m->ctx, &l)) { g_mvs_err = pais_last_error(); return nullptr; }
+                // (a rank that cannot fork a lane must still take part in the part's collective: it refines the part on the
+                //  driver's own context -- same records, no overlap)
+                if (pais_ctx_fork_lane(m->ctx, &l)) return m->ctx;
                 m->partLanes.push_back(l);
             }
             return m->partLanes[p - 1];

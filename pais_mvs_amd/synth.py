@@ -244,8 +244,12 @@ def _make_seeds(obj: SolidOfRevolution, cams: List[Camera], n_seeds: int, rng: n
 
 def pawn_scene(width: int = 640, height: int = 480, n_seeds: int = 200, lod_ratio: float = 0.8,
                cfg_max_lod: int = 15, tex_seed: int = 1234, seed_seed: int = 5678,
-               build_edges: bool = True) -> Scene:
-    """Configs 0/1 of BASELINE.json: the 5 README cameras around a textured pawn-like solid."""
+               build_edges: bool = True, tex_std: float = 34.0, tex_lam=(7.0, 40.0)) -> Scene:
+    """Configs 0/1 of BASELINE.json: the 5 README cameras around a textured pawn-like solid.
+    tex_std / tex_lam: grey-level standard deviation and wavelength range (pixels at the object) of the surface texture.  The
+    defaults give every 31 x 31 window far more variance than MvsConfig.textureVariation, so setLOD (patch.cpp:511-610) stays at
+    level 0; a faint, long-wave texture (e.g. tex_std 9, tex_lam (40, 260)) makes it climb the pyramid -- the LOW-TEXTURE variant
+    of the parity tests (LOD >= 1 end to end)."""
     specs = []
     for name, f, q, C, rad in PAWN_NVM:
         R = quaternion_to_rotation(q)
@@ -265,7 +269,7 @@ def pawn_scene(width: int = 640, height: int = 480, n_seeds: int = 200, lod_rati
              Ellipsoid(0.13 * sc, 0.08 * sc, 0.08 * sc)]
     rng = np.random.default_rng(tex_seed)
     px = depth / 614.0 * (640.0 / width)   # world size of one pixel at the object
-    k, phi, amp = make_texture(rng, 32, 7 * px, 40 * px, 34.0)
+    k, phi, amp = make_texture(rng, 32, tex_lam[0] * px, tex_lam[1] * px, tex_std)
     obj = SolidOfRevolution(X0, up, parts, k, phi, amp)
     cams: List[Camera] = []
     s = width / 640.0

@@ -41,6 +41,47 @@ def workload(scene_name, seeds, device=None):
     raise SystemExit("unknown scene")
 
 
+def literal(a):
+    """VERDICT r4 item 1 (a) + (c) at cloud level.  north_star's sentence is about output CLOUDS; the reference's arithmetic is the
+    oracle's literal mode.  Five reconstructions of the same workload: literal, literal with the window sums accumulated y outer
+    (variant 2), literal with contracted multiply-adds (variant 4), both (6) -- what another loop order / another compiler would
+    make of the reference's own source -- and kernel arithmetic (= the HIP path's cloud bit for bit: its hash is checked against the committed golden)."""
+    from pais_mvs_amd import cloudcmp
+    from pais_mvs_amd.mvs import patches_sha1
+    from tests import common
+    cfg, scene = workload(a.scene, a.seeds, a.device)
+    runs = {}
+    for name, ka, var in (("literal", False, 0), ("literal_y_outer", False, 2), ("literal_contracted", False, 4),
+                          ("literal_y_outer_contracted", False, 6), ("kernel", True, 0)):
+        t0 = time.time()
+        rows, calls, acc, spec, cloud, radius = common.oracle_reconstruct(cfg, scene, a.B, a.max_rounds, parallel=True, kernel_arithmetic=ka,
+                                                                          literal_variant=var, with_cloud=True)
+        runs[name] = {"rows": rows, "cloud": cloud, "refines": int(calls), "accepted": int(acc), "speculative": int(spec),
+                      "sha1": patches_sha1(rows), "seconds": round(time.time() - t0, 1), "radius": radius}
+        print(name, runs[name]["refines"], runs[name]["accepted"], runs[name]["sha1"], runs[name]["seconds"], flush=True)
+    tag = "%s%s" % (a.scene, ("_r%d" % a.max_rounds) if a.max_rounds else "")
+    gold_path = os.path.join(a.out_dir, "bench_cloud_%s.json" % tag)
+    if os.path.exists(gold_path):
+        gold = json.load(open(gold_path))
+        assert gold["cloud_sha1"] == runs["kernel"]["sha1"], "kernel-arithmetic cloud differs from the committed golden"
+    L = runs["literal"]
+    radius = L["radius"]
+    masks = {k: cloudcmp.camera_masks([r[2] for r in v["rows"]]) for k, v in runs.items()}
+    summary = {"scene": a.scene, "seeds": len(scene.seeds), "parents_per_round": a.B, "max_rounds": a.max_rounds, "pso_seed": 42,
+               "neighbor_radius": radius,
+               "runs": {k: {x: v[x] for x in ("refines", "accepted", "speculative", "sha1", "seconds")} for k, v in runs.items()},
+               "surface_error": {k: cloudcmp.surface_error(scene, v["cloud"], [r[2][0] for r in v["rows"]]) for k, v in runs.items()},
+               "vs_literal": {k: cloudcmp.cloud_metrics(v["cloud"], L["cloud"], radius, masks[k], masks["literal"])
+                              for k, v in runs.items() if k != "literal"},
+               "made_by": "tests/golden/make_bench_golden.py --literal (oracle; literal = the reference's statements, platform libm)"}
+    cloudcmp.save_compact(os.path.join(a.out_dir, "bench_cloud_%s_literal.npz" % tag), L["cloud"], [r[2] for r in L["rows"]],
+                          {"scene": a.scene, "accepted": L["accepted"], "refines": L["refines"], "sha1": L["sha1"], "neighbor_radius": radius})
+    with open(os.path.join(a.out_dir, "bench_cloud_%s_literal.json" % tag), "w") as f:
+        json.dump(summary, f, indent=1)
+        f.write("\n")
+    print(json.dumps(summary, indent=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="pawn")
@@ -49,7 +90,12 @@ def main():
     ap.add_argument("--max-rounds", type=int, default=0)
     ap.add_argument("--device", type=int, default=None)
     ap.add_argument("--out-dir", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--literal", action="store_true",
+                    help="the cloud of the oracle in LITERAL arithmetic (the reference's statements, platform libm) as a compact fixture "
+                         "(bench_cloud_<scene>_literal.npz) + the cloud-level CONTROL: literal vs its perturbed variants vs kernel arithmetic")
     a = ap.parse_args()
+    if a.literal:
+        return literal(a)
     from pais_mvs_amd.mvs import patches_sha1
     from tests import common
     cfg, scene = workload(a.scene, a.seeds, a.device)

@@ -19,7 +19,8 @@ def _declared(header):
 def test_library_exports_every_declared_symbol():
     from pais_mvs_amd import _lib
     L = _lib.load()
-    names = _declared("pais_hip.h") + _declared("pais_mvs.h") + _declared("pais_io.h") + _declared("pais_pyramid.h")
+    names = (_declared("pais_hip.h") + _declared("pais_mvs.h") + _declared("pais_io.h") + _declared("pais_pyramid.h") +
+             _declared("pais_seed.h") + _declared("pais_test_hooks.h"))
     assert len(names) >= 30
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing

@@ -200,6 +200,60 @@ def test_refine_against_literal_arithmetic_dome_radius25(dome_small):
     _literal_gate(cfg, dome_small, 400, DOME_BRANCHED_CAP, "dome")
 
 
+def test_low_texture_scene_runs_the_upper_pyramid_levels_end_to_end(pawn_lowtex):
+    """R4 / F2 at LOD >= 1 without a hand-bumped level: seeds + expansion rounds of the low-texture pawn
+    through the driver against the oracle, patch for patch and bit for bit; a sizeable share of the accepted patches sits on
+    levels 1 and 2.  Then the literal gate on the same scene, reported by level."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.mvs import MVS
+    from tests.test_oracle_modes import refine_pairs, mode_statistics, LOWTEX_BRANCHED_CAP
+    cfg = readme_config()
+    rows, calls, acc, spec = common.oracle_reconstruct(cfg, pawn_lowtex, 16, 14, parallel=True)
+    S = common.oracle_scene(cfg, pawn_lowtex)
+    m = MVS(cfg, pawn_lowtex.cameras, device=0, seed=42)
+    for X, vis in pawn_lowtex.seeds:
+        m.add_seed(X, vis)
+    m.refineSeedPatches()
+    m.expansionPatches(16, 14)
+    ps = m.patches()
+    got = [(list(p.center[:]), list(p.normalS[:]), p.cams(), p.fitness, p.correlation) for p in ps]
+    assert len(got) == len(rows) >= 40, (len(got), len(rows))
+    for i, (a, b) in enumerate(zip(got, rows)):
+        assert a == b, (i, a, b)
+    lods = [p.lod for p in ps]
+    upper = sum(1 for l in lods if l >= 1)
+    print("\nlow-texture pawn: %d accepted, by LOD %s" % (len(lods), {l: lods.count(l) for l in sorted(set(lods))}))
+    assert upper >= len(lods) // 5 and max(lods) >= 2, lods
+    m.close()
+    # literal gate, per candidate (seeds + first-ring children), HIP records == kernel arithmetic bit for bit
+    ctx = _ctx(cfg, pawn_lowtex)
+    S.set_omp(True)
+
+    def gpu(seeds_in, child_in):
+        from pais_mvs_amd.context import make_candidate
+        cands = [make_candidate(cen, nrm, cams, key, 0, normalS=ns) for cen, nrm, ns, cams, key in seeds_in]
+        for cen, nrm, cams, key in child_in:
+            child = S.expand_patch(cen, nrm, cams, key)
+            cands.append(make_candidate(child.center[:], child.normal[:], child.cams(), key, 1, normalS=child.normalS[:]))
+        return list(ctx.refine_batch(cands))
+
+    lit, ker, hip = refine_pairs(S, pawn_lowtex, cfg, run_b=gpu)
+    st = mode_statistics(lit, ker, hip=hip)
+    by_lod = {}
+    for a, b in zip(lit, ker):
+        if a.drop or b.drop:
+            continue
+        t = by_lod.setdefault(int(a.LOD), [0, 0])
+        t[0] += 1
+        t[1] += int(not (a.psoSig == b.psoSig and a.psoRuns == b.psoRuns and a.psoIters == b.psoIters))
+    print("low-texture pawn, HIP vs literal:", st, "by LOD (n, branched):", by_lod)
+    assert st["set_mismatch"] == 0 and st["same_centre_max"] <= 1e-12 and st["same_normal_max"] <= 1e-12, st
+    assert sum(v[0] for k, v in by_lod.items() if k >= 1) >= 30, by_lod
+    assert st["branched"] <= LOWTEX_BRANCHED_CAP, st
+    ctx.close()
+
+
 def test_expand_candidates_match_oracle(pawn_small):
     """Children of refined seeds: MVS::expandCell (mvs.cpp:566-577) per candidate."""
     from oracle import po
@@ -1389,21 +1443,10 @@ def test_literal_gate_on_expansion_candidates_of_the_bench_workload(capsys):
     m.close()
     nk = len(kept_c)
     assert nk >= 1200 and rnd >= 26, (nk, rnd)
-    S = common.oracle_scene(cfg, scene)
-    Lo = po.lib()
-    MAXV = 64
-    cs = (C.c_double * (3 * nk))(*[v for c in kept_c for v in c.center[:]])
-    ns = (C.c_double * (3 * nk))(*[v for c in kept_c for v in c.normal[:]])
-    nc = (C.c_int * nk)(*[c.num_cam for c in kept_c])
-    ci = (C.c_int * (MAXV * nk))(*[v for c in kept_c for v in (list(c.cam_idx[:c.num_cam]) + [0] * MAXV)[:MAXV]])
-    ks = (C.c_uint64 * nk)(*[c.key for c in kept_c])
-    runs = {}
-    for mode in (False, True):
-        S.set_kernel_arithmetic(mode)
-        outp = (po.Patch * nk)()
-        Lo.po_expand_candidates_parallel(S.ptr, outp, nk, cs, ns, nc, ci, ks)
-        runs[mode] = list(outp)
-    lit, ker = runs[False], runs[True]
+    # the candidates refined again on the box's host cores: literal, the four perturbed literal arithmetics (the CONTROL:
+    # tests/test_cloud_parity.py), kernel arithmetic
+    ctl, runs = common.literal_control(cfg, scene, kept_c)
+    lit, ker = runs[0], runs["kernel"]
     st = mode_statistics(lit, ker, hip=kept_r)          # (asserts HIP == kernel arithmetic bit for bit)
     # branched candidates by LOD and by visible-camera count of the literal result
     by_lod, by_k = {}, {}
@@ -1424,18 +1467,30 @@ def test_literal_gate_on_expansion_candidates_of_the_bench_workload(capsys):
            "branched_centre_max": st["branched_centre_max"], "branched_normal_max": st["branched_normal_max"],
            "set_mismatch_on_the_same_trajectory": mismatch_same, "set_mismatch_among_branched": mismatch_branched,
            "by_lod": {str(k): {"n": v[0], "branched": v[1]} for k, v in sorted(by_lod.items())},
-           "by_num_cam": {str(k): {"n": v[0], "branched": v[1]} for k, v in sorted(by_k.items())}}
+           "by_num_cam": {str(k): {"n": v[0], "branched": v[1]} for k, v in sorted(by_k.items())},
+           "control": {k: {"branched": v["branched"], "beyond_1e-4": v["beyond_1e-4"], "set_mismatch_among_branched": v["set_mismatch_among_branched"]}
+                       for k, v in ctl.items() if k != "overlap"}, "control_overlap": ctl["overlap"]}
     with capsys.disabled():
         print("\nliteral gate, bench workload rounds 5..25:", json.dumps(rep))
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "literal_gate_bench_workload.json"), "w") as f:
         json.dump(rep, f, indent=1)
-    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "literal_gate_bench_workload.json")))
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = json.load(open(os.path.join(gdir, "literal_gate_bench_workload.json")))
+    gctl = json.load(open(os.path.join(gdir, "literal_control_bench_workload.json")))
     assert st["n"] >= 1000 and mismatch_same == 0, (st, mismatch_same)       # discrete outputs identical wherever they CAN be compared
     assert st["same_centre_max"] <= 1e-12 and st["same_normal_max"] <= 1e-12, st
     assert st["same_trajectory"] + st["branched"] == st["n"]
-    # the chaos of an unconverged, tie-ridden optimiser, counted (no tolerance absorbs it; the reference's own two runs differ
-    # the same way): hard caps = measured + margin, committed next to the measured figures
-    assert st["branched"] <= gold["branched_cap"], (st["branched"], gold["branched_cap"])
-    assert mismatch_branched <= gold["set_mismatch_among_branched_cap"], mismatch_branched
-    S.close()
+    # DRIFT: the run is deterministic (HIP == kernel arithmetic bit for bit; the literal side is this image's
+    # libm), so the figures bench.py prints from the committed file must be THE figures -- a change of two candidates fails
+    assert st["n"] == gold["candidates"], (st["n"], gold["candidates"])
+    assert abs(st["branched"] - gold["branched"]) <= 2, (st["branched"], gold["branched"])
+    assert abs(mismatch_branched - gold["set_mismatch_among_branched"]) <= 1, mismatch_branched
+    for k in ("variant_1", "variant_2", "variant_4", "variant_6"):
+        assert abs(ctl[k]["branched"] - gctl[k]["branched"]) <= 2, (k, ctl[k]["branched"], gctl[k]["branched"])
+    # PARITY (weak 1): the cap is not "measured + 10" but the CONTROL -- what the reference's own source branches under another
+    # loop order and another compiler (variant 6) -- times a margin (tests/test_cloud_parity.py)
+    from tests.test_cloud_parity import BRANCH_FACTOR_OVER_CONTROL
+    assert st["branched"] <= BRANCH_FACTOR_OVER_CONTROL * ctl["variant_6"]["branched"], (st["branched"], ctl["variant_6"]["branched"])
+    assert ctl["kernel"]["beyond_1e-4"] <= BRANCH_FACTOR_OVER_CONTROL * ctl["variant_6"]["beyond_1e-4"]
+    assert mismatch_branched <= ctl["variant_6"]["set_mismatch_among_branched"] + 1

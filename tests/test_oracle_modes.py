@@ -26,6 +26,7 @@ from tests import common
 PAWN_BRANCHED_CAP = 23 + 2
 RING_BRANCHED_CAP = 0 + 2
 DOME_BRANCHED_CAP = 0 + 2
+LOWTEX_BRANCHED_CAP = 21 + 2      # low-texture pawn (conftest.pawn_lowtex): 165 candidates, 84 of them at LOD 1..3
 
 
 def test_cost_modes_agree_to_rounding(pawn_small):
@@ -189,3 +190,20 @@ def test_refine_modes_many_cameras(ring_small):
     st = mode_statistics(lit, ker)
     print("\nliteral vs kernel arithmetic, ring:", st)
     assert_north_star_parity(st, 400, RING_BRANCHED_CAP)
+
+
+def test_refine_modes_low_texture_upper_levels(pawn_lowtex):
+    """The same comparison where setLOD climbs the pyramid (faint long-wave texture): 165 candidates, 37 / 39 / 8 of them at
+    LOD 1 / 2 / 3 -- upper levels, scaled homographies and level-dependent taps in both arithmetics; measured 21 branched
+    (12 at LOD 0, 8 at LOD 1, 1 at LOD 2), every discrete output identical, centres identical and normals within one ulp on
+    the literal trajectory."""
+    from pais_mvs_amd.config import readme_config
+    cfg = readme_config()
+    S = common.oracle_scene(cfg, pawn_lowtex)
+    S.set_omp(True)
+    lit, ker = refine_pairs(S, pawn_lowtex, cfg)
+    st = mode_statistics(lit, ker)
+    upper = sum(1 for a in lit if not a.drop and a.LOD >= 1)
+    print("\nliteral vs kernel arithmetic, low-texture pawn:", st, "candidates at LOD >= 1:", upper)
+    assert upper >= 60, upper
+    assert_north_star_parity(st, 120, LOWTEX_BRANCHED_CAP)
