@@ -339,7 +339,7 @@ def main():
             if (lj["seeds"], lj["parents_per_round"]) == (len(scene.seeds), B):
                 ps = m.patches()
                 mine = m.cloud()
-                met = cloudcmp.cloud_metrics(mine, lit, m.neighbor_radius(), cloudcmp.camera_masks([p.cams() for p in ps]), lmasks)
+                met = cloudcmp.cloud_metrics(mine, lit, lmeta["neighbor_radius"], cloudcmp.camera_masks([p.cams() for p in ps]), lmasks)
                 sides = ("a_to_b", "b_to_a")
                 ctl = {k: v for k, v in lj["vs_literal"].items() if k != "kernel"}
                 cloud_vs_literal = {

@@ -453,7 +453,15 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     for (int i = 0; i < 3; ++i) center[i] = ep->ray[i] * depth + ep->Cref[i]; // :944
     const int M = ep->M, K = ep->K;
     const double s = ep->lodScale;
+#if defined(PAIS_EXP_DUP) && PAIS_EXP_DUP == 7
+    for (int rep = 0; rep < 2; ++rep) // (measurement build: the normal and the homographies twice, scripts/dup_profile.sh)
+#endif
     {
+#if defined(PAIS_EXP_DUP) && PAIS_EXP_DUP == 7
+        asm volatile("" : "+v"(theta));
+        wave_spherical2normal(theta, phi, n, lane);
+        for (int i = 0; i < 3; ++i) center[i] = ep->ray[i] * depth + ep->Cref[i];
+#endif
         const double d = -dot3(center, n);
         double Mref[9], invH[9], kr[9], kt[3];
         for (int i = 0; i < 9; ++i) kr[i] = ep->KRref[i];

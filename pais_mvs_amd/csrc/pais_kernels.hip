@@ -866,6 +866,112 @@ __device__ __forceinline__ int wave_argmin_lex_n(bool valid, double key, int tie
     return __builtin_amdgcn_readfirstlane(v ? t : -1);
 }
 
+// MEASUREMENT BUILDS ONLY (scripts/dup_profile.sh): PAIS_EXP_DUP = 1 ... 6 executes one component of k_pso_iter TWICE -- 1 the
+// moveParticles selections / 2 the gBest scan + convergence sums / 3 the cost evaluation / 4 the four uniforms / 5 ranks + local
+// best / 6 the three fitness-distance-ratio selections -- with identical results, so that the
+// slowdown of the whole reconstruction is that component's share of the critical path (a cycle counter inside one wave is not:
+// DESIGN 4.4).  The library is built with 0.
+#ifndef PAIS_EXP_DUP
+#define PAIS_EXP_DUP 0
+#endif
+__device__ __forceinline__ void exp_opaque(double &v) { asm volatile("" : "+v"(v)); }
+
+// ---- lane-parallel forms of the step replay's serial scans (round 5; swarm of N <= 32 particles in lanes 0 .. N-1) ----------
+// profiles/r05_dup_profile.txt: the replay's selections are 6.7 ms of the 80 ms pawn reconstruction's critical path (the
+// moveParticles selections 3.9 ms, the gBest scan + convergence sums 2.8 ms), and the ISA shows why -- every `for (j < N)` over
+// lane_get(v, j) is a loop of v_readlane_b32 with an SGPR lane index under exec-mask loop control (N came from a vector load),
+// ~200 cycles per trip for one wave alone on its SIMD.  Below, each scan is a fixed number of DPP exchanges inside a 16-lane
+// row (ordinary VALU moves with a lane-permuting operand modifier: no SGPR round trip, no loop, no branch), one crossbar
+// exchange between rows 0 and 1 when N > 16.  Selections only -- every VALUE that is stored is produced by the same
+// operation sequence as before, so the records are the same bits (the goldens and the parity suite did not move).
+template <int CTRL> __device__ __forceinline__ double dpp_mov_d(double v)
+{
+    return __hiloint2double(dpp_mov_i<CTRL>(__double2hiint(v)), dpp_mov_i<CTRL>(__double2loint(v)));
+}
+// a permutation in which every lane has a source (rotations, mirrors): no `old` operand, so no copy in front of the move
+template <int CTRL> __device__ __forceinline__ int dpp_get_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ double dpp_get_d(double v)
+{
+    return __hiloint2double(dpp_get_i<CTRL>(__double2hiint(v)), dpp_get_i<CTRL>(__double2loint(v)));
+}
+// the butterfly of wave_argmin_lex_n as a plain sum: every lane of row 0 ends with the sum over lanes 0 .. 15 (N <= 16) or
+// 0 .. 31 (rows 0 and 1).  The association order differs from lane to lane -- callers use lane 0's value (readfirstlane).
+__device__ __forceinline__ double swarm_sum_fast(double v, int N)
+{
+    if (N > 16) v += __shfl_xor(v, 16, 64);
+    v += dpp_get_d<0x140>(v); // row_mirror
+    v += dpp_get_d<0x141>(v); // row_half_mirror
+    v += dpp_get_d<0x1B>(v);  // quad_perm [3, 2, 1, 0]
+    v += dpp_get_d<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+    return lane_get(v, 0);
+}
+// `mean of 3 N terms < 0.01` (getDispersionIDX / getVelocityIDX, psosolver.cpp:70-92, 293-297) where the reference adds the
+// terms one after the other.  t0, t1, t2: this lane's three terms (lanes >= N: anything).  A tree sum of the same terms differs
+// from the sequential sum by < 3 N ulp (~1e-14 relative); when it is farther than 1e-9 from the threshold the comparison cannot
+// depend on the order, otherwise (never seen) the sequential sum decides -- the decision is the reference's in every case.
+__device__ __forceinline__ bool swarm_mean_below(double t0, double t1, double t2, int lane, int N)
+{
+    const double own = lane < N ? (t0 + t1) + t2 : 0.0;
+    const double fast = swarm_sum_fast(own, N) / (double)(3 * N);
+    if (fabs(fast - 0.01) > 1e-9) return fast < 0.01;
+    double s = 0;
+    for (int j = 0; j < N; ++j) {
+        s += lane_get(t0, j);
+        s += lane_get(t1, j);
+        s += lane_get(t2, j);
+    }
+    s /= (double)(3 * N);
+    return s < 0.01;
+}
+// updateGbest (psosolver.cpp:137-149): `for j: if (pBestFitness[j] <= gBestFitness) { gBestFitness = ...; gBest = j }` -- the
+// scan ends at the LAST index of the swarm's minimum if that minimum is <= the incoming gBestFitness, and leaves (gf, g) alone
+// otherwise (a NaN never satisfies `<=`, on either side).
+__device__ __forceinline__ void swarm_update_gbest(double pbf, int lane, int N, double &gf, int &g)
+{
+    const int w = wave_argmin_lex_n(lane < N && pbf == pbf, pbf, 63 - lane, N);
+    const int j = 63 - (w < 0 ? 63 : w);
+    const double m = lane_get(pbf, j);
+    if (w >= 0 && m <= gf) {
+        gf = m;
+        g = j;
+    }
+}
+// rank(lane) = #{ j < N : d_j < d_lane or (d_j == d_lane and j < lane) } -- getLocalBest's stable sort position
+// (psosolver.cpp:151-191) -- by rotating the distances through the 16-lane row (row_ror:n, n = 1 .. 15: every other lane of the
+// row exactly once).  The source lane's index travels with its value, so the tie-break does not rest on the direction of the
+// rotation.  Lanes N .. 31 must hold DBL_MAX.
+template <int n> __device__ __forceinline__ int rank_ror(double dj, int lane)
+{
+    const double o = dpp_get_d<0x120 + n>(dj);
+    const int j = dpp_get_i<0x120 + n>(lane);
+    return (o < dj || (o == dj && j < lane)) ? 1 : 0;
+}
+template <int n> __device__ __forceinline__ int rank_ror_other(double dj, double od, bool hiRow)
+{
+    const double o = dpp_get_d<0x120 + n>(od);
+    return (o < dj || (o == dj && hiRow)) ? 1 : 0;
+}
+__device__ __forceinline__ int swarm_rank(double dj, int lane, int N)
+{
+    int rank = 0;
+    rank += rank_ror<1>(dj, lane);  rank += rank_ror<2>(dj, lane);  rank += rank_ror<3>(dj, lane);  rank += rank_ror<4>(dj, lane);
+    rank += rank_ror<5>(dj, lane);  rank += rank_ror<6>(dj, lane);  rank += rank_ror<7>(dj, lane);  rank += rank_ror<8>(dj, lane);
+    rank += rank_ror<9>(dj, lane);  rank += rank_ror<10>(dj, lane); rank += rank_ror<11>(dj, lane); rank += rank_ror<12>(dj, lane);
+    rank += rank_ror<13>(dj, lane); rank += rank_ror<14>(dj, lane); rank += rank_ror<15>(dj, lane);
+    if (N > 16) { // the other row's sixteen (rows 0 and 1 exchanged through the crossbar): every one of them precedes a lane of
+                  // row 1, none a lane of row 0
+        const double od = __shfl_xor(dj, 16, 64);
+        const bool hiRow = (lane & 16) != 0;
+        rank += (od < dj || (od == dj && hiRow)) ? 1 : 0;
+        rank += rank_ror_other<1>(dj, od, hiRow);  rank += rank_ror_other<2>(dj, od, hiRow);  rank += rank_ror_other<3>(dj, od, hiRow);
+        rank += rank_ror_other<4>(dj, od, hiRow);  rank += rank_ror_other<5>(dj, od, hiRow);  rank += rank_ror_other<6>(dj, od, hiRow);
+        rank += rank_ror_other<7>(dj, od, hiRow);  rank += rank_ror_other<8>(dj, od, hiRow);  rank += rank_ror_other<9>(dj, od, hiRow);
+        rank += rank_ror_other<10>(dj, od, hiRow); rank += rank_ror_other<11>(dj, od, hiRow); rank += rank_ror_other<12>(dj, od, hiRow);
+        rank += rank_ror_other<13>(dj, od, hiRow); rank += rank_ror_other<14>(dj, od, hiRow); rank += rank_ror_other<15>(dj, od, hiRow);
+    }
+    return rank;
+}
+
 // moveParticles for particle i with the swarm in lanes (lane j = particle j, N <= 64): same selections as
 // pso_move_particle (pais_dev.hpp), evaluated across lanes
 __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw, const double *u, const double *pos,
@@ -880,25 +986,47 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
     // getLocalBest: the localK nearest pBests by (squared distance, index); among them the first strict minimum
     // of pBestFitness in selection order
     double dj;
-    if (lane == i) {
-        dj = DBL_MAX;
-    } else {
+    {
         const double d0 = pp0 - pb[0], d1 = pp1 - pb[1], d2 = pp2 - pb[2];
         dj = 0;
         dj += d0 * d0;
         dj += d1 * d1;
         dj += d2 * d2;
+        dj = (lane == i || !pv) ? DBL_MAX : dj; // (lanes beyond the swarm: behind every particle in every order)
     }
     int rank = 0;
-    for (int j = 0; j < N; ++j) {
-        const double o = lane_get(dj, j);
-        rank += (o < dj || (o == dj && j < lane)) ? 1 : 0;
+    if (N <= 32) {
+        rank = swarm_rank(dj, lane, N);
+    } else {
+        for (int j = 0; j < N; ++j) {
+            const double o = lane_get(dj, j);
+            rank += (o < dj || (o == dj && j < lane)) ? 1 : 0;
+        }
     }
+#if PAIS_EXP_DUP == 5
+    {
+        double dj2 = dj;
+        exp_opaque(dj2);
+        int rank2 = swarm_rank(dj2, lane, N);
+        const int w2 = wave_argmin_lex_n(pv && rank2 < localK && pbf < DBL_MAX, pbf, rank2 * 64 + lane, N);
+        asm volatile("" ::"s"(w2));
+    }
+#endif
     const bool sel = pv && rank < localK;
     const int w = wave_argmin_lex_n(sel && pbf < DBL_MAX, pbf, rank * 64 + lane, N);
     const int lIdx = (w < 0) ? i : (w & 63);
     // setNearNeighborBest: per dimension the first maximum of the fitness-distance ratio
     const double fitI = lane_get(fitj, i);
+#if PAIS_EXP_DUP == 6
+    for (int d = 0; d < 3; ++d) {
+        double pd = lane_get(pos[d], i);
+        exp_opaque(pd);
+        const double FDR = (fitI - pbf) / fabs(pd - pb[d]);
+        const int wn = wave_argmin_lex_n(pv && lane != i && FDR > -DBL_MAX, -FDR, lane, N);
+        double o = lane_get(pb[d], wn < 0 ? 0 : wn);
+        exp_opaque(o);
+    }
+#endif
     for (int d = 0; d < 3; ++d) {
         const double pd = lane_get(pos[d], i);
         const double FDR = (fitI - pbf) / fabs(pd - pb[d]);
@@ -918,15 +1046,6 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
         outP[d] = p;
     }
 }
-
-// MEASUREMENT BUILDS ONLY (scripts/dup_profile.sh): PAIS_EXP_DUP = 1 / 2 / 3 executes one component of k_pso_iter TWICE -- the
-// moveParticles selections / the gBest scan + convergence sums / the cost evaluation -- with identical results, so that the
-// slowdown of the whole reconstruction is that component's share of the critical path (a cycle counter inside one wave is not:
-// DESIGN 4.4).  The library is built with 0.
-#ifndef PAIS_EXP_DUP
-#define PAIS_EXP_DUP 0
-#endif
-__device__ __forceinline__ void exp_opaque(double &v) { asm volatile("" : "+v"(v)); }
 
 // launch L = 0: cost of the initial swarm.  L >= 1: step (L-1) + cost of the moved particle.  finishOnly: one
 // wave per candidate that only replays the step (the launch after the last possible iteration: every run ends).
@@ -971,13 +1090,19 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
         PsoArrays Wb = pso_arrays((unsigned char *)hd, Nmax, L & 1);
         PsoArrays Rb = pso_arrays((unsigned char *)hd, Nmax, (L > 0 ? L - 1 : 0) & 1);
         const int jl = lane < Nmax ? lane : 0;
-        const int active = hd->active, N = hd->N, maxIt = hd->maxIt;
-        const PsoState::IterDyn dr = hd->dyn[(L > 0 ? L - 1 : 0) & 1];
+        // (wave-uniform by construction -- every lane loads the same word; said so, or the compiler keeps them in VGPRs and
+        //  runs every loop over them under exec-mask control)
+        const int active = __builtin_amdgcn_readfirstlane(hd->active), N = __builtin_amdgcn_readfirstlane(hd->N),
+                  maxIt = __builtin_amdgcn_readfirstlane(hd->maxIt);
+        PsoState::IterDyn dr = hd->dyn[(L > 0 ? L - 1 : 0) & 1];
+        dr.started = __builtin_amdgcn_readfirstlane(dr.started);
+        dr.iteration = __builtin_amdgcn_readfirstlane(dr.iteration);
+        dr.gIdx = __builtin_amdgcn_readfirstlane(dr.gIdx);
         // (what only moveParticles reads is requested here too: behind the convergence test it would be a second round trip)
         const double rl[3] = {hd->rangeL[0], hd->rangeL[1], hd->rangeL[2]};
         const double ru[3] = {hd->rangeU[0], hd->rangeU[1], hd->rangeU[2]};
         const uint64_t streamBase = hd->streamBase;
-        const int runIdx = hd->run, localK = hd->localK;
+        const int runIdx = __builtin_amdgcn_readfirstlane(hd->run), localK = __builtin_amdgcn_readfirstlane(hd->localK);
         double pos[3], pb[3];
         for (int d = 0; d < 3; ++d) {
             pos[d] = Rb.pos[jl][d];
@@ -1031,29 +1156,28 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
                 it = dr.iteration + 1;
             }
 #if PAIS_EXP_DUP == 2
-            { // the scan and the convergence sums once more (idempotent), inputs opaque
+            { // the scan and the dispersion test once more (idempotent), inputs opaque
                 double pbf2 = pbf, gf2 = gf;
                 exp_opaque(pbf2);
                 int g2 = g;
-                for (int j = 0; j < N; ++j) {
-                    const double v = lane_get(pbf2, j);
-                    if (v <= gf2) { gf2 = v; g2 = j; }
-                }
-                double q0 = pos[0], q1 = pos[1], q2 = pos[2];
+                swarm_update_gbest(pbf2, lane, N, gf2, g2);
+                double q0 = pos[0];
                 exp_opaque(q0);
                 const double gB2[3] = {lane_get(pb[0], g2), lane_get(pb[1], g2), lane_get(pb[2], g2)};
-                const double a0 = fabs(q0 - gB2[0]), a1 = fabs(q1 - gB2[1]), a2 = fabs(q2 - gB2[2]);
-                double disp = 0;
-                for (int j = 0; j < N; ++j) { disp += lane_get(a0, j); disp += lane_get(a1, j); disp += lane_get(a2, j); }
-                exp_opaque(disp);
+                const bool b2 = swarm_mean_below(fabs(q0 - gB2[0]), fabs(pos[1] - gB2[1]), fabs(pos[2] - gB2[2]), lane, N);
+                asm volatile("" ::"s"((int)b2));
                 exp_opaque(gf2);
             }
 #endif
-            for (int j = 0; j < N; ++j) {
-                const double v = lane_get(pbf, j);
-                if (v <= gf) {
-                    gf = v;
-                    g = j;
+            if (N <= 32) {
+                swarm_update_gbest(pbf, lane, N, gf, g);
+            } else {
+                for (int j = 0; j < N; ++j) {
+                    const double v = lane_get(pbf, j);
+                    if (v <= gf) {
+                        gf = v;
+                        g = j;
+                    }
                 }
             }
             const double gB[3] = {lane_get(pb[0], g), lane_get(pb[1], g), lane_get(pb[2], g)};
@@ -1061,23 +1185,33 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
             bool finished = it >= maxIt;
             if (!finished) {
                 const double a0 = fabs(pos[0] - gB[0]), a1 = fabs(pos[1] - gB[1]), a2 = fabs(pos[2] - gB[2]);
-                double disp = 0;
-                for (int j = 0; j < N; ++j) {
-                    disp += lane_get(a0, j);
-                    disp += lane_get(a1, j);
-                    disp += lane_get(a2, j);
-                }
-                disp /= (double)(3 * N);
-                if (disp < 0.01) {
-                    const double v0 = fabs(Rb.vec[jl][0]), v1 = fabs(Rb.vec[jl][1]), v2 = fabs(Rb.vec[jl][2]);
-                    double vel = 0;
+                bool dispBelow;
+                if (N <= 32) {
+                    dispBelow = swarm_mean_below(a0, a1, a2, lane, N);
+                } else {
+                    double disp = 0;
                     for (int j = 0; j < N; ++j) {
-                        vel += lane_get(v0, j);
-                        vel += lane_get(v1, j);
-                        vel += lane_get(v2, j);
+                        disp += lane_get(a0, j);
+                        disp += lane_get(a1, j);
+                        disp += lane_get(a2, j);
                     }
-                    vel /= (double)(3 * N);
-                    finished = vel < 0.01;
+                    disp /= (double)(3 * N);
+                    dispBelow = disp < 0.01;
+                }
+                if (dispBelow) {
+                    const double v0 = fabs(Rb.vec[jl][0]), v1 = fabs(Rb.vec[jl][1]), v2 = fabs(Rb.vec[jl][2]);
+                    if (N <= 32) {
+                        finished = swarm_mean_below(v0, v1, v2, lane, N);
+                    } else {
+                        double vel = 0;
+                        for (int j = 0; j < N; ++j) {
+                            vel += lane_get(v0, j);
+                            vel += lane_get(v1, j);
+                            vel += lane_get(v2, j);
+                        }
+                        vel /= (double)(3 * N);
+                        finished = vel < 0.01;
+                    }
                 }
             }
             if (finished) {
@@ -1117,6 +1251,13 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
             double u[4];
             const uint32_t k0 = (uint32_t)(6 * N + 3 + 4 * (it * N + i));
             for (int q = 0; q < 4; ++q) u[q] = uniform_from(streamBase, (uint32_t)runIdx, k0 + q);
+#if PAIS_EXP_DUP == 4
+            {
+                uint32_t k2 = k0;
+                asm volatile("" : "+v"(k2));
+                for (int q = 0; q < 4; ++q) { double t = uniform_from(streamBase, (uint32_t)runIdx, k2 + q); exp_opaque(t); }
+            }
+#endif
             double nP[3], nV[3], nNb[3];
 #if PAIS_EXP_DUP == 1
             {
@@ -1982,7 +2123,8 @@ static hipError_t pso_tile_launch(const DevScene &sc, unsigned char *states, int
                                   const void *win, int stripSteps, unsigned long long *dbg, double *hscr, size_t hscrBytes, hipStream_t stream)
 {
     static LdsAttr attr;
-    const size_t lds = 160 * 1024, fixed = tile_fixed_lds_bytes(Kmax);
+    const size_t lds = ((160 * 1024) / TILE_WGS_PER_CU) & ~(size_t)1023, fixed = tile_fixed_lds_bytes(Kmax);
+    if (fixed + 4096 > lds) return hipErrorInvalidValue;
     hipError_t e = attr.ensure((const void *)k_pso_tile<NS, NP>, lds);
     if (e != hipSuccess) return e;
     const int groups = (Nmax + TILE_WAVES - 1) / TILE_WAVES;

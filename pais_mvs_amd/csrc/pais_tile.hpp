@@ -34,7 +34,12 @@
 //   * a camera whose tile does not fit the tile area any more (huge magnification): tapped from global memory.
 #pragma once
 
-#define TILE_WAVES 8
+#ifndef TILE_WAVES
+#define TILE_WAVES 8              // waves (= particles) of a workgroup
+#endif
+#ifndef TILE_WGS_PER_CU
+#define TILE_WGS_PER_CU 1         // workgroups that share a CU's 160 KB of LDS (each gets 160 / TILE_WGS_PER_CU KB)
+#endif
 #define TILE_MAX_CAMS PAIS_MAX_VIS // cameras of a candidate.  Two instantiations: NS = 2 pixels per lane, 16 camera pairs in registers
                                   // (M <= 32 tapped cameras); NS = 1, 32 pairs (M <= 64)
 #ifndef TILE_STRIP_STEPS

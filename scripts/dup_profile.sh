@@ -1,6 +1,6 @@
 #!/bin/bash
 # Slowdown profiling of the latency-bound PSO chain: the library against builds that execute ONE component of
-# k_pso_iter twice (-DPAIS_EXP_DUP=1 move selections / 2 gBest scan + convergence sums / 3 cost evaluation; same records).
+# k_pso_iter twice (-DPAIS_EXP_DUP=1 move selections | 2 gBest scan + dispersion test | 3 cost evaluation | 4 uniforms | 5 ranks + lBest | 6 FDR x3 | 7 normal + homographies; same records).
 # The slowdown of the pawn reconstruction is that component's share of the critical path.  On the GPU box:
 #   bash scripts/dup_profile.sh <tag>       (variants built beforehand into pais_mvs_amd/csrc/variants/libpais_dup{1,2,3}.so)
 out=gpurun_out/${1:-dup}; mkdir -p $out
@@ -19,7 +19,7 @@ PY
 run warm ""
 for i in 1 2; do
 run base_$i ""
-for d in 1 2 3; do run dup${d}_$i pais_mvs_amd/csrc/variants/libpais_dup$d.so; done
+for d in 1 2 3 4 5 6 7; do run dup${d}_$i pais_mvs_amd/csrc/variants/libpais_dup$d.so; done
 done
 } > $out/summary.txt 2>&1
 cat $out/summary.txt

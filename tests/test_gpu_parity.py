@@ -1331,7 +1331,8 @@ def test_seed_batches_and_device_pointer_batches_through_the_task_ring(pawn_smal
             monkeypatch.delenv(k, raising=False)
         return sha, st
     c0, st0 = cloud_rounds({"PAIS_STREAM_ROUNDS": "0"})
-    c1, st1 = cloud_rounds({"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_PARTS": "4"})
+    # (PAIS_STREAM_SHARDED=1: over a real communicator the streamed sharded rounds are opt-in until a run on >= 2 GPUs has been green)
+    c1, st1 = cloud_rounds({"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_PARTS": "4", "PAIS_STREAM_SHARDED": "1"})
     assert c0 == c1 and st0.rounds_streamed == 0 and st1.rounds_streamed > 0 and st1.batches_sharded > st0.batches_sharded
 
 
