@@ -143,16 +143,28 @@ PAIS_HD double det_exp_poly(double x)
     r = fma(-k, ln2LO, r);
     // Horner step q = q * r + c.  On the GPU the three-operand VOP3 form is forced: left alone the compiler emits
     // v_mov_b64 + v_fmac_f64 per step (the coefficients sit in VGPRs), i.e. 11 extra instructions per window pixel.
+    // Round 5: the coefficient is the instruction's ONE scalar operand (an SGPR pair, set by two s_mov on the scalar unit,
+    // which issues beside the VALU).  As VGPR operands the twelve coefficients were 24 registers that the compiler hoisted
+    // out of the pixel loops and, in the register-bound kernels, spilled: the tile kernel re-loaded nine of them from
+    // scratch per pixel, one `s_waitcnt vmcnt(0)` each -- a chain of memory round trips in the walk (profiles/r05_*).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PAIS_HORNER(c)                                                                        \
     {                                                                                         \
         const double c_ = (c);                                                                \
-        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(q), "v"(r), "v"(c_));                  \
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(q), "v"(r), "s"(c_));                  \
     }
 #else
 #define PAIS_HORNER(c) q = fma(q, r, (c));
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    double q;                                // 1/13!  (moved in from the scalar unit at the point of use: as a loop-invariant VGPR
+    {                                        //  constant it was hoisted out of the pixel loops and spilled with the others)
+        const double c13 = 1.6059043836821613e-10;
+        asm volatile("v_mov_b64 %0, %1" : "=v"(q) : "s"(c13));
+    }
+#else
     double q = 1.6059043836821613e-10;       // 1/13!
+#endif
     PAIS_HORNER(2.08767569878681e-09)        // 1/12!
     PAIS_HORNER(2.505210838544172e-08)       // 1/11!
     PAIS_HORNER(2.755731922398589e-07)       // 1/10!

@@ -53,6 +53,21 @@ struct WinPix {
 };
 // WinPix entries per candidate: S*S rounded up to whole 64-pixel steps; the padding entries are "masked", so that the
 // evaluation needs no lane-level validity test
+// v * u with u as the instruction's scalar operand (u wave-uniform): keeps u out of the vector registers for good -- left to
+// the compiler, a uniform double that feeds a VALU instruction is copied to a VGPR pair and kept (or spilled) there
+__device__ __forceinline__ double mul_uniform(double v, double u)
+{
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(v), "s"(u));
+    return r;
+}
+// a double that every lane holds alike, moved to an SGPR pair (the compiler cannot prove it uniform when it comes from LDS or a
+// VALU division): SGPR operands cost no vector register
+__device__ __forceinline__ double uniform_d(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 __host__ __device__ inline int win_stride(const DevScene &sc) { return (sc.cfg.patchSize * sc.cfg.patchSize + 63) & ~63; }
 
 // median of three == clamp(v, lo, hi) for lo <= hi, one instruction
@@ -500,7 +515,7 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
     const int M = ep->M, K = ep->K;
     const int S = sc.cfg.patchSize, S2 = S * S;
     const double a0 = ep->a0, b0 = ep->b0;
-    const double invDiffW = 1.0 / sc.cfg.diffWeighting;
+    const double invDiffW = uniform_d(1.0 / sc.cfg.diffWeighting);
     const bool useDiff = sc.cfg.adaptiveDifferenceEnable != 0;
     const bool hasRef = ep->hasRef != 0;
     const double invK = 1.0 / (double)K;
@@ -577,7 +592,7 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
             if (CHECK && __any(act && badBits[q] != 0)) return 1; // :1001 -- whole call
             const double sadq = sad[q] * invK;
             double weight = wp[q].wStat;
-            if (useDiff) weight *= det_exp_poly(-(sadq * sadq) * invDiffW);
+            if (useDiff) weight *= det_exp_poly(mul_uniform(-(sadq * sadq), invDiffW));
             if (ACCREG) {
                 // the sub-accumulator index is wave-uniform: a scalar branch selects the registers
 #define PAIS_ACC(a)                                           \

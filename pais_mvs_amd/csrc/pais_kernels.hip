@@ -835,10 +835,13 @@ __device__ __forceinline__ int wave_argmin_lex(bool valid, double key, int tie)
 // bound launch is a chain of four such selections: measured 16.6 k of the 34 k cycles of a thin launch's wave).  (key, tie)
 // pairs are distinct, so any all-to-all pairing order selects the same winner.  Result of lane 0, broadcast.
 template <int CTRL> __device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+// a permutation in which every lane has a source (rotations, mirrors): no `old` operand, so no copy in front of the move
+template <int CTRL> __device__ __forceinline__ int dpp_get_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 template <int CTRL> __device__ __forceinline__ void argmin_dpp_step(double &k, int &t, int &v)
 {
-    const int olo = dpp_mov_i<CTRL>(__double2loint(k)), ohi = dpp_mov_i<CTRL>(__double2hiint(k));
-    const int ot = dpp_mov_i<CTRL>(t), ov = dpp_mov_i<CTRL>(v);
+    // (mirrors and quad permutations give every lane a source: the moves need no `old` operand, i.e. no copy in front of them)
+    const int olo = dpp_get_i<CTRL>(__double2loint(k)), ohi = dpp_get_i<CTRL>(__double2hiint(k));
+    const int ot = dpp_get_i<CTRL>(t), ov = dpp_get_i<CTRL>(v);
     const double ok = __hiloint2double(ohi, olo);
     const bool take = ov && (!v || ok < k || (ok == k && ot < t));
     k = take ? ok : k;
@@ -888,8 +891,6 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov_d(double v)
 {
     return __hiloint2double(dpp_mov_i<CTRL>(__double2hiint(v)), dpp_mov_i<CTRL>(__double2loint(v)));
 }
-// a permutation in which every lane has a source (rotations, mirrors): no `old` operand, so no copy in front of the move
-template <int CTRL> __device__ __forceinline__ int dpp_get_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 template <int CTRL> __device__ __forceinline__ double dpp_get_d(double v)
 {
     return __hiloint2double(dpp_get_i<CTRL>(__double2hiint(v)), dpp_get_i<CTRL>(__double2loint(v)));
@@ -1169,6 +1170,21 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
                 exp_opaque(gf2);
             }
 #endif
+#if PAIS_EXP_DUP == 12
+            // (measurement build: the scan and the convergence test run twice AS A LOOP -- the same instructions a second time --
+            //  where PAIS_EXP_DUP == 2 runs a second COPY of them: the difference is what fetching the copy's code costs)
+            int expReps = 2;
+            asm volatile("" : "+s"(expReps));
+            const double gfIn = gf;
+            const int gIn = g;
+            double gB[3];
+            bool finished = false;
+#pragma nounroll
+            for (int expRep = 0; expRep < expReps; ++expRep) {
+            gf = gfIn;
+            g = gIn;
+            exp_opaque(pbf);
+#endif
             if (N <= 32) {
                 swarm_update_gbest(pbf, lane, N, gf, g);
             } else {
@@ -1180,9 +1196,14 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
                     }
                 }
             }
+#if PAIS_EXP_DUP == 12
+            gB[0] = lane_get(pb[0], g); gB[1] = lane_get(pb[1], g); gB[2] = lane_get(pb[2], g);
+            finished = it >= maxIt;
+#else
             const double gB[3] = {lane_get(pb[0], g), lane_get(pb[1], g), lane_get(pb[2], g)};
             // loop head of run(): `iteration < maxIteration`, then the convergence break (:293-297)
             bool finished = it >= maxIt;
+#endif
             if (!finished) {
                 const double a0 = fabs(pos[0] - gB[0]), a1 = fabs(pos[1] - gB[1]), a2 = fabs(pos[2] - gB[2]);
                 bool dispBelow;
@@ -1214,6 +1235,9 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
                     }
                 }
             }
+#if PAIS_EXP_DUP == 12
+            }
+#endif
             if (finished) {
                 if (i == 0 && part == 0 && lane == 0) {
                     // write back (patch.cpp:208-213) and the maxFitness gate (:156-159)

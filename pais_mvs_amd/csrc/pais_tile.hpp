@@ -281,11 +281,12 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
             asm volatile("" : "+s"(lo), "+s"(hi)::"memory");
             hs = (TileHS)(((uintptr_t)hi << 32) | (uintptr_t)lo);
         }
-        const double a0 = ep->a0, b0 = ep->b0;
-        const double invDiffW = 1.0 / sc.cfg.diffWeighting;
+        // (wave-uniform scalars of the walk live in SGPRs: as VGPR values they were four of the registers the walk spilled)
+        const double a0 = uniform_d(ep->a0), b0 = uniform_d(ep->b0);
+        const double invDiffW = uniform_d(1.0 / sc.cfg.diffWeighting);
         const bool useDiff = sc.cfg.adaptiveDifferenceEnable != 0;
         const bool hasRef = ep->hasRef != 0;
-        const double invK = 1.0 / (double)K;
+        const double invK = uniform_d(1.0 / (double)K);
         double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0};
         const int nPairs = (M >= 2) ? ((M & 1) ? (M - 3) / 2 : M / 2) : 0; // cameras 0 .. 2 nPairs - 1 in pairs, then a tail of 3, 1 or 0
         const int tail0 = 2 * nPairs, nTail = M - tail0;
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                         const bool act = wp[q].wStat >= 0.0;
                         const double sadq = sad * invK;
                         double weight = wp[q].wStat;
-                        if (useDiff) weight *= det_exp_poly(-(sadq * sadq) * invDiffW);
+                        if (useDiff) weight *= det_exp_poly(mul_uniform(-(sadq * sadq), invDiffW));
                         const int ga = (st + q) & 3; // canonical sub-accumulator of the step (uniform)
 #define PAIS_TACC(a)                                          \
     {                                                         \

@@ -18,4 +18,5 @@ if f:
             if "k_pso" in k: print("%-40s %-30s %16.6g (%d)"%(k.split("(")[0][:40],c,v,n))
     except Exception as e: print("err",e)
 PY
+  rm -rf $out/p$i
 done
