@@ -37,6 +37,9 @@
 #ifndef TILE_WAVES
 #define TILE_WAVES 8              // waves (= particles) of a workgroup
 #endif
+#ifndef TILE_STAGGER
+#define TILE_STAGGER 0           // see the walk
+#endif
 #ifndef TILE_WGS_PER_CU
 #define TILE_WGS_PER_CU 1         // workgroups that share a CU's 160 KB of LDS (each gets 160 / TILE_WGS_PER_CU KB)
 #endif
@@ -393,6 +396,20 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's LDS-DMA has landed ...
             __syncthreads();                                  // ... everybody's has
             const unsigned long long tc3 = dbg ? __builtin_readcyclecounter() : 0;
+#if TILE_STAGGER
+            // (experiment, profiles/r05_dome_tile_stagger_ab.txt: the eight waves leave the barrier in lockstep -- the same LDS reads at
+            //  the same time, then the same arithmetic at the same time; waves 1 .. 7 start the walk 64 * TILE_STAGGER * wave cycles late)
+            switch (wave) {
+            case 1: __builtin_amdgcn_s_sleep(1 * TILE_STAGGER); break;
+            case 2: __builtin_amdgcn_s_sleep(2 * TILE_STAGGER); break;
+            case 3: __builtin_amdgcn_s_sleep(3 * TILE_STAGGER); break;
+            case 4: __builtin_amdgcn_s_sleep(4 * TILE_STAGGER); break;
+            case 5: __builtin_amdgcn_s_sleep(5 * TILE_STAGGER); break;
+            case 6: __builtin_amdgcn_s_sleep(6 * TILE_STAGGER); break;
+            case 7: __builtin_amdgcn_s_sleep(7 * TILE_STAGGER); break;
+            default: break;
+            }
+#endif
             // ---- 4. the strip's steps for this wave's particle, NS steps (NS pixels per lane) per trip
             if (state == 0) {
                 const int kpix = 64 * s0 + lane;
