@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--emulate-world", default="", help="e.g. 2,4,8: after the normal line's measurements, run ONE rank of a world of N "
                     "on this GPU through the real sharded code path (include/pais_mvs.h pais_mvs_emulate: the other ranks' blocks are "
                     "replayed from a recorded single-rank run) and print measured T_rank(N) next to the model (config.emulated_speedup_at)")
-    ap.add_argument("--emulate-ranks", default="ends", choices=["ends", "all"], help="which ranks of each emulated world are run: "
+    ap.add_argument("--emulate-ranks", default="all", choices=["ends", "all"], help="which ranks of each emulated world are run: "
                     "the first and the last (default) or every one; T(N) = the slowest")
     ap.add_argument("--emulate-steps", type=int, default=2)
     ap.add_argument("--no-emulate", action="store_true", help="the default pawn line emulates ranks of worlds of 2 / 4 / 8 on this GPU "
@@ -573,6 +573,14 @@ def main():
                             "would produce from the reference's own source (tests/golden/make_literal_control.py)"}
         except Exception:
             pass
+        if args.scene in ("ring", "dome"):
+            try:   # the same gate at FULL size (tests/golden/make_literal_gate_full.py, run on the GPU box): printed, not re-measured
+                lg = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_gate_%s_full.json" % args.scene)))
+                literal_gate = {k: lg[k] for k in ("candidates", "branched", "branched_fraction", "same_trajectory_centre_max",
+                                                   "same_trajectory_normal_max", "set_mismatch_on_the_same_trajectory",
+                                                   "set_mismatch_among_branched", "control_literal_y_outer_and_fused", "workload")}
+            except Exception:
+                pass
         mb = None
         try:   # saturated rate of the same evaluation code (scripts/microbench_eval.py under profiles/)
             mb = json.load(open(os.path.join(ROOT, "profiles", "microbench_eval.json")))["evals_per_s"]

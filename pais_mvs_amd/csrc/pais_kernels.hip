@@ -973,6 +973,55 @@ __device__ __forceinline__ int swarm_rank(double dj, int lane, int N)
     return rank;
 }
 
+// FOUR lexicographic arg-mins at once (N <= 32): the selections of moveParticles -- the local best and the three per-dimension
+// near-neighbour bests -- are independent chains of five dependent exchange-compare-select steps; written one after the other
+// each waits for itself (1.5 us of the 13.3 us thin launch for the three FDR selections alone, profiles/r05_thin_launch_latency_
+// budget.txt), interleaved step by step the four chains fill each other's latencies.  Same pairings, same comparisons as
+// wave_argmin_lex_n: the same winners.
+template <int CTRL> __device__ __forceinline__ void argmin4_dpp_step(double (&k)[4], int (&t)[4], int (&v)[4])
+{
+    int olo[4], ohi[4], ot[4], ov[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        olo[c] = dpp_get_i<CTRL>(__double2loint(k[c]));
+        ohi[c] = dpp_get_i<CTRL>(__double2hiint(k[c]));
+        ot[c] = dpp_get_i<CTRL>(t[c]);
+        ov[c] = dpp_get_i<CTRL>(v[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double ok = __hiloint2double(ohi[c], olo[c]);
+        const bool take = ov[c] && (!v[c] || ok < k[c] || (ok == k[c] && ot[c] < t[c]));
+        k[c] = take ? ok : k[c];
+        t[c] = take ? ot[c] : t[c];
+        v[c] = take ? 1 : v[c];
+    }
+}
+__device__ __forceinline__ void wave_argmin4_lex_n(const bool (&valid)[4], const double (&key)[4], const int (&tie)[4], int N, int (&out)[4])
+{
+    double k[4];
+    int t[4], v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { k[c] = key[c]; t[c] = tie[c]; v[c] = valid[c] ? 1 : 0; }
+    if (N > 16) { // rows 0 and 1 first (one crossbar exchange per word)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double ok = __shfl_xor(k[c], 16, 64);
+            const int ot = __shfl_xor(t[c], 16, 64), ov = __shfl_xor(v[c], 16, 64);
+            const bool take = ov && (!v[c] || ok < k[c] || (ok == k[c] && ot < t[c]));
+            k[c] = take ? ok : k[c];
+            t[c] = take ? ot : t[c];
+            v[c] = take ? 1 : v[c];
+        }
+    }
+    argmin4_dpp_step<0x140>(k, t, v); // row_mirror
+    argmin4_dpp_step<0x141>(k, t, v); // row_half_mirror
+    argmin4_dpp_step<0x1B>(k, t, v);  // quad_perm [3, 2, 1, 0]
+    argmin4_dpp_step<0xB1>(k, t, v);  // quad_perm [1, 0, 3, 2]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = __builtin_amdgcn_readfirstlane(v[c] ? t[c] : -1);
+}
+
 // moveParticles for particle i with the swarm in lanes (lane j = particle j, N <= 64): same selections as
 // pso_move_particle (pais_dev.hpp), evaluated across lanes
 __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw, const double *u, const double *pos,
@@ -1014,10 +1063,41 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
     }
 #endif
     const bool sel = pv && rank < localK;
-    const int w = wave_argmin_lex_n(sel && pbf < DBL_MAX, pbf, rank * 64 + lane, N);
-    const int lIdx = (w < 0) ? i : (w & 63);
     // setNearNeighborBest: per dimension the first maximum of the fitness-distance ratio
     const double fitI = lane_get(fitj, i);
+    if (N <= 32) {
+        // the four selections side by side (wave_argmin4_lex_n)
+        double FDR[3];
+        for (int d = 0; d < 3; ++d) {
+            const double pd = lane_get(pos[d], i);
+            FDR[d] = (fitI - pbf) / fabs(pd - pb[d]);
+        }
+        const bool valid[4] = {sel && pbf < DBL_MAX, pv && lane != i && FDR[0] > -DBL_MAX, pv && lane != i && FDR[1] > -DBL_MAX,
+                               pv && lane != i && FDR[2] > -DBL_MAX};
+        const double key[4] = {pbf, -FDR[0], -FDR[1], -FDR[2]};
+        const int tie[4] = {rank * 64 + lane, lane, lane, lane};
+        int win[4];
+        wave_argmin4_lex_n(valid, key, tie, N, win);
+        const int lIdx4 = (win[0] < 0) ? i : (win[0] & 63);
+        for (int d = 0; d < 3; ++d) {
+            const int wn = win[1 + d];
+            const double o = lane_get(pb[d], wn < 0 ? 0 : wn);
+            outNb[d] = (wn < 0) ? nbI[d] : o;
+        }
+        for (int d = 0; d < 3; ++d) {
+            double p = lane_get(pos[d], i);
+            const double pbi = lane_get(pb[d], i), pbl = lane_get(pb[d], lIdx4);
+            double v = iw * vecI[d] + pVecW * (pbi - p) + gVecW * (gB[d] - p) + lVecW * (pbl - p) + nVecW * (outNb[d] - p);
+            outV[d] = v;
+            p += v;
+            if (p > ru[d]) p = ru[d];
+            if (p < rl[d]) p = rl[d];
+            outP[d] = p;
+        }
+        return;
+    }
+    const int w = wave_argmin_lex_n(sel && pbf < DBL_MAX, pbf, rank * 64 + lane, N);
+    const int lIdx = (w < 0) ? i : (w & 63);
 #if PAIS_EXP_DUP == 6
     for (int d = 0; d < 3; ++d) {
         double pd = lane_get(pos[d], i);
