@@ -459,6 +459,7 @@ def main():
         for N in worlds:
             ranks = list(range(N)) if args.emulate_ranks == "all" else sorted(set([0, N - 1]))
             worst, worst_st = 0.0, None
+            by_rank = []
             for r in ranks:
                 m.emulate(2, r, N)
                 step()                                   # (buffers of this world size grow here)
@@ -472,11 +473,15 @@ def main():
                 te = ((time.perf_counter() - t0e) * 1e3 - replay) / max(args.emulate_steps, 1)
                 if m.cloud_sha1() != ref_sha:
                     emulated["cloud_matches_single_rank"] = False
+                by_rank.append({"rank": r, "ms": te, "gpu_refine_ms": float(ste.gpu_refine_ms), "enumerate_ms": float(ste.host_enumerate_ms),
+                                "commit_ms": float(ste.host_commit_ms), "exchange_ms": float(ste.exchange_ms), "replay_ms": float(ste.emu_replay_ms),
+                                "streamed": int(ste.rounds_streamed), "sharded": int(ste.batches_sharded)})
                 if te > worst:
                     worst, worst_st = te, ste
             emulated["ms_at"][str(N)] = worst
             emulated[str(N)] = t1 / worst if worst > 0 else None
             emulated["ranks_run"][str(N)] = ranks
+            emulated.setdefault("by_rank", {})[str(N)] = by_rank
             emulated["streamed_rounds_at"][str(N)] = int(worst_st.rounds_streamed)
             emulated["exchange_ms_at"][str(N)] = float(worst_st.exchange_ms)
             emulated["batches_sharded_at"][str(N)] = int(worst_st.batches_sharded)

@@ -108,7 +108,7 @@ int  pais_mvs_set_thin_front(pais_mvs *m, int thin_front);
 /* ---- multi-GPU: one process per GPU, replicated driver, sharded refinement ----
  * Every rank creates the same driver on its own GPU (same cameras, config, seeds, pso_seed) and joins a
  * communicator.  From then on pais_mvs_refine_seed_patches / pais_mvs_expansion_patches split every batch of
- * candidates into `world` contiguous, count-balanced shards; a rank refines its shard (pais_refine_batch_device_async,
+ * candidates into `world` contiguous, count-balanced shards (PAIS_SHARD_STRIDED=1: candidate i to rank i mod world instead); a rank refines its shard (pais_refine_batch_device_async,
  * records stay in HBM) and the records -- packed into fixed-size wire slots behind a 64-byte status header that is written on
  * the device -- are exchanged with ONE all-gather per batch -- ncclAllGather (RCCL over xGMI) on the context's stream, ONE host
  * synchronisation per batch -- after which every rank replays the identical host bookkeeping.  Large rounds are streamed in

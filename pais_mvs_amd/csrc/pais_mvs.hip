@@ -302,6 +302,7 @@ struct pais_mvs {
     std::vector<pais_patch_result> emuRecs;
     double emuLatencyUs = 25.0;                                    // PAIS_EMU_LATENCY_US: modelled launch latency of the collective
     std::vector<pais_patch_result> sendBuf;
+    std::vector<pais_candidate> shardCands; // this rank's candidates of a batch on the host-transport path, gathered (strided shards)
     std::vector<unsigned char> wireSend, wireAll;
     std::vector<HostCamera> cams;
     std::vector<HostPatch *> patches; // index == id; nullptr once deleted  (map<int,Patch>, mvs.h:86)
@@ -366,6 +367,11 @@ struct pais_mvs {
     // -1 (default) = on in the one-GPU emulation, where it has been measured, OFF over a real RCCL communicator until a run on
     // >= 2 real GPUs has been green (that path has only ever run against the emulated transport)
     int streamSharded = -1;
+    // how a batch is dealt to the ranks: false (default) = contiguous count-balanced shards, true = candidate i to rank i mod world
+    // (PAIS_SHARD_STRIDED=1; must be the same on every rank).  Round 5 built the second rule against a suspected cost gradient along
+    // the work list and then measured EVERY rank of the emulated 8-rank dome: contiguous shards are balanced already (1.40 ... 1.48 s
+    // over the eight ranks), dealing the candidates out is no better (profiles/r05_emu_dome40_by_rank.txt) -- the default stays.
+    bool shardStrided = false;
     int streamHead = 4, streamStep = 2; // PAIS_STREAM_HEAD / _STEP: PSO iterations of a part enqueued when it is opened / per turn after that
     const std::function<int(const pais_candidate *, int)> *onFirstPart = nullptr; // set by the streamed driver for one round_begin
     int firstPart = -1;                // candidates of the first part of the current round (-1: the round is one batch)
@@ -837,6 +843,7 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
     if (const char *e = getenv("PAIS_STREAM_HOST_SHARE")) m->streamHostShare = atof(e);
     if (const char *e = getenv("PAIS_STREAM_HEAD")) m->streamHead = std::max(1, atoi(e));
     if (const char *e = getenv("PAIS_STREAM_SHARDED")) m->streamSharded = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("PAIS_SHARD_STRIDED")) m->shardStrided = atoi(e) != 0;
     if (const char *e = getenv("PAIS_STREAM_FIRST")) m->streamFirst = std::max(0.0, std::min(0.9, atof(e)));
     if (const char *e = getenv("PAIS_STREAM_PARTS")) m->streamParts = std::max(2, std::min(atoi(e), PAIS_MAX_STREAM_PARTS));
     if (const char *e = getenv("PAIS_STREAM_STEP")) m->streamStep = std::max(1, atoi(e));
@@ -1120,6 +1127,19 @@ static int shard_ensure(pais_mvs *m, pais_mvs::ShardBufs &B, size_t per, size_t 
     return shard_growth_handshake(m, rc);
 }
 
+// which candidates of a batch of n are rank r's, and where its j-th one sits in the batch (see pais_mvs::shardStrided)
+static inline int shard_count(const pais_mvs *m, int r, int n, int per)
+{
+    if (m->shardStrided) return r < n ? (n - r + m->world - 1) / m->world : 0;
+    const int lo = std::min(r * per, n);
+    return std::min(lo + per, n) - lo;
+}
+static inline int shard_index(const pais_mvs *m, int r, int j, int n, int per)
+{
+    (void)n;
+    return m->shardStrided ? j * m->world + r : r * per + j;
+}
+
 // other ranks' blocks of an emulated exchange, from the records of the single-rank run (host, into the pinned staging)
 static int emu_fill_blocks(pais_mvs *m, pais_mvs::ShardXfer &X)
 {
@@ -1127,12 +1147,12 @@ static int emu_fill_blocks(pais_mvs *m, pais_mvs::ShardXfer &X)
     for (int r = 0; r < m->world; ++r) {
         if (r == m->rank) continue;
         unsigned char *blk = X.B->h_wireAll + X.slot * (size_t)r;
-        const int rlo = std::min(r * X.per, X.n), rcnt = std::min(rlo + X.per, X.n) - rlo;
+        const int rcnt = shard_count(m, r, X.n, X.per);
         WireHeader hd = {PAIS_WIRE_MAGIC, 0, rcnt, r, m->streamWish ? 1u : 0u}; // (every emulated rank decides as this one does)
         memset(blk, 0, kWireHeader);
         memcpy(blk, &hd, sizeof(hd));
         for (int i = 0; i < rcnt; ++i) {
-            auto it = m->emuIndex.find(X.c[rlo + i].key);
+            auto it = m->emuIndex.find(X.c[shard_index(m, r, i, X.n, X.per)].key);
             if (it == m->emuIndex.end()) return mfail("emulated world: a candidate of this run is not among the recorded run's (another workload?)");
             if (pais_pack_records(1, &m->emuRecs[it->second], X.Kb, blk + kWireHeader + X.WB * (size_t)i)) return mfail(pais_last_error());
         }
@@ -1179,7 +1199,7 @@ static void shard_refine_enqueue(pais_mvs *m, pais_mvs::ShardXfer &X)
     hipStream_t ls = (hipStream_t)pais_ctx_stream(X.lane);
     int rc = 0;
     if (X.cnt > 0) {
-        memcpy(B.h_shardC, X.c + X.lo, sizeof(pais_candidate) * (size_t)X.cnt);
+        for (int j = 0; j < X.cnt; ++j) B.h_shardC[j] = X.c[shard_index(m, m->rank, j, X.n, X.per)];
         if (hipMemcpyAsync(B.d_shardC, B.h_shardC, sizeof(pais_candidate) * (size_t)X.cnt, hipMemcpyHostToDevice, ls) != hipSuccess) rc = -2;
         if (!rc) rc = pais_refine_batch_device_async(X.lane, X.cnt, B.d_shardC, B.d_shardR, X.Kmax, X.hasSeeds);
         if (rc) g_mvs_err = pais_last_error();
@@ -1196,14 +1216,14 @@ static int shard_submit(pais_mvs *m, pais_mvs::ShardXfer &X, pais_mvs::ShardBufs
     const int world = m->world;
     X.B = &B; X.lane = lane; X.c = c; X.n = n; X.hasSeeds = has_seeds; X.sharded = true; X.open = true;
     X.per = (n + world - 1) / world;
-    X.lo = std::min(m->rank * X.per, n);
-    X.cnt = std::min(X.lo + X.per, n) - X.lo;
+    X.lo = std::min(m->rank * X.per, n); // (contiguous shards only)
+    X.cnt = shard_count(m, m->rank, n, X.per);
     // What travels: wire slots (include/pais_hip.h "wire format of a record") sized for the batch's largest camera count --
     // the same on every rank, the candidate list is replicated
     X.Kb = 1;
     for (int i = 0; i < n; ++i) X.Kb = std::max(X.Kb, c[i].num_cam);
     X.Kmax = 1;
-    for (int i = X.lo; i < X.lo + X.cnt; ++i) X.Kmax = std::max(X.Kmax, c[i].num_cam);
+    for (int j = 0; j < X.cnt; ++j) X.Kmax = std::max(X.Kmax, c[shard_index(m, m->rank, j, n, X.per)].num_cam);
     X.WB = pais_record_wire_bytes(X.Kb);
     X.slot = kWireHeader + X.WB * (size_t)X.per;
     X.t0 = now_ms();
@@ -1239,7 +1259,7 @@ static int shard_finish(pais_mvs *m, pais_mvs::ShardXfer &X, pais_patch_result *
             WireHeader hd;
             memcpy(&hd, B.h_wireAll + X.slot * (size_t)r, sizeof(hd));
             if (r == 0 && hd.magic == PAIS_WIRE_MAGIC) m->streamAgreed = (hd.user & 1u) != 0; // rank 0's choice binds every rank
-            const int rlo = std::min(r * X.per, X.n), rcnt = std::min(rlo + X.per, X.n) - rlo;
+            const int rcnt = shard_count(m, r, X.n, X.per);
             if (hd.magic != PAIS_WIRE_MAGIC || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
             if (hd.rc == PAIS_WIRE_RC_RING_RETRY) { retry = true; continue; }
             if (hd.rc != 0) {
@@ -1258,8 +1278,14 @@ static int shard_finish(pais_mvs *m, pais_mvs::ShardXfer &X, pais_patch_result *
     }
     m->st.exchange_ms += now_ms() - X.t0; // (from the submission: refinement of the shard included)
     for (int r = 0; r < world; ++r) {
-        const int rlo = std::min(r * X.per, X.n), rcnt = std::min(rlo + X.per, X.n) - rlo;
-        if (rcnt > 0 && pais_unpack_records(rcnt, B.h_wireAll + X.slot * (size_t)r + kWireHeader, X.Kb, out + rlo)) return mfail(pais_last_error());
+        const int rcnt = shard_count(m, r, X.n, X.per);
+        const unsigned char *blk = B.h_wireAll + X.slot * (size_t)r + kWireHeader;
+        if (!m->shardStrided) {
+            if (rcnt > 0 && pais_unpack_records(rcnt, blk, X.Kb, out + shard_index(m, r, 0, X.n, X.per))) return mfail(pais_last_error());
+        } else {
+            for (int j = 0; j < rcnt; ++j)
+                if (pais_unpack_records(1, blk + X.WB * (size_t)j, X.Kb, out + shard_index(m, r, j, X.n, X.per))) return mfail(pais_last_error());
+        }
     }
     return 0;
 }
@@ -1306,14 +1332,18 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
     }
     // records through host memory: GPU-less driver, or a caller-supplied transport
     const int per = (n + world - 1) / world;
-    const int lo = std::min(m->rank * per, n), hi = std::min(lo + per, n), cnt = hi - lo;
+    const int cnt = shard_count(m, m->rank, n, per);
     int Kb = 1;
     for (int i = 0; i < n; ++i) Kb = std::max(Kb, c[i].num_cam);
     const size_t WB = pais_record_wire_bytes(Kb), slot = kWireHeader + WB * (size_t)per;
     m->wireAll.resize(slot * (size_t)world);
     int localRc = 0;
     m->sendBuf.assign((size_t)per, pais_patch_result());
-    if (cnt > 0) localRc = refine_local(m, cnt, c + lo, m->sendBuf.data(), has_seeds);
+    if (cnt > 0) {
+        m->shardCands.resize((size_t)cnt);
+        for (int j = 0; j < cnt; ++j) m->shardCands[(size_t)j] = c[shard_index(m, m->rank, j, n, per)];
+        localRc = refine_local(m, cnt, m->shardCands.data(), m->sendBuf.data(), has_seeds);
+    }
     m->wireSend.assign(slot, 0);
     WireHeader hd0 = {PAIS_WIRE_MAGIC, localRc, cnt, m->rank, 0u};
     memcpy(m->wireSend.data(), &hd0, sizeof(hd0));
@@ -1325,11 +1355,11 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
         m->st.exchange_bytes += (int64_t)(slot * (size_t)world);
         if (rc) return rc;
     }
-    // every rank reads every rank's status, then the shards in rank order (contiguous, count balanced)
+    // every rank reads every rank's status, then the shards in rank order
     for (int r = 0; r < world; ++r) {
         WireHeader hd;
         memcpy(&hd, m->wireAll.data() + slot * (size_t)r, sizeof(hd));
-        const int rlo = std::min(r * per, n), rcnt = std::min(rlo + per, n) - rlo;
+        const int rcnt = shard_count(m, r, n, per);
         if (hd.magic != PAIS_WIRE_MAGIC || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
         if (hd.rc != 0) {
             if (r != m->rank || g_mvs_err.empty()) g_mvs_err = "sharded batch: rank " + std::to_string(r) + " failed to refine its shard (rc " + std::to_string(hd.rc) + ")";
@@ -1337,9 +1367,10 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
         }
     }
     for (int r = 0; r < world; ++r) {
-        const int rlo = std::min(r * per, n), rcnt = std::min(rlo + per, n) - rlo;
-        if (rcnt > 0 && pais_unpack_records(rcnt, m->wireAll.data() + slot * (size_t)r + kWireHeader, Kb, m->results.data() + rlo))
-            return mfail(pais_last_error());
+        const int rcnt = shard_count(m, r, n, per);
+        const unsigned char *blk = m->wireAll.data() + slot * (size_t)r + kWireHeader;
+        for (int j = 0; j < rcnt; ++j)
+            if (pais_unpack_records(1, blk + WB * (size_t)j, Kb, m->results.data() + shard_index(m, r, j, n, per))) return mfail(pais_last_error());
     }
     *view = m->results.data();
     return 0;

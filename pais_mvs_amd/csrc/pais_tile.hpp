@@ -37,6 +37,9 @@
 #ifndef TILE_WAVES
 #define TILE_WAVES 8              // waves (= particles) of a workgroup
 #endif
+#ifndef TILE_MIN_WAVES_PER_SIMD
+#define TILE_MIN_WAVES_PER_SIMD 2  // occupancy the register allocation must allow
+#endif
 #ifndef TILE_STAGGER
 #define TILE_STAGGER 0           // see the walk
 #endif
@@ -179,7 +182,7 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
 // The evaluation launch of many-camera batches.  Grid: candidates x particle groups of TILE_WAVES; workgroup of TILE_WAVES
 // waves.  Writes A.fit[i], or flags the particle pending (A.part[i][0] = 1) for the pending-only k_pso_eval2 launch behind it.
 template <int NS, int NP>
-__global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+__global__ __launch_bounds__(64 * TILE_WAVES, TILE_MIN_WAVES_PER_SIMD) void k_pso_tile(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                                                 const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
                                                                 int tileBytes, int groups, int stripSteps, unsigned long long *dbg,
                                                                 double *hscr)

@@ -31,6 +31,11 @@ def shard_bounds(n: int, rank: int, world: int):
     return per, lo, hi
 
 
+def shard_indices(n: int, rank: int, world: int):
+    """The candidates of a batch of n that rank `rank` refines under PAIS_SHARD_STRIDED=1: candidate i goes to rank i mod world."""
+    return list(range(rank, n, world))
+
+
 @dataclass
 class Job:
     rank: int

@@ -160,6 +160,24 @@ def test_shard_bounds_cover_everything():
             assert seen == list(range(n))
 
 
+def test_strided_shards_cover_everything_evenly():
+    from pais_mvs_amd.distributed import shard_indices
+    for n in (0, 1, 7, 8, 9, 1000):
+        for world in (1, 2, 3, 8):
+            parts = [shard_indices(n, r, world) for r in range(world)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+            assert all(len(p) <= (n + world - 1) // world for p in parts)      # a rank's block never exceeds the wire slot
+
+
+def test_strided_shards_rebuild_the_same_cloud(monkeypatch):
+    """PAIS_SHARD_STRIDED=1 deals the same batch differently (candidate i to rank i mod world) and rebuilds the same cloud."""
+    ref = _run(1, 1024)[0]
+    monkeypatch.setenv("PAIS_SHARD_STRIDED", "1")      # (the spawned ranks inherit the environment)
+    for rank, blob, shape, eff, sharded, replicated, cands, xbytes, nmin in _run(2, 0):
+        assert blob == ref[1] and shape == ref[2] and sharded > 0
+
+
 def test_rank_arguments_are_validated(pawn_small):
     from pais_mvs_amd.config import readme_config
     from pais_mvs_amd.mvs import MVS
