@@ -2222,14 +2222,14 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
 }
 // many-camera batches: the tile kernel (pais_tile.hpp) can take the evaluation launch of the large-batch pipeline
 bool tile_eligible(int Kmax) { return eval_shape(Kmax) == 2 && Kmax <= TILE_MAX_CAMS; }
-template <int NS, int NP, bool PF>
+template <int NS, int NP>
 static hipError_t pso_tile_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
                                   const void *win, int stripSteps, unsigned long long *dbg, double *hscr, size_t hscrBytes, hipStream_t stream)
 {
     static LdsAttr attr;
     const size_t lds = ((160 * 1024) / TILE_WGS_PER_CU) & ~(size_t)1023, fixed = tile_fixed_lds_bytes(Kmax);
     if (fixed + 4096 > lds) return hipErrorInvalidValue;
-    hipError_t e = attr.ensure((const void *)k_pso_tile<NS, NP, PF>, lds);
+    hipError_t e = attr.ensure((const void *)k_pso_tile<NS, NP>, lds);
     if (e != hipSuccess) return e;
     const int groups = (Nmax + TILE_WAVES - 1) / TILE_WAVES;
     long grid = (long)n * groups;
@@ -2241,7 +2241,7 @@ static hipError_t pso_tile_launch(const DevScene &sc, unsigned char *states, int
         if (slots < 1) return hipErrorInvalidValue;
         if (grid > slots) grid = slots;
     }
-    hipLaunchKernelGGL((k_pso_tile<NS, NP, PF>), dim3((unsigned)grid), dim3(64 * TILE_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+    hipLaunchKernelGGL((k_pso_tile<NS, NP>), dim3((unsigned)grid), dim3(64 * TILE_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
                        eval_block_bytes(Kmax), (const WinPix *)win, getenv("PAIS_TILE_NOTILES") ? 0 : (int)(lds - fixed), groups, stripSteps, dbg,
                        hscr);
     return hipGetLastError();
@@ -2252,16 +2252,8 @@ hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, 
     // two pixels per lane while the colours of 2 x 32 cameras fit the registers; one pixel per lane beyond.  Strip lengths
     // swept on the full-size dome (profiles/r03_dome_tile_sweep.txt): 14 / 24 steps; longer strips = fewer barriers, until the
     // tiles of a strip stop fitting the tile area (cameras then tap global memory)
-    // PAIS_TILE_PF (default 1): one pixel per lane with the next camera pair's homography records read ahead, for batches of up
-    // to 32 / 44 cameras (16 / 22 pairs of colours in registers leave room for the 40 registers of a pair's records); 0: round
-    // 4's instantiations (two pixels per lane up to 32 cameras, one pixel per lane beyond)
-    static const int pf = getenv("PAIS_TILE_PF") ? atoi(getenv("PAIS_TILE_PF")) : 1;
-    if (pf && !forceNs1) {
-        if (Kmax <= 32) return pso_tile_launch<1, 16, true>(sc, states, n, Nmax, Kmax, evalBlocks, win, strip1, dbg, hscr, hscrBytes, stream);
-        if (Kmax <= 44) return pso_tile_launch<1, 22, true>(sc, states, n, Nmax, Kmax, evalBlocks, win, strip1, dbg, hscr, hscrBytes, stream);
-    }
-    if (Kmax <= 32 && !forceNs1) return pso_tile_launch<2, 16, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, (strip2 + 1) & ~1, dbg, hscr, hscrBytes, stream);
-    return pso_tile_launch<1, 32, false>(sc, states, n, Nmax, Kmax, evalBlocks, win, strip1, dbg, hscr, hscrBytes, stream);
+    if (Kmax <= 32 && !forceNs1) return pso_tile_launch<2, 16>(sc, states, n, Nmax, Kmax, evalBlocks, win, (strip2 + 1) & ~1, dbg, hscr, hscrBytes, stream);
+    return pso_tile_launch<1, 32>(sc, states, n, Nmax, Kmax, evalBlocks, win, strip1, dbg, hscr, hscrBytes, stream);
 }
 template <int P, int NS, bool BYTES, bool ACCR>
 static hipError_t pso_iter_launch(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount,

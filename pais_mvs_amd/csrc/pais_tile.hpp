@@ -37,9 +37,6 @@
 #ifndef TILE_WAVES
 #define TILE_WAVES 8              // waves (= particles) of a workgroup
 #endif
-#ifndef TILE_MIN_WAVES_PER_SIMD
-#define TILE_MIN_WAVES_PER_SIMD 2  // occupancy the register allocation must allow
-#endif
 #ifndef TILE_STAGGER
 #define TILE_STAGGER 0           // see the walk
 #endif
@@ -85,21 +82,9 @@ __host__ __device__ inline size_t tile_fixed_lds_bytes(int Kmax)
 // variant stays selectable (-DPAIS_TILE_SCALAR_H=1).  (PAIS_TILE_SCALAR_H itself is defined in pais_internal.h: the host
 // only allocates the scratch when it is on.)
 typedef const double __attribute__((address_space(4))) *TileHS;
-// the homography records (9 doubles + the tile word) of a camera pair, read ahead of the group that uses them (TILE prefetch, PF)
-struct TilePairH { double2 v[2][5]; };
-__device__ __forceinline__ void tile_load_pair(const double *Hbuf, int c0, TilePairH &h)
-{
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) h.v[u][k] = H2[k];
-    }
-}
 template <int G, int NS, bool SH>
 __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam *cams, const unsigned char *tiles,
-                                               const double *Hbuf, TileHS hs, int c0, double *x, double *y, double (*col)[NS], double *sum,
-                                               const TilePairH *pre = nullptr)
+                                               const double *Hbuf, TileHS hs, int c0, double *x, double *y, double (*col)[NS], double *sum)
 {
 #pragma unroll
     for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
@@ -112,8 +97,6 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
             TileHS h = hs + PAIS_H_STRIDE * (c0 + u); // wave-uniform address in the constant address space: s_load
             ha.x = h[0]; ha.y = h[1]; hb.x = h[2]; hb.y = h[3]; hc.x = h[4]; hc.y = h[5]; hd.x = h[6]; hd.y = h[7]; he.x = h[8];
             he.y = Hbuf[PAIS_H_STRIDE * (c0 + u) + 9]; // the tile word of this strip: one 8-byte LDS read
-        } else if (G == 2 && pre) {
-            ha = pre->v[u < 2 ? u : 0][0]; hb = pre->v[u < 2 ? u : 0][1]; hc = pre->v[u < 2 ? u : 0][2]; hd = pre->v[u < 2 ? u : 0][3]; he = pre->v[u < 2 ? u : 0][4];
         } else {
             const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
             ha = H2[0]; hb = H2[1]; hc = H2[2]; hd = H2[3]; he = H2[4];
@@ -195,8 +178,8 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
 
 // The evaluation launch of many-camera batches.  Grid: candidates x particle groups of TILE_WAVES; workgroup of TILE_WAVES
 // waves.  Writes A.fit[i], or flags the particle pending (A.part[i][0] = 1) for the pending-only k_pso_eval2 launch behind it.
-template <int NS, int NP, bool PF>
-__global__ __launch_bounds__(64 * TILE_WAVES, TILE_MIN_WAVES_PER_SIMD) void k_pso_tile(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+template <int NS, int NP>
+__global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                                                 const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
                                                                 int tileBytes, int groups, int stripSteps, unsigned long long *dbg,
                                                                 double *hscr)
@@ -462,22 +445,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES, TILE_MIN_WAVES_PER_SIMD) void k_ps
                     double col[2 * NP][NS], t3[3][NS];
 #pragma unroll
                     for (int q = 0; q < NS; ++q) t3[0][q] = t3[1][q] = t3[2][q] = 0;
-                    // PF: the records of pair u + 1 are requested before pair u is worked on -- a group is two dependent LDS round
-                    // trips (homographies -> arithmetic -> byte taps -> arithmetic) at two waves per SIMD; read one group ahead,
-                    // the first of them hides behind the previous group's taps.  40 registers: only the instantiations whose
-                    // colours leave them (one pixel per lane, <= 44 cameras)
-                    TilePairH hpre[2];
-                    if (PF && nPairs > 0) tile_load_pair(Hbuf, 0, hpre[0]);
 #pragma unroll
                     for (int u = 0; u < NP; ++u) {
-                        if (u < nPairs) {
-                            if (PF) {
-                                if (u + 1 < nPairs) tile_load_pair(Hbuf, 2 * (u + 1), hpre[(u + 1) & 1]);
-                                tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, &col[2 * u], sum, &hpre[u & 1]);
-                            } else {
-                                tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, &col[2 * u], sum);
-                            }
-                        } else {
+                        if (u < nPairs) tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, &col[2 * u], sum);
+                        else {
 #pragma unroll
                             for (int q = 0; q < NS; ++q) col[2 * u][q] = col[2 * u + 1][q] = 0;
                         }
