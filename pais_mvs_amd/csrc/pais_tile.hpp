@@ -37,6 +37,12 @@
 #ifndef TILE_WAVES
 #define TILE_WAVES 8              // waves (= particles) of a workgroup
 #endif
+#ifndef TILE_EXP_DUP
+#define TILE_EXP_DUP 0            // measurement builds (scripts/dome_dup_profile.sh): ONE component of the walk executed twice, same results:
+#endif                            // 1 homography reads, 2 byte taps, 3 a whole camera group, 4 the per-pixel tail (mean, SAD, exp, accumulate), 5 WinPix loads
+#ifndef TILE_EXP_SKIP
+#define TILE_EXP_SKIP 0           // measurement builds, WRONG results (timing of the first seed pass only, scripts/dome_skip_profile.sh):
+#endif                            // 1 four of the five homography reads per camera replaced by constants, 2 the byte taps, 3 the exp of the tail
 #ifndef TILE_STAGGER
 #define TILE_STAGGER 0           // see the walk
 #endif
@@ -99,7 +105,20 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
             he.y = Hbuf[PAIS_H_STRIDE * (c0 + u) + 9]; // the tile word of this strip: one 8-byte LDS read
         } else {
             const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
+#if TILE_EXP_SKIP == 1
+            he = H2[4];
+            ha.x = 1.0; ha.y = 0.0; hb.x = 0.25 * he.x; hb.y = 0.0; hc.x = 1.0; hc.y = 0.125 * he.x; hd.x = 0.0; hd.y = 0.0;
+#else
             ha = H2[0]; hb = H2[1]; hc = H2[2]; hd = H2[3]; he = H2[4];
+#endif
+#if TILE_EXP_DUP == 1
+            {
+                const double2 *H3 = H2;
+                asm volatile("" : "+v"(H3));
+                const double2 t0 = H3[0], t1 = H3[1], t2 = H3[2], t3_ = H3[3], t4 = H3[4];
+                asm volatile("" ::"v"(t0.x), "v"(t0.y), "v"(t1.x), "v"(t1.y), "v"(t2.x), "v"(t2.y), "v"(t3_.x), "v"(t3_.y), "v"(t4.x), "v"(t4.y));
+            }
+#endif
         }
         // (the camera's tile rides in the padding of its homography record: no read of its own)
         tbase[u] = __double2loint(he.y);
@@ -143,6 +162,9 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
             bx[q][u] = __builtin_amdgcn_fract(ix);
             by[q][u] = __builtin_amdgcn_fract(iy);
         }
+#if TILE_EXP_SKIP == 1
+        if (ttw[u] == 0) { ttw[u] = 64; tbase[u] = 0; } // (timing build: no global-memory taps at coordinates that mean nothing)
+#endif
         if (ttw[u] != 0) { // wave-uniform: the camera's tile is staged
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -151,8 +173,20 @@ __device__ __forceinline__ void tile_tap_group(const DevScene &sc, const EvalCam
                 const uint32_t a = (uint32_t)(tbase[u] + py[q] * ttw[u] + px[q]);
                 uint32_t ar = a + 1;
                 asm volatile("" : "+v"(ar));
+#if TILE_EXP_SKIP == 2
+                a0[q][u] = a & 255; b0[q][u] = ar & 255; a1[q][u] = (a >> 3) & 255; b1[q][u] = (ar >> 5) & 255;
+#else
                 a0[q][u] = tiles[a]; b0[q][u] = tiles[ar];
                 a1[q][u] = tiles[a + (uint32_t)ttw[u]]; b1[q][u] = tiles[ar + (uint32_t)ttw[u]];
+#endif
+#if TILE_EXP_DUP == 2
+                {
+                    uint32_t a2 = a, ar2 = ar;
+                    asm volatile("" : "+v"(a2), "+v"(ar2));
+                    const int e0 = tiles[a2], e1 = tiles[ar2], e2 = tiles[a2 + (uint32_t)ttw[u]], e3 = tiles[ar2 + (uint32_t)ttw[u]];
+                    asm volatile("" ::"v"(e0), "v"(e1), "v"(e2), "v"(e3));
+                }
+#endif
             }
         } else {
             TapInfo ti;
@@ -424,6 +458,14 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                         // (a step past the window -- uniform, skipped below -- re-reads the last entry; the padding lanes of
                         // the last step are masked entries)
                         wp[q] = wbase[stq < nSteps ? (64 * stq + lane) : (S2 - 1)];
+#if TILE_EXP_DUP == 5
+                        {
+                            const WinPix *wb2 = wbase;
+                            asm volatile("" : "+v"(wb2));
+                            const WinPix w2 = wb2[stq < nSteps ? (64 * stq + lane) : (S2 - 1)];
+                            asm volatile("" ::"v"(w2.refCol), "v"(w2.wStat));
+                        }
+#endif
                         x[q] = a0 + (double)xw;
                         y[q] = b0 + (double)yw;
                         xw += rA; yw += qA;
@@ -447,8 +489,19 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                     for (int q = 0; q < NS; ++q) t3[0][q] = t3[1][q] = t3[2][q] = 0;
 #pragma unroll
                     for (int u = 0; u < NP; ++u) {
-                        if (u < nPairs) tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, &col[2 * u], sum);
-                        else {
+                        if (u < nPairs) {
+#if TILE_EXP_DUP == 3
+                            {
+                                double sumd[NS], cold[2][NS];
+#pragma unroll
+                                for (int q = 0; q < NS; ++q) sumd[q] = 0;
+                                tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, cold, sumd);
+#pragma unroll
+                                for (int q = 0; q < NS; ++q) asm volatile("" ::"v"(sumd[q]), "v"(cold[0][q]), "v"(cold[1][q]));
+                            }
+#endif
+                            tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, &col[2 * u], sum);
+                        } else {
 #pragma unroll
                             for (int q = 0; q < NS; ++q) col[2 * u][q] = col[2 * u + 1][q] = 0;
                         }
@@ -472,10 +525,33 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                             sad += fabs(t3[1][q] - mean);
                             sad += fabs(t3[2][q] - mean);
                         }
+#if TILE_EXP_DUP == 4
+                        {
+                            double m2 = sum[q];
+                            asm volatile("" : "+v"(m2));
+                            const double mean2 = m2 * invK;
+                            double sad2 = hasRef ? fabs(wp[q].refCol - mean2) : 0.0;
+#pragma unroll
+                            for (int u = 0; u < NP; ++u) {
+                                if (u < nPairs) {
+                                    sad2 += fabs(col[2 * u][q] - mean2);
+                                    sad2 += fabs(col[2 * u + 1][q] - mean2);
+                                }
+                            }
+                            const double sq2 = sad2 * invK;
+                            double w2 = wp[q].wStat;
+                            if (useDiff) w2 *= det_exp_poly(mul_uniform(-(sq2 * sq2), invDiffW));
+                            asm volatile("" ::"v"(w2));
+                        }
+#endif
                         const bool act = wp[q].wStat >= 0.0;
                         const double sadq = sad * invK;
                         double weight = wp[q].wStat;
+#if TILE_EXP_SKIP == 3
+                        if (useDiff) weight *= mul_uniform(-(sadq * sadq), invDiffW);
+#else
                         if (useDiff) weight *= det_exp_poly(mul_uniform(-(sadq * sadq), invDiffW));
+#endif
                         const int ga = (st + q) & 3; // canonical sub-accumulator of the step (uniform)
 #define PAIS_TACC(a)                                          \
     {                                                         \
