@@ -200,3 +200,29 @@ def test_hip_cloud_of_the_bench_workload_against_the_literal_cloud():
     for side in ("a_to_b", "b_to_a"):
         for k in ("dist_over_radius_p95", "normal_angle_p95_rad", "within_radius", "within_1e-4_rel_centre"):
             assert abs(met[side][k] - gold[side][k]) <= 2e-3 * max(abs(gold[side][k]), 1e-3) + 1e-4, (side, k, met[side][k], gold[side][k])
+
+
+@pytest.mark.parametrize("scene_name,B,rounds,grad", [("pawn_small", 64, 0, False), ("ring_small", 64, 6, True)])
+def test_small_scenes_at_cloud_level(request, scene_name, B, rounds, grad):
+    """The cloud-level comparison on the test-size scenes, CPU only: the oracle's kernel-arithmetic cloud (= the HIP path's, bit for
+    bit: tests/test_gpu_parity.py) against its literal-arithmetic cloud -- the small pawn to convergence, the 24-camera ring (all
+    adaptive weights, K = 7..11) for six rounds.  Measured: pawn 2 612 vs 2 612 patches, 97.2 % with a counterpart inside one
+    neighborRadius, normal angle p95 0.048 rad (the low-resolution pawn is the flattest cost of all scenes: K = 3..5, 320 x 240);
+    ring 841 vs 841, 94 % of the centres identical, the rest within 1e-12 radius.  Gates: counts within 3 %, 95 % inside one radius
+    in both directions, normal angle p95 below 0.08 rad."""
+    from pais_mvs_amd import cloudcmp
+    from pais_mvs_amd.config import readme_config
+    scene = request.getfixturevalue(scene_name)
+    cfg = readme_config(adaptiveGradientEnable=grad)
+    runs = {}
+    for name, ka in (("literal", False), ("kernel", True)):
+        rows, calls, acc, spec, cloud, radius = common.oracle_reconstruct(cfg, scene, B, rounds, parallel=True, kernel_arithmetic=ka, with_cloud=True)
+        runs[name] = (cloud, radius, cloudcmp.camera_masks([r[2] for r in rows]))
+    (ck, rk, mk), (cl, rl, ml) = runs["kernel"], runs["literal"]
+    assert len(cl) >= 100
+    m = cloudcmp.cloud_metrics(ck, cl, rl, mk, ml)
+    print("\n%s kernel vs literal cloud:" % scene_name, json.dumps(m))
+    assert abs(m["count_ratio"] - 1.0) <= 0.03, m["count_ratio"]
+    for side in ("a_to_b", "b_to_a"):
+        assert m[side]["within_radius"] >= 0.95, (side, m[side])
+        assert m[side]["normal_angle_p95_rad"] <= 0.08, (side, m[side])
