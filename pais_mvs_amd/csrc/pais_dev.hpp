@@ -47,7 +47,16 @@ PAIS_HD uint32_t rand31(uint64_t seed, uint64_t key, uint32_t run, uint32_t k)
 }
 PAIS_HD double uniform_from(uint64_t base, uint32_t run, uint32_t k)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // r / 2147483647 without the division sequence (four uniforms per particle and iteration sit on the PSO chain): q0 = r * y with
+    // y = RN(1 / d), one fused correction step q1 = q0 + (r - q0 * d) * y.  Correctly rounded -- i.e. the bits of the division --
+    // for EVERY r in [0, 2^31): checked exhaustively (tests/test_detmath_and_devmath.py::test_uniform_without_division_is_the_division).
+    const double x = (double)rand31_from(base, run, k), d = 2147483647.0, y = 1.0 / 2147483647.0;
+    const double q0 = x * y;
+    return fma(fma(-q0, d, x), y, q0);
+#else
     return ((double)rand31_from(base, run, k)) / ((double)2147483647);
+#endif
 }
 PAIS_HD uint64_t child_key(uint64_t parentKey, int cam, int cx, int cy)
 {

@@ -616,13 +616,13 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             if ((a - part) % nparts != 0 || a < part) continue;
-            f4[a] = wave_sum(accF[a]);
-            w4[a] = wave_sum(accW[a]);
+            f4[a] = wave_sum_x(accF[a]);
+            w4[a] = wave_sum_x(accW[a]);
         }
     } else {
         for (int a = part; a < 4; a += nparts) {
-            f4[a] = wave_sum(myacc[a * 128]);
-            w4[a] = wave_sum(myacc[a * 128 + 64]);
+            f4[a] = wave_sum_x(myacc[a * 128]);
+            w4[a] = wave_sum_x(myacc[a * 128 + 64]);
         }
     }
     return 0;

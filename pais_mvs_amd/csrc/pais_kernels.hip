@@ -106,10 +106,39 @@ __device__ __forceinline__ double lane_get(double v, int src)
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), s), hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum(double v)
+__device__ __forceinline__ double wave_sum_x(double v);
+// the wave64 xor butterfly of every reduction of the path (m = 32, 16, ..., 1): wave_sum_x below computes it without the LDS crossbar
+// (round 4: six __shfl_xor = twelve ds_bpermute_b32 per sum)
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_x(v); }
+// The same xor butterfly (m = 32, 16, 8, 4, 2, 1: at every level a lane adds its partner's value, both partners get the same sum)
+// without the LDS crossbar -- round 5: the eight reductions of an evaluation were 96 ds_bpermute_b32, a quarter of its LDS
+// instructions and six dependent ~130-cycle round trips each.  gfx950: v_permlane32_swap / v_permlane16_swap exchange halves /
+// rows between two registers (given v twice they leave {v[l], v[l ^ m]} in some order in every lane: the sum is the same either
+// way, IEEE addition commutes); xor 8 is a row rotation by 8, xor 4 a half-row mirror followed by a quad reversal, xor 2 and 1
+// quad permutations: DPP operand modifiers of v_mov.  Same pairs, same sums, same bits.  ALL 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ double wsum_dpp(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double wave_sum_x(double v)
+{
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+    }
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+    }
+    v += wsum_dpp<0x128>(v);                  // row_ror:8          l ^ 8
+    v += wsum_dpp<0x1B>(wsum_dpp<0x141>(v));  // row_half_mirror, then quad_perm [3, 2, 1, 0]: l ^ 4
+    v += wsum_dpp<0x4E>(v);                   // quad_perm [2, 3, 0, 1]  l ^ 2
+    v += wsum_dpp<0xB1>(v);                   // quad_perm [1, 0, 3, 2]  l ^ 1
     return v;
 }
 __device__ __forceinline__ int wave_sum_i(int v)

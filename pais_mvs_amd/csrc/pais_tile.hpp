@@ -573,8 +573,8 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
             double f4[4], w4[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                f4[a] = wave_sum(accF[a]);
-                w4[a] = wave_sum(accW[a]);
+                f4[a] = wave_sum_x(accF[a]);
+                w4[a] = wave_sum_x(accW[a]);
             }
             if (lane == 0) A.fit[i] = combine_parts(f4, w4);
         }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the built library against pais_mvs_amd/csrc/variants/libpais_prev.so on one box: pawn bench, alternating
 out=gpurun_out/${1:-ab}; mkdir -p $out
-V=pais_mvs_amd/csrc/variants/libpais_prev.so
+V=${PREV_LIB:-pais_mvs_amd/csrc/variants/libpais_prev.so}
 if [ -n "$AB_TESTS" ]; then python -m pytest tests/test_gpu_parity.py tests/test_bench_parity.py -x -q -m gpu -k "$AB_TESTS" > $out/tests.log 2>&1; echo "tests rc $?" >> $out/tests.log; fi
 run() { name=$1; shift; envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   env "${envs[@]}" python bench.py --no-cpu-baseline "$@" > $out/$name.json 2> $out/$name.err

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the built library against pais_mvs_amd/csrc/variants/libpais_prev.so on one box, dome scene (seeds + R rounds), alternating
 out=gpurun_out/${1:-ab_dome}; mkdir -p $out; R=${2:-10}; B=${3:-4096}
-V=pais_mvs_amd/csrc/variants/libpais_prev.so
+V=${PREV_LIB:-pais_mvs_amd/csrc/variants/libpais_prev.so}
 run() { name=$1; shift; envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   env "${envs[@]}" python bench.py --no-cpu-baseline --scene dome --max-rounds $R --parents-per-round $B "$@" > $out/$name.json 2> $out/$name.err
   python - $out/$name.json $name <<'PY'
