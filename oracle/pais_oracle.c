@@ -808,7 +808,7 @@ static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const
 /* ------------------------------------------------------------------------ */
 double po_get_fitness(const po_scene *s, const po_patch *patch, const double pos[3])
 {
-    if (s->detMath || s->treeSum) return get_fitness_kernel(s, patch, pos); /* the two switches are set together */
+    if ((s->detMath || s->treeSum) && !s->costLiteral) return get_fitness_kernel(s, patch, pos); /* the two switches are set together */
     const int patchRadius = s->cfg.patchRadius;
     const int LOD = patch->LOD;
     const po_camera *refCam = &s->cams[patch->refCamIdx];

@@ -119,6 +119,11 @@ typedef struct po_scene {
                                           *     homography rows, the bilinear sum and the weighted accumulation.
                                           *  6 = another loop order AND another compiler: the closest like-for-like of what the
                                           *     kernel arithmetic changes (reduction order, fused multiply-adds). */
+    int        costLiteral;              /* with detMath / treeSum on: the COST (and only the cost) keeps the reference's statements and
+                                          * its x-outer / y-inner sequential sums (patch.cpp:979-1041), with po_detmath.h's exp / sin /
+                                          * cos -- what the HIP path computes under PAIS_ARITH=literal (pais_literal.hpp), bit for bit.
+                                          * Differs from the all-literal mode (all switches 0) by the libm and by the sums of setLOD /
+                                          * the NCC table, which the PSO trajectory does not depend on. */
 } po_scene;
 
 /* mvs/abstractpatch.h:22-53 + patch.h:19-20 */

@@ -47,6 +47,7 @@ class SceneS(C.Structure):
         ("cfg", Config), ("numCams", C.c_int), ("cams", C.POINTER(CameraS)), ("gauss", C.POINTER(C.c_double)),
         ("lodScale", C.c_double * MAX_LEVELS), ("seed", C.c_uint64), ("ompParticles", C.c_int),
         ("detMath", C.c_int), ("treeSum", C.c_int), ("windowPerParticle", C.c_int), ("literalVariant", C.c_int),
+        ("costLiteral", C.c_int),
     ]
 
 
@@ -323,6 +324,11 @@ class OracleScene:
         off: platform libm + the reference's sequential sums."""
         self.ptr.contents.detMath = 1 if on else 0
         self.ptr.contents.treeSum = 1 if on else 0
+
+    def set_cost_literal(self, on: bool):
+        """with kernel arithmetic on: the cost keeps the reference's statements and its sequential x-outer / y-inner sums (with the
+        deterministic exp / sin / cos) -- the checker of the HIP path's PAIS_ARITH=literal mode."""
+        self.ptr.contents.costLiteral = 1 if on else 0
 
     def set_literal_variant(self, v: int):
         """CONTROL experiments (pais_oracle.h po_scene.literalVariant, bit flags): 0 the reference's statements; 1 one rounding

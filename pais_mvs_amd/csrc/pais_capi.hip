@@ -112,6 +112,10 @@ struct pais_ctx {
                                         // 192 registers allow: they are built without an occupancy target, pais_kernels.hip PAIS_ITER_BOUNDS)
     int psoStreams = 2;
     int tileStrip2 = 14, tileStrip1 = 24; // 64-pixel steps per strip of the two instantiations (PAIS_TILE_STRIP2 / PAIS_TILE_STRIP1)
+    int arithLiteral = 0;               // PAIS_ARITH=literal: the cost in the reference's own statements and summation order (pais_literal.hpp);
+                                        // every batch then runs the launch-per-iteration pipeline k_pso_eval_lit + k_pso_step
+    int tileSplit = 1;                  // PAIS_TILE_SPLIT: 1 the sixteen-wave kernel (pais_tile2.hpp: a particle's cameras shared by two waves), 0 k_pso_tile
+    int tileStripSplit = 24, tileBias = 3; // PAIS_TILE_STRIP_SPLIT / PAIS_TILE_BIAS: its strip length; cameras the first half takes beyond an even share
     int tileForceNs1 = 0;               // PAIS_TILE_FORCE_NS1 (tests): the one-pixel instantiation also for batches of <= 32 cameras
     unsigned char *d_tileH = nullptr;   // homography scratch of the tile kernel (pais_tile.hpp PAIS_TILE_SCALAR_H): 16 regions of tileHSlice bytes
     size_t tileHBytes = 0, tileHSlice = 0;
@@ -409,6 +413,10 @@ static int ctx_init_work(pais_ctx *ctx)
     if (const char *e = getenv("PAIS_TILE_STRIP2")) { int v = atoi(e); if (v >= 2) ctx->tileStrip2 = v; }
     if (const char *e = getenv("PAIS_TILE_STRIP1")) { int v = atoi(e); if (v >= 1) ctx->tileStrip1 = v; }
     if (const char *e = getenv("PAIS_TILE_FORCE_NS1")) ctx->tileForceNs1 = atoi(e) != 0;
+    if (const char *e = getenv("PAIS_ARITH")) ctx->arithLiteral = (strcmp(e, "literal") == 0);
+    if (const char *e = getenv("PAIS_TILE_SPLIT")) ctx->tileSplit = atoi(e) != 0;
+    if (const char *e = getenv("PAIS_TILE_STRIP_SPLIT")) { int v = atoi(e); if (v >= 1) ctx->tileStripSplit = v; }
+    if (const char *e = getenv("PAIS_TILE_BIAS")) ctx->tileBias = atoi(e);
     if (const char *e = getenv("PAIS_TILE_ABOVE")) { long v = atol(e); if (v > 0) ctx->tileAbove = v; }
     HIPCHK(hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming));
     for (int i = 0; i + 1 < ctx->psoStreams; ++i) { // slice 0 runs on ctx->stream itself
@@ -665,7 +673,7 @@ extern "C" int pais_fitness_batch(pais_ctx *ctx, int n_states, const pais_patch_
     Timed tf;
     if (tf.begin(ctx, ctx->stream, &ctx->evEval)) return -2; // kernel-only time, reported as eval_ms / eval_launches
     HIPCHK(pais_launch::fitness(ctx->sc, ctx->d_states, n_states, ctx->d_idx, ctx->d_particles, ctx->d_out, n_evals, Kmax,
-                                ctx->d_evalBlocks, ctx->d_win, ctx->stream));
+                                ctx->d_evalBlocks, ctx->d_win, ctx->arithLiteral, ctx->stream));
     if (tf.end()) return -2;
     ctx->evalLaunches++;
     HIPCHK(hipMemcpyAsync(out, ctx->d_out, sizeof(double) * (size_t)n_evals, hipMemcpyDeviceToHost, ctx->stream));
@@ -702,6 +710,7 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
     const int nPlan = ctx->roundHint > n ? ctx->roundHint : n;
     P.useIter = Nmax <= 64 && (long)nPlan * Nmax < (tileOk ? ctx->tileAbove : ctx->splitAbove);
     P.useTile = tileOk && !P.useIter;
+    if (ctx->arithLiteral) P.useIter = P.useTile = false; // (and no ring below): k_pso_eval_lit + k_pso_step for every batch
     // the PSO pass as ONE launch over device-side task rings (k_pso_ring): host batches, device-pointer batches (the shards of
     // the multi-GPU drivers) and the passes of seed batches alike -- the error words are read at the batch's (pass's) next
     // synchronisation point and a pass that did not complete is re-run through the per-iteration launches (ring_failed below).
@@ -709,7 +718,7 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
     // cameras --, the more candidates it takes for throughput to dominate that chain: PAIS_RING_PER_CAM waves per iteration and camera)
     const long ringWaves = (long)(P.hasSeeds && pass > 0 ? againCount : n) * Nmax;
     const size_t ringNeed = pais_launch::ring_words(n, Nmax, P.maxIt) * sizeof(unsigned);
-    P.useRing = ctx->ringMode != 0 && !ctx->ringSuppressed && !P.useTile && Nmax <= 64 && n < (1 << 24) && ringNeed <= ctx->ringMaxBytes &&
+    P.useRing = ctx->ringMode != 0 && !ctx->arithLiteral && !ctx->ringSuppressed && !P.useTile && Nmax <= 64 && n < (1 << 24) && ringNeed <= ctx->ringMaxBytes &&
                 (P.hasSeeds ? (ctx->ringSeedAbove > 0 && ringWaves >= ctx->ringSeedAbove)
                             : (!P.useIter && ringWaves >= (long)(ctx->ringPerCam * P.Kmax)));
     // (the parts of a streamed round keep the per-iteration launches, which interleave on their lanes; two ring launches would
@@ -798,12 +807,15 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
                 // many cameras: footprints staged in LDS (pais_tile.hpp); the particles it flags take the checked walk
                 // (each slice's launches have their own region of the homography scratch: the slices run at the same time)
                 HIPCHK(pais_launch::pso_tile(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
-                                             ctx->d_win + P.WB * (size_t)q.lo, ctx->tileStrip2, ctx->tileStrip1, ctx->tileForceNs1,
+                                             ctx->d_win + P.WB * (size_t)q.lo, ctx->tileStrip2, ctx->tileStrip1, ctx->tileForceNs1, ctx->tileSplit,
+                                             ctx->tileStripSplit, ctx->tileBias,
                                              ctx->tileDebug ? ctx->d_stat + 8 : nullptr,
                                              (double *)((unsigned char *)ctx->d_tileH + ctx->tileHSlice * (size_t)k), ctx->tileHSlice, q.st));
                 HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
                                              ctx->d_win + P.WB * (size_t)q.lo, ctx->tileVerify ? 2 : 1, ctx->d_stat + 18, q.st));
-            } else
+            } else if (ctx->arithLiteral)
+                HIPCHK(pais_launch::pso_eval_literal(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo, q.st));
+            else
                 HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
                                              ctx->d_win + P.WB * (size_t)q.lo, 0, nullptr, q.st));
             if (te.end()) return -2;

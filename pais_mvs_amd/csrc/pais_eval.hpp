@@ -44,7 +44,9 @@ struct EvalPatch {
     int hasRef;         // the reference camera is among the visible ones (always, for patches refine() builds)
     int valid;          // the window lies inside [2, dim-3) of the reference level (patch.cpp:952-962)
     int LOD, refCam;
-    int pad16[2];       // sizeof % 16 == 0: EvalCam[] and the homographies behind it stay 16-byte aligned
+    int refPos;         // position in camIdx of the first occurrence of the reference camera (-1: none) -- the literal arithmetic
+                        // (pais_literal.hpp) adds the colours in camIdx order
+    int pad16;          // sizeof % 16 == 0: EvalCam[] and the homographies behind it stay 16-byte aligned
 };
 static_assert(sizeof(EvalPatch) % 16 == 0, "EvalPatch layout");
 struct WinPix {
@@ -207,6 +209,8 @@ __device__ void build_eval_block(const DevScene &sc, EvalPatch *ep, EvalCam *cam
         ep->M = __popcll(om);
         ep->K = K;
         ep->hasRef = firstRef >= 0 ? 1 : 0;
+        ep->refPos = firstRef;
+        ep->pad16 = 0;
         ep->valid = valid ? 1 : 0;
         ep->LOD = LOD;
         ep->refCam = refCam;

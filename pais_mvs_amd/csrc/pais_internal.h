@@ -86,7 +86,8 @@ namespace pais_launch {
 size_t eval_block_bytes_host(int Kmax);
 size_t win_bytes_per_candidate(const DevScene &sc);
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
-                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream);
+                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, int literal, hipStream_t stream);
+hipError_t pso_eval_literal(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, hipStream_t stream);
 hipError_t begin(const DevScene &sc, const pais_candidate *cands, pais_patch_result *recs, int n, unsigned char *states, int Nmax,
                  int *activeList, int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);
 hipError_t neighbor_count(const double *centers, int n, double radius, int32_t *counts, hipStream_t stream);
@@ -101,7 +102,9 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
                     int pendingOnly, unsigned long long *verify, hipStream_t stream);
 bool tile_eligible(int Kmax);
 hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int strip2, int strip1, int forceNs1, unsigned long long *dbg, double *hscr, size_t hscrBytes, hipStream_t stream);
+                    int strip2, int strip1, int forceNs1, int split, int stripSplit, int bias, unsigned long long *dbg, double *hscr,
+                    size_t hscrBytes, hipStream_t stream);
+                    // split: the sixteen-wave kernel of pais_tile2.hpp (strips of stripSplit steps, the first half's share `bias` cameras larger)
                     // hscr: per-launch scratch for the waves' homographies (pais_tile.hpp PAIS_TILE_SCALAR_H), hscrBytes of it
 hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *activeList, const int *activeCount, int listLo,
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,

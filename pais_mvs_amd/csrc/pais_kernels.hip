@@ -826,6 +826,8 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
 }
 
 #include "pais_tile.hpp"
+#include "pais_tile2.hpp"
+#include "pais_literal.hpp"
 
 // ------------------------------------------------------------- k_pso_iter ---
 // Default PSO pipeline: ONE launch per PSO iteration.  The wave of (candidate c, particle i) first replays
@@ -2162,13 +2164,22 @@ static hipError_t fitness_launch(const DevScene &sc, const int32_t *idx, const d
     return hipGetLastError();
 }
 hipError_t fitness(const DevScene &sc, const pais_patch_state *states, int nStates, const int32_t *idx, const double *particles,
-                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, hipStream_t stream)
+                   double *out, int nEvals, int Kmax, unsigned char *evalBlocks, void *win, int literal, hipStream_t stream)
 {
     if (nEvals <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_state_blocks, dim3(nStates < 65536 ? nStates : 65536), dim3(64), 0, stream, sc, states, nStates, evalBlocks,
                        eval_block_bytes(Kmax), (WinPix *)win);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (literal) { // PAIS_ARITH=literal (pais_literal.hpp)
+        static LdsAttr attr;
+        const size_t lds = literal_lds_bytes(Kmax);
+        e = attr.ensure((const void *)k_fitness_lit, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fitness_lit, dim3(nEvals < (1 << 20) ? nEvals : (1 << 20)), dim3(64), lds, stream, sc, idx, particles, out, nEvals, Kmax,
+                           evalBlocks, eval_block_bytes(Kmax));
+        return hipGetLastError();
+    }
     PAIS_SHAPE_DISPATCH(fitness_launch, sc, idx, particles, out, nEvals, Kmax, evalBlocks, win, stream);
 }
 
@@ -2249,6 +2260,18 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
 {
     PAIS_SHAPE_DISPATCH(pso_eval2_launch, sc, states, n, Nmax, Kmax, evalBlocks, win, pendingOnly, verify, stream);
 }
+// the evaluation launch of a PSO iteration under PAIS_ARITH=literal (pais_literal.hpp)
+hipError_t pso_eval_literal(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, hipStream_t stream)
+{
+    static LdsAttr attr;
+    const size_t lds = literal_lds_bytes(Kmax);
+    hipError_t e = attr.ensure((const void *)k_pso_eval_lit, lds);
+    if (e != hipSuccess) return e;
+    const long tasks = (long)n * Nmax;
+    hipLaunchKernelGGL(k_pso_eval_lit, dim3((unsigned)(tasks < (1 << 20) ? tasks : (1 << 20))), dim3(64), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax));
+    return hipGetLastError();
+}
 // many-camera batches: the tile kernel (pais_tile.hpp) can take the evaluation launch of the large-batch pipeline
 bool tile_eligible(int Kmax) { return eval_shape(Kmax) == 2 && Kmax <= TILE_MAX_CAMS; }
 template <int NS, int NP>
@@ -2275,9 +2298,32 @@ static hipError_t pso_tile_launch(const DevScene &sc, unsigned char *states, int
                        hscr);
     return hipGetLastError();
 }
-hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int strip2, int strip1, int forceNs1, unsigned long long *dbg, double *hscr, size_t hscrBytes, hipStream_t stream)
+// the split kernel (pais_tile2.hpp): sixteen waves, the cameras of a particle shared by two of them
+template <int NP>
+static hipError_t pso_tile2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
+                                   const void *win, int stripSteps, int bias, unsigned long long *dbg, hipStream_t stream)
 {
+    static LdsAttr attr;
+    const size_t lds = (160 * 1024) & ~(size_t)1023, fixed = tile2_fixed_lds_bytes(Kmax);
+    if (fixed + 4096 > lds) return hipErrorInvalidValue;
+    hipError_t e = attr.ensure((const void *)k_pso_tile2<NP>, lds);
+    if (e != hipSuccess) return e;
+    const int groups = (Nmax + TILE2_SLOTS - 1) / TILE2_SLOTS;
+    long grid = (long)n * groups;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL((k_pso_tile2<NP>), dim3((unsigned)grid), dim3(64 * TILE2_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+                       eval_block_bytes(Kmax), (const WinPix *)win, getenv("PAIS_TILE_NOTILES") ? 0 : (int)(lds - fixed), groups, stripSteps, bias, dbg);
+    return hipGetLastError();
+}
+hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
+                    int strip2, int strip1, int forceNs1, int split, int stripSplit, int bias, unsigned long long *dbg, double *hscr,
+                    size_t hscrBytes, hipStream_t stream)
+{
+    if (split) { // the colours of at most NP pairs per wave: Kmax <= 4 NP cameras, with room for the first half's larger share
+        if (Kmax <= 28) return pso_tile2_launch<8>(sc, states, n, Nmax, Kmax, evalBlocks, win, stripSplit, bias, dbg, stream);
+        if (Kmax <= 44) return pso_tile2_launch<12>(sc, states, n, Nmax, Kmax, evalBlocks, win, stripSplit, bias, dbg, stream);
+        return pso_tile2_launch<16>(sc, states, n, Nmax, Kmax, evalBlocks, win, stripSplit, bias, dbg, stream);
+    }
     // two pixels per lane while the colours of 2 x 32 cameras fit the registers; one pixel per lane beyond.  Strip lengths
     // swept on the full-size dome (profiles/r03_dome_tile_sweep.txt): 14 / 24 steps; longer strips = fewer barriers, until the
     // tiles of a strip stop fitting the tile area (cameras then tap global memory)

@@ -1,0 +1,474 @@
+// pais_tile2.hpp -- PAIS::getFitness (TMVS/mvs/patch.cpp:914-1047) for patches seen by MANY cameras: the LDS-tile kernel of
+// pais_tile.hpp with the cameras of a particle SPLIT over two waves (round 6).  Device-only; included by pais_kernels.hip
+// after pais_tile.hpp (whose staging -- boxes, layout, LDS-DMA -- it shares statement for statement).
+//
+// Why (profiles/r05_pmc_dome.txt).  k_pso_tile keeps the colours of ALL of a pixel's cameras in registers
+// (mean first, then sum |c - mean|: two passes over the same colours, patch.cpp:1022-1027): 128 VGPRs of colours, 256 VGPRs
+// per wave, 2 waves per SIMD -- and the walk is a chain of exposed LDS round trips (homography read -> 40 instructions ->
+// byte taps -> 100 instructions) that two waves cannot cover: SQ_WAIT_ANY 47-50 % of the wave cycles with the VALU 35-49 % and
+// the LDS pipe 18-31 % busy.  Six tunings of that kernel moved nothing.  What it needs is more waves per SIMD, i.e. fewer
+// colours per wave.
+//
+// Mapping.  One workgroup = one candidate x 8 particles of one PSO iteration as before, but SIXTEEN waves: particle slot
+// p = wave & 7 is served by wave p ("first half", role 0: camera pairs 0 .. pA-1) and wave p + 8 ("second half", role 1:
+// pairs pA .. nPairs-1 and the odd tail).  One pixel per lane; a wave holds at most 2 NP colours, <= 128 VGPRs, 4 waves per
+// SIMD (each SIMD gets two waves of either role).  The canonical arithmetic is sequential over the cameras (reference
+// first, then camIdx order: pais_eval.hpp) and is kept BIT FOR BIT; per 64-pixel step the two waves of a particle hand
+// over through two 512-byte LDS rows:
+//   1. both tap their cameras from the tiles; role 0 sums ref + its colours -> row 0;                         barrier
+//   2. role 1 continues that sum with its colours, mean = sum / K -> row 0;                                   barrier
+//   3. role 0 adds |ref - mean| and its |c - mean| -> row 1; role 1 meanwhile turns its colours into |c - mean|; barrier
+//   4. role 1 continues the SAD, weight = wStat * exp(-sad^2 / diffW), canonical sub-accumulators; role 0 is already
+//      tapping the next step.
+// Role 1 does steps 2 and 4 alone, so role 0 takes the larger share of the cameras (`bias`, in cameras).
+// Same results as k_pso_tile and as eval_window<1, false, true, true> (tests/test_gpu_parity.py:
+// test_dome_radius25_many_cameras, PAIS_TILE_VERIFY; the dome's cloud hash).
+#pragma once
+
+#define TILE2_WAVES 16
+#define TILE2_SLOTS 8 // particles of a workgroup
+#ifndef TILE2_NOSYNC
+#define TILE2_NOSYNC 0 // measurement builds, WRONG results: 1 the three hand-over barriers of a step removed (what they cost)
+#endif
+#if TILE2_NOSYNC
+#define TILE2_PHASE_BARRIER() wave_sync()
+#else
+#define TILE2_PHASE_BARRIER() __syncthreads()
+#endif
+
+__host__ __device__ inline size_t tile2_fixed_lds_bytes(int Kmax)
+{
+    size_t b = eval_block_bytes(Kmax);                                    // EvalPatch + EvalCam[Kmax], shared by the waves
+    b += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE2_SLOTS;     // homographies, per particle
+    b += 2 * sizeof(TileBox) * (size_t)Kmax;                              // boxes (two sets)
+    b += sizeof(double) * 64 * 2 * TILE2_SLOTS;                           // hand-over rows: 2 per particle
+    b += 64;                                                              // flags[0], pstate[8]
+    return (b + 15) & ~(size_t)15;
+}
+
+// pairs of cameras the first-half wave takes: its share is `bias` cameras larger than the second half's, which also does
+// steps 2 and 4 (NP: the colours of at most NP pairs fit a wave)
+__host__ __device__ inline int tile2_pairs_first(int M, int nPairs, int bias, int NP)
+{
+    int pA = (M + bias + 2) / 4;
+    if (pA > nPairs) pA = nPairs;
+    if (pA > NP) pA = NP;
+    if (nPairs - pA > NP) pA = nPairs - NP;
+    return pA < 0 ? 0 : pA;
+}
+
+// one camera group of the lane's pixel from the tiles: the statements of tile_tap_group<G, 1, false> without the running sum
+template <int G>
+__device__ __forceinline__ void tile2_tap_group(const DevScene &sc, const EvalCam *cams, const unsigned char *tiles, const double *Hbuf, int c0,
+                                                double &x, double &y, double *col)
+{
+    asm volatile("" : "+v"(x), "+v"(y));
+    double nx[G], ny[G], w[G], rw[G];
+    int tbase[G], ttw[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
+        const double2 hd = H2[3], he = H2[4];
+        w[u] = fma(hd.y, y, fma(hd.x, x, he.x));
+        tbase[u] = __double2loint(he.y);
+        ttw[u] = __builtin_amdgcn_readfirstlane(__double2hiint(he.y));
+        const double2 ha = H2[0], hb = H2[1], hc = H2[2];
+        nx[u] = fma(ha.y, y, fma(ha.x, x, hb.x));
+        ny[u] = fma(hc.x, y, fma(hb.y, x, hc.y));
+    }
+    if (G == 3) {
+        const double p01 = w[0] * w[G > 1 ? 1 : 0];
+        const double r = rcp_cr(p01 * w[G - 1]);
+        rw[G - 1] = r * p01;
+        const double r01 = r * w[G - 1];
+        rw[0] = r01 * w[G > 1 ? 1 : 0];
+        rw[G > 1 ? 1 : 0] = r01 * w[0];
+    } else if (G == 2) {
+        const double r = rcp_cr(w[0] * w[G - 1]);
+        rw[0] = r * w[G - 1];
+        rw[G - 1] = r * w[0];
+    } else {
+        rw[0] = rcp_cr(w[0]);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const double ix = nx[u] * rw[u], iy = ny[u] * rw[u];
+        const int px = (int)ix, py = (int)iy;
+        const double bx = __builtin_amdgcn_fract(ix), by = __builtin_amdgcn_fract(iy);
+        int a0, b0, a1, b1;
+        if (ttw[u] != 0) { // wave-uniform: the camera's tile is staged (four BYTE reads, see tile_tap_group)
+            const uint32_t a = (uint32_t)(tbase[u] + py * ttw[u] + px);
+            uint32_t ar = a + 1;
+            asm volatile("" : "+v"(ar));
+            a0 = tiles[a]; b0 = tiles[ar];
+            a1 = tiles[a + (uint32_t)ttw[u]]; b1 = tiles[ar + (uint32_t)ttw[u]];
+        } else {
+            TapInfo ti;
+            __builtin_memcpy(&ti, __builtin_assume_aligned(&cams[c0 + u].imgOff, 16), sizeof(ti));
+            const unsigned char *lvl = sc.imgBlob + ti.imgOff;
+            const uint32_t off = (uint32_t)py * (uint32_t)ti.w + (uint32_t)px;
+            const uint16_t r0 = load_row_at<uint16_t>(lvl, off), r1 = load_row_at<uint16_t>(lvl, off + (uint32_t)ti.w);
+            a0 = r0 & 0xff; b0 = r0 >> 8;
+            a1 = r1 & 0xff; b1 = r1 >> 8;
+        }
+        col[u] = lerp3((double)a0, (double)(b0 - a0), (double)a1, (double)(b1 - a1), bx, by);
+    }
+}
+
+// corners_inside (pais_eval.hpp) for the cameras [cLo, cHi) of a particle
+__device__ __forceinline__ bool corners_inside_range(const EvalPatch *ep, const EvalCam *cams, const double *Hbuf, int S, int lane, int cLo, int cHi)
+{
+    const int n4 = 4 * (cHi - cLo);
+    bool ok = true;
+    for (int t0 = 0; t0 < n4; t0 += 64) {
+        const int t = t0 + lane;
+        const int c = cLo + ((t < n4) ? (t >> 2) : 0), corner = t & 3;
+        const double x = ep->a0 + (double)((corner & 1) ? (S - 1) : 0), y = ep->b0 + (double)((corner & 2) ? (S - 1) : 0);
+        const double *H = Hbuf + PAIS_H_STRIDE * c;
+        const double w = fma(H[7], y, fma(H[6], x, H[8]));
+        const double rw = rcp_cr(w);
+        const double ix = fma(H[1], y, fma(H[0], x, H[2])) * rw, iy = fma(H[4], y, fma(H[3], x, H[5])) * rw;
+        const int qx = (int)ix, qy = (int)iy;
+        const uint32_t qp = cams[c].qpack;
+#if PAIS_CORNER_WTEST
+        bool in = qx >= 3 && qx < (int)(qp & 0xffffu) && qy >= 3 && qy < (int)(qp >> 16) && fabs(w) > 1e-90 && fabs(w) < 1e90;
+#else
+        bool in = qx >= 3 && qx < (int)(qp & 0xffffu) && qy >= 3 && qy < (int)(qp >> 16);
+#endif
+        const unsigned long long neg = __ballot(w < 0.0), pos = __ballot(w > 0.0);
+        const unsigned long long grp = 0xFull << (lane & ~3);
+        in = in && (((neg & grp) == 0) || ((pos & grp) == 0)) && (((neg | pos) & grp) == grp);
+        ok = ok && (in || t >= n4);
+    }
+    return __all(ok);
+}
+
+// Grid: candidates x particle groups of TILE2_SLOTS; workgroup of 16 waves.  Writes A.fit[i], or flags the particle pending
+// (A.part[i][0] = 1) for the pending-only k_pso_eval2 launch behind it -- the interface of k_pso_tile.
+template <int NP>
+__global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
+                                                               const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
+                                                               int tileBytes, int groups, int stripSteps, int bias, unsigned long long *dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = wave & (TILE2_SLOTS - 1), role = wave >> 3; // (a SIMD's waves w, w + 4, w + 8, w + 12: two of either role)
+    EvalPatch *ep = (EvalPatch *)smem;
+    EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
+    size_t o = eval_block_bytes(Kmax);
+    double *Hbuf = (double *)(smem + o) + (size_t)slot * Kmax * PAIS_H_STRIDE; o += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE2_SLOTS;
+    TileBox *boxAll = (TileBox *)(smem + o);                                    o += 2 * sizeof(TileBox) * (size_t)Kmax; // [2][Kmax]
+    double *row0 = (double *)(smem + o) + (size_t)slot * 128 + lane;            // sum of the first half, then the mean
+    double *row1 = row0 + 64;                                                   // SAD of the first half
+    o += sizeof(double) * 64 * 2 * TILE2_SLOTS;
+    int *flags = (int *)(smem + o);                                             // [0]: some particle of the group walks the tiles
+    int *pstate = flags + 1;                                                    // [slot]: != 0: the particle takes the checked walk (pending)
+    unsigned char *tiles = smem + tile2_fixed_lds_bytes(Kmax);
+    const size_t SB = pso_state_bytes(Nmax);
+    const int WS = win_stride(sc);
+    const int S = sc.cfg.patchSize, S2 = S * S;
+    const int nSteps = (S2 + 63) >> 6;
+    const int nwMax = (int)(eval_block_bytes(Kmax) / 8);
+
+    for (int task = blockIdx.x; task < n * groups; task += gridDim.x) {
+        const int c = task / groups, g = task - c * groups;
+        const int i = g * TILE2_SLOTS + slot; // this wave's particle
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        const int active = hd->active, Nrun = hd->N;
+        if (!active || g * TILE2_SLOTS >= Nrun) continue; // uniform over the workgroup
+        const bool have = i < Nrun;
+        const int iLoad = have ? i : 0;
+        const double theta = A.pos[iLoad][0], phi = A.pos[iLoad][1], depth = A.pos[iLoad][2];
+        __syncthreads(); // the previous task's LDS is no longer read
+        {
+            const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+            uint64_t *dst = (uint64_t *)smem;
+            for (int q = threadIdx.x; q < nwMax; q += 64 * TILE2_WAVES) dst[q] = src[q];
+            for (int q = threadIdx.x; q < 2 * Kmax; q += 64 * TILE2_WAVES) boxAll[q] = TileBox{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
+            if (threadIdx.x < 1 + TILE2_SLOTS) flags[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        const int M = ep->M, K = ep->K;
+        const WinPix *wbase = win + (size_t)c * WS;
+        // cameras 0 .. 2 nPairs - 1 in pairs, then a tail of 3, 1 or 0 (the groups of the kernel arithmetic, pais_eval.hpp);
+        // the first-half wave takes pairs 0 .. pA - 1, the second-half wave the rest
+        const int nPairs = (M >= 2) ? ((M & 1) ? (M - 3) / 2 : M / 2) : 0;
+        const int tail0 = 2 * nPairs, nTail = M - tail0;
+        const int pA = tile2_pairs_first(M, nPairs, bias, NP);
+        const int cLo = role ? 2 * pA : 0, cHi = role ? M : 2 * pA; // this wave's cameras
+        const int myPairs = role ? (nPairs - pA) : pA;
+
+        // ---- the particle: normal, early exits, this wave's homographies (the statements of eval_fitness_parts)
+        bool bad = false;
+        if (have) {
+            double nrm[3];
+            wave_spherical2normal(theta, phi, nrm, lane);
+            const double on[3] = {ep->optNref[0], ep->optNref[1], ep->optNref[2]};
+            if (dot3(nrm, on) > 0 || !ep->valid || !(fabs(depth) > 0)) {
+                bad = true;
+            } else {
+                double center[3];
+                for (int q = 0; q < 3; ++q) center[q] = ep->ray[q] * depth + ep->Cref[q];
+                const double d = -dot3(center, nrm);
+                double Mref[9], invH[9], kr[9], kt[3];
+                for (int q = 0; q < 9; ++q) kr[q] = ep->KRref[q];
+                for (int q = 0; q < 3; ++q) kt[q] = ep->KTref[q];
+                plane_matrix(d, ep->lodScale, kr, kt, nrm, Mref);
+                inv3(Mref, invH);
+                for (int cc = cLo + lane; cc < cHi; cc += 64) {
+                    double H[9];
+                    if (cams[cc].cam == ep->refCam) {
+                        H[0] = 1; H[1] = 0; H[2] = 0; H[3] = 0; H[4] = 1; H[5] = 0; H[6] = 0; H[7] = 0; H[8] = 1;
+                    } else {
+                        double Mc[9];
+                        for (int q = 0; q < 9; ++q) kr[q] = cams[cc].KR[q];
+                        for (int q = 0; q < 3; ++q) kt[q] = cams[cc].KT[q];
+                        plane_matrix(d, ep->lodScale, kr, kt, nrm, Mc);
+                        mul33(Mc, invH, H);
+                    }
+                    for (int q = 0; q < 9; ++q) Hbuf[cc * PAIS_H_STRIDE + q] = H[q];
+                }
+                wave_sync();
+                if (!corners_inside_range(ep, cams, Hbuf, S, lane, cLo, cHi) && lane == 0) atomicOr(&pstate[slot], 1);
+            }
+        }
+        __syncthreads();
+        // 0: walks the tiles, 1: DBL_MAX, 2: pending (checked walk by k_pso_eval2), 3: no particle -- the same in both waves of a slot
+        const int state = !have ? 3 : (bad ? 1 : (pstate[slot] ? 2 : 0));
+        if (lane == 0 && have) {
+            if (role == 1) {
+                if (state == 1) A.fit[i] = DBL_MAX;
+                A.part[i][0] = (state == 2) ? 1.0 : 0.0;
+                if (dbg) atomicAdd(&dbg[state], 1ULL); // [0] particles through the tiles, [1] DBL_MAX, [2] pending
+            }
+            if (state == 0) flags[0] = 1;
+        }
+        __syncthreads();
+        if (!flags[0]) continue; // nobody walks the tiles (uniform)
+
+        const double a0 = uniform_d(ep->a0), b0 = uniform_d(ep->b0);
+        const double invDiffW = uniform_d(1.0 / sc.cfg.diffWeighting);
+        const bool useDiff = sc.cfg.adaptiveDifferenceEnable != 0;
+        const bool hasRef = ep->hasRef != 0;
+        const double invK = uniform_d(1.0 / (double)K);
+        double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0}; // (second-half wave)
+
+        // stage(strip): boxes -> layout -> LDS-DMA of the strip's tiles (pais_tile.hpp, the same statements; this wave's cameras
+        // only in the box pass, the copy dealt to sixteen waves).  One workgroup barrier inside; every wave calls it alike.
+        auto stage = [&](int s0, int par) {
+            const int s1 = min(s0 + stripSteps, nSteps);
+            TileBox *box = boxAll + par * Kmax;
+            if (state == 0) {
+                const int ya = (64 * s0) / S, yb = (min(64 * s1, S2) - 1) / S;
+                for (int cc = cLo + lane; cc < cHi; cc += 64) {
+                    const double *H = Hbuf + PAIS_H_STRIDE * cc;
+                    int xmin = INT_MAX, ymin = INT_MAX, xmax = INT_MIN, ymax = INT_MIN;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double x = a0 + (double)((k & 1) ? (S - 1) : 0), y = b0 + (double)((k & 2) ? yb : ya);
+                        const double rw = rcp_cr(fma(H[7], y, fma(H[6], x, H[8])));
+                        const int qx = (int)(fma(H[1], y, fma(H[0], x, H[2])) * rw), qy = (int)(fma(H[4], y, fma(H[3], x, H[5])) * rw);
+                        xmin = min(xmin, qx); xmax = max(xmax, qx);
+                        ymin = min(ymin, qy); ymax = max(ymax, qy);
+                    }
+                    atomicMin(&box[cc].xmin, xmin); atomicMin(&box[cc].ymin, ymin);
+                    atomicMax(&box[cc].xmax, xmax); atomicMax(&box[cc].ymax, ymax);
+                }
+            }
+            __syncthreads(); // the boxes are complete -- and every wave has finished the strip before this one
+            int x0 = 0, y0 = 0, tw = 0, th = 0;
+            if (lane < M && box[lane].xmax >= box[lane].xmin) {
+                const int lw = cams[lane].w, lh = cams[lane].h;
+                x0 = max(box[lane].xmin - 1, 0); y0 = max(box[lane].ymin - 1, 0);
+                const int x1 = min(box[lane].xmax + 2, lw - 1), y1 = min(box[lane].ymax + 2, lh - 1);
+                tw = max(((x1 - x0 + 1) + 3) & ~3, 8);
+                th = y1 - y0 + 1;
+            }
+            const int szFull = (th > 0 && tw > (tileBytes + 1) / th) ? tileBytes + 1 : tw * th;
+            const int sz = min(szFull, tileBytes + 1);
+            int incl = sz;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const int up = __shfl_up(incl, m, 64);
+                incl = min(incl + ((lane >= m) ? up : 0), tileBytes + 1);
+            }
+            const int off = incl - sz;
+            const bool fits = sz > 0 && incl <= tileBytes;
+            if (!fits) { tw = 0; th = 0; }
+            if (lane < M) {
+                // (the tile word of camera `lane` goes into this particle's record of it: written by the wave that taps it)
+                if (lane >= cLo && lane < cHi) Hbuf[lane * PAIS_H_STRIDE + 9] = __hiloint2double(tw, fits ? (off - y0 * tw - x0) : 0);
+                if (wave == 0) {
+                    boxAll[(par ^ 1) * Kmax + lane] = TileBox{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
+                    if (dbg && sz > 0) atomicAdd(&dbg[fits ? 3 : 4], 1ULL); // [3] tiles staged, [4] cameras left in global memory
+                    if (dbg && fits) atomicAdd(&dbg[5], (unsigned long long)sz); // [5] bytes staged
+                }
+            }
+            int inFlight = 0;
+            for (int cc = wave; cc < M; cc += TILE2_WAVES) {
+                const int ctw = __shfl(tw, cc, 64), cth = __shfl(th, cc, 64);
+                const int cx0 = __shfl(x0, cc, 64), cy0 = __shfl(y0, cc, 64), coff = __shfl(off, cc, 64);
+                if (ctw == 0) continue;
+                const uint32_t twd = (uint32_t)ctw >> 2, J = twd * (uint32_t)cth;
+                const int need = (int)((J + 63) >> 6);
+                if (inFlight + need > 48) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    inFlight = 0;
+                }
+                inFlight += need;
+                const uint32_t magic = 0xFFFFFFFFu / twd + 1; // j / twd == umulhi(j, magic) for j * twd < 2^32
+                const unsigned char *lvl = sc.imgBlob + cams[cc].imgOff + (size_t)(uint32_t)cy0 * (uint32_t)cams[cc].w + (uint32_t)cx0;
+                const uint32_t lw = (uint32_t)cams[cc].w;
+                const unsigned ldsTile = (unsigned)(uintptr_t)(tiles + coff);
+                for (uint32_t j0 = 0; j0 < J; j0 += 64) {
+                    const uint32_t j = j0 + lane;
+                    if (j < J) {
+                        const uint32_t row = __umulhi(j, magic), dd = j - row * twd;
+                        const unsigned char *gsrc = lvl + (size_t)row * lw + 4 * dd;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ldsTile + 4 * j0);
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+                    }
+                }
+            }
+        };
+
+        const unsigned long long tc0 = dbg ? __builtin_readcyclecounter() : 0;
+        unsigned long long tWalk = 0;
+        int sIdx = 0;
+        for (int s0 = 0; s0 < nSteps; s0 += stripSteps, ++sIdx) {
+            const int s1 = min(s0 + stripSteps, nSteps);
+            stage(s0, sIdx & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's LDS-DMA has landed ...
+            __syncthreads();                                  // ... everybody's has
+            const unsigned long long tc3 = dbg ? __builtin_readcyclecounter() : 0;
+            const int kpix = 64 * s0 + lane;
+            int yw = kpix / S, xw = kpix - yw * S;
+            const int qA = 64 / S, rA = 64 - qA * S;
+            const double xs = a0 + (double)((64 * s0) % S), ys = b0 + (double)((64 * s0) / S); // the strip's first pixel
+            for (int st = s0; st < s1; ++st) {
+                double col[2 * NP], t3[3] = {0, 0, 0};
+                double refCol = 0, wStat = -1.0;
+                // ---- 1. this wave's taps of the step
+                if (state == 0) {
+                    const WinPix wp = wbase[64 * st + lane]; // (the padding lanes of the last step are masked entries)
+                    refCol = wp.refCol;
+                    wStat = wp.wStat;
+                    // lanes without a pixel tap the strip's first pixel: an address inside the tiles
+                    const bool nopix = 64 * st + lane >= S2;
+                    double x = nopix ? xs : a0 + (double)xw, y = nopix ? ys : b0 + (double)yw;
+                    xw += rA; yw += qA;
+                    yw += (xw >= S) ? 1 : 0;
+                    xw -= (xw >= S) ? S : 0;
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        if (u < myPairs) tile2_tap_group<2>(sc, cams, tiles, Hbuf, cLo + 2 * u, x, y, &col[2 * u]);
+                        else col[2 * u] = col[2 * u + 1] = 0;
+                    }
+                    if (role == 1) {
+                        if (nTail == 3) tile2_tap_group<3>(sc, cams, tiles, Hbuf, tail0, x, y, t3);
+                        else if (nTail == 1) tile2_tap_group<1>(sc, cams, tiles, Hbuf, tail0, x, y, t3);
+                    } else {
+                        double s = hasRef ? refCol : 0.0;
+#pragma unroll
+                        for (int u = 0; u < NP; ++u)
+                            if (u < myPairs) {
+                                s += col[2 * u];
+                                s += col[2 * u + 1];
+                            }
+                        *row0 = s;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2 * NP; ++u) col[u] = 0;
+                }
+                TILE2_PHASE_BARRIER();
+                // ---- 2. second half: the sum continued, the mean
+                double mean = 0;
+                if (state == 0 && role == 1) {
+                    double s = *row0;
+#pragma unroll
+                    for (int u = 0; u < NP; ++u)
+                        if (u < myPairs) {
+                            s += col[2 * u];
+                            s += col[2 * u + 1];
+                        }
+                    if (nTail >= 1) s += t3[0];
+                    if (nTail == 3) {
+                        s += t3[1];
+                        s += t3[2];
+                    }
+                    mean = s * invK;
+                    *row0 = mean;
+                }
+                TILE2_PHASE_BARRIER();
+                // ---- 3. first half: its share of the SAD; second half: |c - mean| in place
+                if (state == 0) {
+                    if (role == 0) {
+                        mean = *row0;
+                        double sad = hasRef ? fabs(refCol - mean) : 0.0;
+#pragma unroll
+                        for (int u = 0; u < NP; ++u)
+                            if (u < myPairs) {
+                                sad += fabs(col[2 * u] - mean);
+                                sad += fabs(col[2 * u + 1] - mean);
+                            }
+                        *row1 = sad;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < NP; ++u)
+                            if (u < myPairs) {
+                                col[2 * u] = fabs(col[2 * u] - mean);
+                                col[2 * u + 1] = fabs(col[2 * u + 1] - mean);
+                            }
+                        t3[0] = fabs(t3[0] - mean); t3[1] = fabs(t3[1] - mean); t3[2] = fabs(t3[2] - mean);
+                    }
+                }
+                TILE2_PHASE_BARRIER();
+                // ---- 4. second half: the SAD continued, the weight, the canonical sub-accumulator of the step
+                if (state == 0 && role == 1) {
+                    double sad = *row1;
+#pragma unroll
+                    for (int u = 0; u < NP; ++u)
+                        if (u < myPairs) {
+                            sad += col[2 * u];
+                            sad += col[2 * u + 1];
+                        }
+                    if (nTail >= 1) sad += t3[0];
+                    if (nTail == 3) {
+                        sad += t3[1];
+                        sad += t3[2];
+                    }
+                    const bool act = wStat >= 0.0;
+                    const double sadq = sad * invK;
+                    double weight = wStat;
+                    if (useDiff) weight *= det_exp_poly(mul_uniform(-(sadq * sadq), invDiffW));
+                    const int ga = st & 3; // (uniform)
+#define PAIS_TACC(a)                                          \
+    {                                                         \
+        accW[a] = act ? (accW[a] + weight) : accW[a];         \
+        accF[a] = act ? fma(weight, sadq, accF[a]) : accF[a]; \
+    }
+                    if (ga == 0) PAIS_TACC(0) else if (ga == 1) PAIS_TACC(1) else if (ga == 2) PAIS_TACC(2) else PAIS_TACC(3)
+#undef PAIS_TACC
+                }
+            }
+            if (dbg) tWalk += __builtin_readcyclecounter() - tc3;
+        }
+        if (dbg && threadIdx.x == 0) {
+            atomicAdd(&dbg[6], __builtin_readcyclecounter() - tc0 - tWalk); // staging (boxes, layout, DMA issue, barriers) ...
+            atomicAdd(&dbg[9], tWalk);                                      // ... and the walks of wave 0
+        }
+        if (state == 0 && role == 1) {
+            double f4[4], w4[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f4[a] = wave_sum_x(accF[a]);
+                w4[a] = wave_sum_x(accW[a]);
+            }
+            if (lane == 0) A.fit[i] = combine_parts(f4, w4);
+        }
+    }
+}

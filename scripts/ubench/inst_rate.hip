@@ -111,6 +111,82 @@ __global__ __launch_bounds__(256) void k_lds_lane(double *out, long long *cyc)
     out[blockIdx.x * 256 + threadIdx.x] = 0;
 }
 
+// LDS: wave-uniform 16-byte reads (a camera's homography record in the tile kernels: five per camera and trip)
+__global__ __launch_bounds__(256) void k_lds_b128_bcast(double *out, long long *cyc)
+{
+    __shared__ __attribute__((aligned(16))) double buf[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) buf[i] = i;
+    __syncthreads();
+    long long t0 = clock64();
+    for (int it = 0; it < ITER; ++it) {
+        const int o = (it & 31) * 128;
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i v0, v1, v2, v3, v4, v5, v6, v7;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(o));
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(v1) : "v"(o));
+        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(v2) : "v"(o));
+        asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(v3) : "v"(o));
+        asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(v4) : "v"(o));
+        asm volatile("ds_read_b128 %0, %1 offset:80" : "=v"(v5) : "v"(o));
+        asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(v6) : "v"(o));
+        asm volatile("ds_read_b128 %0, %1 offset:112" : "=v"(v7) : "v"(o));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
+    }
+    long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+    out[blockIdx.x * 256 + threadIdx.x] = 0;
+}
+// LDS: byte reads at scattered per-lane addresses (the bilinear taps from the tiles: a smooth map of the window pixels -- lanes
+// of a row 1..2 bytes apart, rows a tile stride apart)
+__global__ __launch_bounds__(256) void k_lds_u8_taps(double *out, long long *cyc)
+{
+    __shared__ unsigned char buf[16384];
+    for (int i = threadIdx.x; i < 16384; i += 256) buf[i] = (unsigned char)i;
+    __syncthreads();
+    long long t0 = clock64();
+    const int l = threadIdx.x & 63;
+    const int a0 = ((l % 51) * 5) / 4 + (l / 51) * 84; // ~1.25 bytes per window pixel along a row, 84-byte tile stride
+    int acc = 0;
+    for (int it = 0; it < ITER; ++it) {
+        const int o = a0 + (it & 63) * 100;
+        int v0, v1, v2, v3, v4, v5, v6, v7;
+        asm volatile("ds_read_u8 %0, %1" : "=v"(v0) : "v"(o));
+        asm volatile("ds_read_u8 %0, %1 offset:1" : "=v"(v1) : "v"(o));
+        asm volatile("ds_read_u8 %0, %1 offset:84" : "=v"(v2) : "v"(o));
+        asm volatile("ds_read_u8 %0, %1 offset:85" : "=v"(v3) : "v"(o));
+        asm volatile("ds_read_u8 %0, %1 offset:4096" : "=v"(v4) : "v"(o));
+        asm volatile("ds_read_u8 %0, %1 offset:4097" : "=v"(v5) : "v"(o));
+        asm volatile("ds_read_u8 %0, %1 offset:4180" : "=v"(v6) : "v"(o));
+        asm volatile("ds_read_u8 %0, %1 offset:4181" : "=v"(v7) : "v"(o));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
+    }
+    long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+#define RDL(i) { int t_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(t_) : "v"(ia)); asm volatile("" :: "s"(t_)); }
+KERNEL(k_readlane, DECL_D, REP8(RDL))
+// s_barrier of a 16-wave workgroup (one per CU): cycles per barrier when every wave arrives at once
+__global__ __launch_bounds__(1024) void k_barrier16(double *out, long long *cyc)
+{
+    long long t0 = clock64();
+    for (int it = 0; it < ITER; ++it) {
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+    }
+    long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+    if (threadIdx.x < 256) out[blockIdx.x * 256 + threadIdx.x] = 0;
+}
+
 typedef void (*kern_t)(double *, long long *);
 int main()
 {
@@ -127,7 +203,8 @@ int main()
         {"v_rcp_f64", k_rcp}, {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_cvt_f64_u32", k_cvt_f64_u32},
         {"v_cvt_i32_f64", k_cvt_i32_f64}, {"v_div_scale_f64", k_div_scale}, {"v_div_fixup_f64", k_div_fixup}, {"v_div_fmas_f64", k_div_fmas},
         {"v_med3_i32", k_med3_i32}, {"v_mad_u64_u32", k_mad_u64_u32}, {"v_sub_f32", k_sub_f32}, {"v_mov_b64", k_mov_b64},
-        {"v_cndmask_b32", k_cndmask}, {"v_cmp_lt_f64", k_cmp_f64}, {"ds_read_b64 broadcast", k_lds_bcast}, {"ds_read_b64 per-lane", k_lds_lane}};
+        {"v_cndmask_b32", k_cndmask}, {"v_cmp_lt_f64", k_cmp_f64}, {"ds_read_b64 broadcast", k_lds_bcast}, {"ds_read_b64 per-lane", k_lds_lane},
+        {"ds_read_b128 broadcast", k_lds_b128_bcast}, {"ds_read_u8 tile taps", k_lds_u8_taps}, {"v_readlane_b32", k_readlane}};
     printf("%d CUs; cycles per wave64 instruction per SIMD with 4 waves/SIMD (clock64 ticks = shader cycles)\n", cus);
     for (auto &t : T) {
         for (int rep = 0; rep < 2; ++rep) {
@@ -137,5 +214,13 @@ int main()
         hipMemcpy(&h, cyc, sizeof(h), hipMemcpyDeviceToHost);
         printf("%-24s %6.2f\n", t.n, (double)h / ((double)ITER * 8 * 4));
     }
+    // (LDS rows above: 16 waves of a CU share ONE LDS pipe -- the figure is cycles per instruction per SIMD with all four SIMDs
+    //  issuing, i.e. a quarter of the pipe each: cycles per instruction of the CU's LDS pipe = the figure / 4)
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(k_barrier16, dim3(cus), dim3(1024), 0, 0, out, cyc);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(&h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    printf("%-24s %6.2f   (cycles per s_barrier of a 16-wave workgroup, every wave arriving at once)\n", "s_barrier x16 waves", (double)h / ((double)ITER * 8));
     return 0;
 }

@@ -246,8 +246,13 @@ def literal_control(cfg, scene, kept_c, threads=None, is_seed=False):
     S.set_literal_variant(0)
     S.set_kernel_arithmetic(True)
     runs["kernel"] = oracle_refine_many(S, kept_c, is_seed, threads)
+    # the HIP path's PAIS_ARITH=literal (pais_literal.hpp): the cost in the reference's statements and summation ORDER, with the
+    # deterministic exp / sin / cos; everything outside the cost as in kernel arithmetic
+    S.set_cost_literal(True)
+    runs["cost_literal"] = oracle_refine_many(S, kept_c, is_seed, threads)
+    S.set_cost_literal(False)
     S.close()
-    out = {"kernel": trajectory_split(runs[0], runs["kernel"])}
+    out = {"kernel": trajectory_split(runs[0], runs["kernel"]), "cost_literal": trajectory_split(runs[0], runs["cost_literal"])}
     for v in CONTROL_VARIANTS:
         out["variant_%d" % v] = trajectory_split(runs[0], runs[v])
     # which candidates branch: is it the same set under every perturbation?

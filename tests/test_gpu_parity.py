@@ -108,6 +108,77 @@ def test_fitness_batch_matches_oracle(pawn_small, weights):
     ctx.close()
 
 
+@pytest.mark.parametrize("scene_name", ["pawn_small", "ring_small", "dome_small"])
+def test_literal_arithmetic_cost_is_the_reference_statement(request, scene_name, monkeypatch):
+    """PAIS_ARITH=literal (pais_literal.hpp, round 6): the cost with the reference's per-pixel expressions (no fused
+    multiply-adds, a true division per tap, the four-product bilinear of patch.cpp:1014-1017, mean /= K) and its x-outer /
+    y-inner SEQUENTIAL sums (patch.cpp:979-1041), the window from the particle's own centre.  Checker: the oracle's literal
+    statements of po_get_fitness with the deterministic exp / sin / cos (po_scene.costLiteral) -- bit for bit; against the
+    all-literal oracle (platform libm) the values differ by the libm's last bits only (<= 1e-13 relative)."""
+    from pais_mvs_amd.config import readme_config
+    scene = request.getfixturevalue(scene_name)
+    if scene_name == "dome_small":
+        cfg = readme_config(patchRadius=25, distWeighting=25 / 3.0, reduceNormalRange=4.0, adaptiveGradientEnable=True)
+    else:
+        cfg = readme_config(adaptiveGradientEnable=(scene_name == "ring_small"))
+    monkeypatch.setenv("PAIS_ARITH", "literal")
+    S = common.oracle_scene(cfg, scene)
+    ctx = _ctx(cfg, scene)
+    rng = np.random.default_rng(11)
+    states, pats, idx, parts = _states_and_particles(S, scene, rng, n_per=12 if scene_name == "dome_small" else 24)
+    got = ctx.fitness_batch(states, idx, parts)
+    n_max = n_fin = 0
+    worst = 0.0
+    for e, (si, pos) in enumerate(zip(idx, parts)):
+        S.set_kernel_arithmetic(False)
+        S.set_cost_literal(False)
+        lit = S.fitness(pats[si], pos)
+        S.set_kernel_arithmetic(True)
+        S.set_cost_literal(True)
+        want = S.fitness(pats[si], pos)
+        assert common.same_value(got[e], want, RTOL_EXACT), (e, got[e], want, got[e] - want)
+        if want == DBL_MAX:
+            n_max += 1
+            assert lit == DBL_MAX
+        elif want == want:
+            n_fin += 1
+            worst = max(worst, abs(got[e] - lit) / abs(lit))
+    assert n_max > 5 and n_fin > 30, (n_max, n_fin)
+    assert worst <= 1e-13, worst
+    ctx.close()
+
+
+def test_literal_arithmetic_refine_is_the_reference_order_run(pawn_small, monkeypatch):
+    """Whole refine() runs under PAIS_ARITH=literal -- seeds and first-ring children of the 320x240 pawn scene -- ARE the
+    oracle's runs with the literal cost (po_scene.costLiteral) bit for bit, and are held to north_star's gate against the
+    all-literal oracle (platform libm, sequential sums everywhere) like the default arithmetic is: discrete outputs identical,
+    centre / normal within 1e-12 on the literal run's trajectory, branched trajectories counted (printed; the default
+    arithmetic branches 23 of these 211 candidates)."""
+    from pais_mvs_amd.config import readme_config
+    from pais_mvs_amd.context import make_candidate
+    from tests.test_oracle_modes import refine_pairs, mode_statistics, assert_north_star_parity, PAWN_BRANCHED_CAP
+    cfg = readme_config()
+    monkeypatch.setenv("PAIS_ARITH", "literal")
+    S = common.oracle_scene(cfg, pawn_small)
+    S.set_omp(True)
+    ctx = _ctx(cfg, pawn_small)
+
+    def gpu(seeds_in, child_in):
+        cands = [make_candidate(cen, nrm, cams, key, 0, normalS=ns) for cen, nrm, ns, cams, key in seeds_in]
+        for cen, nrm, cams, key in child_in:
+            child = S.expand_patch(cen, nrm, cams, key)
+            cands.append(make_candidate(child.center[:], child.normal[:], child.cams(), key, 1, normalS=child.normalS[:]))
+        return list(ctx.refine_batch(cands))
+
+    S.set_cost_literal(True)          # (only read in kernel arithmetic: refine_pairs' second run)
+    lit, ker, got = refine_pairs(S, pawn_small, cfg, run_b=gpu)
+    S.set_cost_literal(False)
+    st = mode_statistics(lit, ker, hip=got)     # (asserts HIP == oracle with the literal cost, bit for bit)
+    print("\nHIP path, PAIS_ARITH=literal, vs the all-literal oracle, pawn:", st)
+    assert_north_star_parity(st, 150, PAWN_BRANCHED_CAP)
+    ctx.close()
+
+
 def _compare_patch(r, p, what):
     assert bool(r.dropped) == bool(p.drop), (what, r.dropped, p.drop)
     if p.drop:
@@ -503,7 +574,8 @@ def test_bench_refuses_a_rank_count_it_cannot_run():
     assert r.returncode != 0 and "n_gpus" not in r.stdout
 
 
-@pytest.mark.parametrize("tile", ["tile kernel for every batch", "tile kernel, one pixel per lane, one-row last strip", "one wave per evaluation"])
+@pytest.mark.parametrize("tile", ["tile kernel, cameras split over two waves", "tile kernel, cameras split unevenly, one-row last strip",
+                                  "tile kernel for every batch", "tile kernel, one pixel per lane, one-row last strip", "one wave per evaluation"])
 def test_dome_radius25_many_cameras(dome_small, monkeypatch, capfd, tile):
     """Config-4-like parameters: patchRadius 25 (S^2 = 2601), reduceNormalRange 4, all weights, many visible
     cameras per patch.  Cost + seeds + a few expansion rounds against the oracle, bit for bit -- through the LDS-tile
@@ -513,6 +585,12 @@ def test_dome_radius25_many_cameras(dome_small, monkeypatch, capfd, tile):
     if tile.startswith("tile"):
         monkeypatch.setenv("PAIS_TILE", "2")            # (by default only scenes too large for the float tap copy take it)
         monkeypatch.setenv("PAIS_TILE_ABOVE", "1")
+        # round 6: the sixteen-wave kernel (pais_tile2.hpp: a particle's cameras shared by two waves, sums handed over in LDS)
+        # is the default; k_pso_tile stays selectable
+        monkeypatch.setenv("PAIS_TILE_SPLIT", "1" if "split" in tile else "0")
+        if "unevenly" in tile:
+            monkeypatch.setenv("PAIS_TILE_STRIP_SPLIT", "4")
+            monkeypatch.setenv("PAIS_TILE_BIAS", "11")
         if "one pixel" in tile:
             # the instantiation of batches of more than 32 cameras, with strips of 4 steps: the last strip is step 40 alone, a
             # single window row (whose footprint may be one image column wide)

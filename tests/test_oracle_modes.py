@@ -54,6 +54,37 @@ def test_cost_modes_agree_to_rounding(pawn_small):
     assert n > 100 and worst <= 1e-12, worst
 
 
+def test_literal_cost_with_deterministic_libm_is_the_literal_cost_up_to_the_libm(pawn_small):
+    """po_scene.costLiteral (the checker of the HIP path's PAIS_ARITH=literal): the reference's cost statements and summation
+    order with fdlibm's exp / sin / cos instead of the platform's -- the same values up to the libm's last bits, and far
+    closer to the all-literal cost than the kernel arithmetic needs to be."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    L = po.lib()
+    rng = np.random.default_rng(6)
+    worst = 0.0
+    n = same = 0
+    for grad in (False, True):
+        cfg = readme_config(adaptiveGradientEnable=grad)
+        S = common.oracle_scene(cfg, pawn_small)
+        for i, (X, vis) in enumerate(pawn_small.seeds[:10]):
+            p = S.seed_patch(X, vis, key=i)
+            L.po_set_reference_camera(S.ptr, C.byref(p)); L.po_set_depth_and_ray(S.ptr, C.byref(p))
+            L.po_set_depth_range(S.ptr, C.byref(p)); L.po_set_lod(S.ptr, C.byref(p))
+            for j in range(10):
+                pos = [p.normalS[0] + rng.normal(0, .15), p.normalS[1] + rng.normal(0, .15), p.depth + rng.normal(0, .01)]
+                S.set_kernel_arithmetic(False); S.set_cost_literal(False); a = S.fitness(p, pos)
+                S.set_kernel_arithmetic(True); S.set_cost_literal(True); b = S.fitness(p, pos)
+                S.set_cost_literal(False)
+                if a == common.DBL_MAX or b == common.DBL_MAX:
+                    assert a == b
+                    continue
+                worst = max(worst, abs(a - b) / abs(a)); n += 1
+                same += int(a == b)
+    assert n > 100 and worst <= 1e-13, worst
+    print("literal cost, deterministic libm vs platform libm: %d of %d values identical, worst relative difference %.2e" % (same, n, worst))
+
+
 def refine_pairs(S, scene, cfg, run_b=None):
     """(literal patches, kernel-arithmetic patches[, run_b's records]) for every seed of the scene and the first-ring
     children of the literal parents.  run_b(seed inputs, child inputs) -> record-like objects (the GPU tests pass the HIP
