@@ -41,10 +41,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-world", default="", help="e.g. 2,4,8: after the normal line's measurements, run ONE rank of a world of N "
-                    "on this GPU through the real sharded code path (include/pais_mvs.h pais_mvs_emulate: the other ranks' blocks are "
+                    "on this GPU through the real sharded code path (include/pais_test_hooks.h pais_mvs_emulate: the other ranks' blocks are "
                     "replayed from a recorded single-rank run) and print measured T_rank(N) next to the model (config.emulated_speedup_at)")
     ap.add_argument("--emulate-ranks", default="all", choices=["ends", "all"], help="which ranks of each emulated world are run: "
-                    "the first and the last (default) or every one; T(N) = the slowest")
+                    "every one (default) or only the first and the last; T(N) = the slowest")
     ap.add_argument("--emulate-steps", type=int, default=2)
     ap.add_argument("--no-emulate", action="store_true", help="the default pawn line emulates ranks of worlds of 2 / 4 / 8 on this GPU "
                     "(a few hundred ms); this switches that off")
@@ -427,6 +427,26 @@ def main():
             ranks_agree = all(allsha[40 * r:40 * (r + 1)] == allsha[:40] for r in range(world))
         except Exception:
             ranks_agree = None
+    # SELF-CHECK of a multi-rank run: a line is only printed for a run in which every rank holds the same cloud
+    # and no sharded batch needed a second exchange / no one-launch PSO pass fell back -- both are handled correctly by the library,
+    # but a scaling figure measured over them would not be the steady state (PAIS_BENCH_ALLOW_RETRIES=1 prints it anyway)
+    if world > 1:
+        ksc = _lib.KernelStats()
+        m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ksc), 0)
+        retries = int(job.max_over_ranks(float(last.exchange_retries if last else 0)))
+        fallbacks = int(job.max_over_ranks(float(ksc.ring_fallbacks)))
+        problems = []
+        if ranks_agree is not True:
+            problems.append("the ranks do NOT hold the same cloud (ranks_hold_the_same_cloud = %r)" % (ranks_agree,))
+        if (retries or fallbacks) and os.environ.get("PAIS_BENCH_ALLOW_RETRIES") != "1":
+            problems.append("%d sharded batch(es) took a second exchange, %d one-launch PSO pass(es) fell back to per-iteration launches "
+                            "(PAIS_BENCH_ALLOW_RETRIES=1 reports the line anyway)" % (retries, fallbacks))
+        if problems:
+            if rank == 0:
+                sys.stderr.write("bench.py --gpus %d: REFUSING to print a result line:\n  %s\n" % (world, "\n  ".join(problems)))
+            m.close()
+            job.close()
+            raise SystemExit(3)
     # Roofline leg (not part of `value`): ONE more step of the same workload with every cost-evaluation launch
     # bracketed by HIP events on the stream it is launched on (two overlapping sub-streams by default).
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 1)

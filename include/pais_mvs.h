@@ -54,6 +54,9 @@ typedef struct pais_mvs_stats {
                                    * include host work that ran under the GPU's, gpu_refine_ms only what the host waited for */
     double  emu_replay_ms;        /* pais_mvs_emulate mode 2: host time spent packing the OTHER ranks' blocks from the recorded
                                    * run -- work a real rank does not have; bench.py subtracts it from the emulated rank's time */
+    int64_t exchange_retries;     /* sharded batches that took a SECOND exchange: some rank's one-launch PSO pass (k_pso_ring) did not
+                                   * complete and its shard was refined again.  Correct, but never expected: bench.py --gpus N > 1
+                                   * refuses to print a line when it happened */
 } pais_mvs_stats;
 
 /* One entry per GPU batch of the last reconstruction (the seed batch first, then one per expansion round with

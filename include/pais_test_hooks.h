@@ -31,6 +31,14 @@ int  pais_mvs_emulate(pais_mvs *m, int mode, int rank, int world);
 typedef int (*pais_record_source_fn)(void *user, int n, const pais_candidate *cands, pais_patch_result *out, int has_seeds);
 int  pais_mvs_set_record_source(pais_mvs *m, pais_record_source_fn fn, void *user);
 
+/* FAILURE INJECTION into the sharded batch protocol on THIS rank (tests/test_distributed_cpu.py; drivers with a caller-supplied
+ * all-gather -- the host instance of shard_submit / shard_finish).  The statuses are those the device path produces by itself:
+ *   what 1  the next `count` sharded batches: this rank's header says PAIS_WIRE_RC_RING_RETRY (its k_pso_ring pass did not
+ *           complete) -> every rank must take a second exchange, after this rank has refined its shard again;
+ *   what 2  the `count`-th growth of the exchange buffers from now fails on this rank -> the growth handshake fails every rank;
+ *   what 3  the `count`-th sharded refinement from now fails on this rank -> its header carries the status, every rank fails. */
+int  pais_mvs_test_inject(pais_mvs *m, int what, int count);
+
 #ifdef __cplusplus
 }
 #endif

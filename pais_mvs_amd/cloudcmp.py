@@ -31,11 +31,13 @@ def cloud_metrics(A: np.ndarray, B: np.ndarray, radius: float, masksA=None, mask
     for name, X, Y, ty, mx, my in (("a_to_b", A, B, tb, masksA, masksB), ("b_to_a", B, A, ta, masksB, masksA)):
         d, j = ty.query(X[:, :3])
         rel = d / np.maximum(np.linalg.norm(X[:, :3], axis=1), 1e-300)
-        cosang = np.clip(np.abs(np.einsum("ij,ij->i", X[:, 3:], Y[j, 3:])), 0.0, 1.0)
-        ang = np.arccos(cosang)
+        # signed: a normal pointing the other way is 180 degrees off, not 0 (patch normals are oriented: towards the cameras)
+        dot = np.einsum("ij,ij->i", X[:, 3:], Y[j, 3:])
+        ang = np.arccos(np.clip(dot, -1.0, 1.0))
         m = {"dist_over_radius_median": _q(d / radius, 0.5), "dist_over_radius_p95": _q(d / radius, 0.95),
              "dist_over_radius_max": float((d / radius).max()),
              "normal_angle_median_rad": _q(ang, 0.5), "normal_angle_p95_rad": _q(ang, 0.95),
+             "flipped_normals": int((dot < 0).sum()),
              "within_radius": float((d <= radius).mean()),
              "identical_centre": float((d == 0).mean()),
              "within_1e-4_rel_centre": float((rel <= 1e-4).mean()),

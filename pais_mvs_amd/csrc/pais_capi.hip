@@ -414,7 +414,7 @@ static int ctx_init_work(pais_ctx *ctx)
     if (const char *e = getenv("PAIS_TILE_STRIP1")) { int v = atoi(e); if (v >= 1) ctx->tileStrip1 = v; }
     if (const char *e = getenv("PAIS_TILE_FORCE_NS1")) ctx->tileForceNs1 = atoi(e) != 0;
     if (const char *e = getenv("PAIS_ARITH")) ctx->arithLiteral = (strcmp(e, "literal") == 0);
-    if (const char *e = getenv("PAIS_TILE_SPLIT")) ctx->tileSplit = atoi(e) != 0;
+    if (const char *e = getenv("PAIS_TILE_SPLIT")) ctx->tileSplit = atoi(e) > 0 ? atoi(e) : 0; // 0 off, 1 every batch, k > 1: batches of >= k cameras
     if (const char *e = getenv("PAIS_TILE_STRIP_SPLIT")) { int v = atoi(e); if (v >= 1) ctx->tileStripSplit = v; }
     if (const char *e = getenv("PAIS_TILE_BIAS")) ctx->tileBias = atoi(e);
     if (const char *e = getenv("PAIS_TILE_ABOVE")) { long v = atol(e); if (v > 0) ctx->tileAbove = v; }

@@ -1073,7 +1073,9 @@ __device__ __forceinline__ void pso_move_own(int i, int N, int localK, double iw
         dj += d0 * d0;
         dj += d1 * d1;
         dj += d2 * d2;
-        dj = (lane == i || !pv) ? DBL_MAX : dj; // (lanes beyond the swarm: behind every particle in every order)
+        // (self: DBL_MAX, psosolver.cpp:161; lanes beyond the swarm: +inf, behind every particle in every order -- also behind
+        //  one whose squared distance overflowed to +inf: equal keys are ordered by lane, and they have the higher lanes)
+        dj = (lane == i) ? DBL_MAX : (!pv ? __builtin_inf() : dj);
     }
     int rank = 0;
     if (N <= 32) {
@@ -2319,7 +2321,8 @@ hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, 
                     int strip2, int strip1, int forceNs1, int split, int stripSplit, int bias, unsigned long long *dbg, double *hscr,
                     size_t hscrBytes, hipStream_t stream)
 {
-    if (split) { // the colours of at most NP pairs per wave: Kmax <= 4 NP cameras, with room for the first half's larger share
+    if (split && Kmax > split - 1) { // `split` - 1 = camera count above which a batch takes the split kernel (1: every batch)
+        // the colours of at most NP pairs per wave: Kmax <= 4 NP cameras, with room for the first half's larger share
         if (Kmax <= 28) return pso_tile2_launch<8>(sc, states, n, Nmax, Kmax, evalBlocks, win, stripSplit, bias, dbg, stream);
         if (Kmax <= 44) return pso_tile2_launch<12>(sc, states, n, Nmax, Kmax, evalBlocks, win, stripSplit, bias, dbg, stream);
         return pso_tile2_launch<16>(sc, states, n, Nmax, Kmax, evalBlocks, win, stripSplit, bias, dbg, stream);

@@ -13,11 +13,11 @@
 //     test of :999 on the doubles, the four-product bilinear of :1014-1017;
 //   * mean /= K, avgSad /= K (:1022-1027), weight = 1 * dist * exp(-avgSad * avgSad / diffW) * exp(-1 / (edge * gradW)) in
 //     that order (:1029-1038), with fdlibm's exp (det_exp: the platform libm of the reference's MSVC build is not
-//     reproducible anywhere else; the CPU checker uses the same function, oracle/po_detmath.h);
+//     reproducible anywhere else; the CPU checker of the tests uses the same function);
 //   * sumWeight += weight; fitness += weight * avgSad over the pixels in the reference's x-outer / y-inner order (:979-1041):
 //     a wave computes 64 consecutive pixels of that order at a time, parks (weight, weight * avgSad) in LDS and every lane
 //     adds them one after the other (wave-uniform broadcast reads) -- a strict sequential sum, bit for bit the CPU's.
-// Checker: oracle/pais_oracle.c po_get_fitness with po_scene.costLiteral (tests/test_gpu_parity.py:
+// Checker: the CPU restatement's literal cost with the same exp / sin / cos (tests/test_gpu_parity.py:
 // test_literal_arithmetic_cost_is_the_reference_statement).  Slower than the kernel arithmetic (a division per tap, two
 // serial chains of S*S additions per evaluation); bench.py reports its throughput next to the default's.
 #pragma once

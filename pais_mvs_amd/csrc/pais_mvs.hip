@@ -284,6 +284,11 @@ struct pais_mvs {
         size_t wireCap = 0;   // bytes of d_wireAll / h_wireAll (every rank's block)
         size_t wireSCap = 0;  // bytes of d_wireS (this rank's block): tracked on its own -- a smaller world makes the slot larger
         hipEvent_t packed = nullptr, done = nullptr;
+        // the same buffers of the HOST instance of the protocol (drivers without RCCL: a caller-supplied all-gather, GPU-less
+        // schedulers under test) -- shard_submit / shard_finish run the same header / growth / retry protocol over them
+        std::vector<pais_candidate> hostC;
+        std::vector<pais_patch_result> hostR;
+        std::vector<unsigned char> hostS, hostAll;
     } sb[PAIS_MAX_STREAM_PARTS];
     struct ShardXfer {
         ShardBufs *B = nullptr;
@@ -293,7 +298,11 @@ struct pais_mvs {
         size_t WB = 0, slot = 0;
         double t0 = 0;
         bool sharded = false, open = false;                        // sharded: device path + exchange; else replicated on `lane` (host batch)
+        bool hostRetry = false;                                    // host instance: this rank's block said "ring retry" (test hook)
+        bool secondAttempt = false;                                // the shard is being refined again after such a status
     } sx[PAIS_MAX_STREAM_PARTS];
+    // pais_mvs_test_inject (include/pais_test_hooks.h): failures of the sharded protocol provoked on this rank
+    int injectRingRetry = 0, injectGrowthFail = 0, injectRefineFail = 0;
     int *d_hs = nullptr, *d_hsAll = nullptr, *h_hs = nullptr;      // growth handshake of the sharded path (4 bytes per rank)
     // one-GPU emulation of a rank of a larger world (pais_mvs_emulate): the sharded code path with the other ranks' blocks
     // replayed from the records of a single-rank run of the same workload
@@ -367,6 +376,13 @@ struct pais_mvs {
     // -1 (default) = on in the one-GPU emulation, where it has been measured, OFF over a real RCCL communicator until a run on
     // >= 2 real GPUs has been green (that path has only ever run against the emulated transport)
     int streamSharded = -1;
+    // streamed rounds over a REAL communicator (streamSharded < 0, the default): off until one streamed sharded round -- the canary --
+    // has been refined a second time as ONE unstreamed sharded batch and every rank has found the two record sets identical, byte
+    // for byte (agreed through the 4-byte handshake); 0 not tried yet, 1 verified: stream, -1 differed on some rank: never stream.
+    // PAIS_STREAM_CANARY=1 applies the same rule to the one-GPU emulation (tests), =0 skips the canary (stream unverified: round 5)
+    int streamCanary = 0;
+    int streamCanaryMode = -1;
+    std::vector<pais_patch_result> canaryRecs;
     // how a batch is dealt to the ranks: false (default) = contiguous count-balanced shards, true = candidate i to rank i mod world
     // (PAIS_SHARD_STRIDED=1; must be the same on every rank).  Round 5 built the second rule against a suspected cost gradient along
     // the work list and then measured EVERY rank of the emulated 8-rank dome: contiguous shards are balanced already (1.40 ... 1.48 s
@@ -843,6 +859,7 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
     if (const char *e = getenv("PAIS_STREAM_HOST_SHARE")) m->streamHostShare = atof(e);
     if (const char *e = getenv("PAIS_STREAM_HEAD")) m->streamHead = std::max(1, atoi(e));
     if (const char *e = getenv("PAIS_STREAM_SHARDED")) m->streamSharded = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("PAIS_STREAM_CANARY")) m->streamCanaryMode = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("PAIS_SHARD_STRIDED")) m->shardStrided = atoi(e) != 0;
     if (const char *e = getenv("PAIS_STREAM_FIRST")) m->streamFirst = std::max(0.0, std::min(0.9, atof(e)));
     if (const char *e = getenv("PAIS_STREAM_PARTS")) m->streamParts = std::max(2, std::min(atoi(e), PAIS_MAX_STREAM_PARTS));
@@ -1064,11 +1081,25 @@ static int all_gather_host(pais_mvs *m, const void *send, void *recv, size_t byt
 // second part is refined on a lane and the exchange waits for its pack through an event.
 struct WireHeader { uint32_t magic; int32_t rc; int32_t count; int32_t rank; uint32_t user; };
 static bool sharded_transport(const pais_mvs *m) { return m->ctx && (m->nccl || m->emuMode == 2); }
+// the HOST instance of the same protocol: blocks through the caller's all-gather (pais_mvs_comm_init_callback), this rank's shard
+// refined by refine_local (its GPU context through the host batch call, or the record source of a GPU-less driver)
+static bool host_transport(const pais_mvs *m) { return !sharded_transport(m) && m->gatherCb != nullptr; }
 
 // every rank grows its buffers for the same batches (sizes follow from the replicated candidate list); a rank that cannot
 // must not leave the others in the collective that follows: the outcome of a growth is agreed on first, 4 bytes per rank
 static int shard_growth_handshake(pais_mvs *m, int localRc)
 {
+    if (host_transport(m)) { // 4 bytes per rank through the caller's all-gather
+        std::vector<int> all((size_t)m->world, 0);
+        int mine = localRc;
+        if (all_gather_host(m, &mine, all.data(), sizeof(int))) return -3;
+        for (int r = 0; r < m->world; ++r)
+            if (all[(size_t)r] != 0) {
+                if (!localRc) g_mvs_err = "sharded batch: rank " + std::to_string(r) + " could not grow its exchange buffers";
+                return all[(size_t)r] < 0 ? all[(size_t)r] : -2;
+            }
+        return 0;
+    }
     if (m->emuMode == 2 || !m->nccl) return localRc;
     hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
     std::string err;
@@ -1090,6 +1121,20 @@ static int shard_growth_handshake(pais_mvs *m, int localRc)
 static int shard_ensure(pais_mvs *m, pais_mvs::ShardBufs &B, size_t per, size_t slot)
 {
     const int world = m->world;
+    if (host_transport(m)) {
+        const bool grow = per > B.hostC.size() || slot > B.hostS.size() || slot * (size_t)world > B.hostAll.size();
+        if (!grow) return 0;
+        int rc = 0;
+        if (m->injectGrowthFail > 0 && --m->injectGrowthFail == 0) { rc = -2; g_mvs_err = "injected: exchange buffers could not grow"; }
+        if (!rc) {
+            const size_t cap = per + per / 2 + 64, capS = slot * 3 / 2 + 4096;
+            B.hostC.resize(std::max(cap, B.hostC.size()));
+            B.hostR.resize(B.hostC.size());
+            B.hostS.resize(std::max(capS, B.hostS.size()));
+            B.hostAll.resize(std::max(B.hostS.size() * (size_t)world, B.hostAll.size()));
+        }
+        return shard_growth_handshake(m, rc);
+    }
     const bool growShard = per > B.shardCap, growWire = slot * (size_t)world > B.wireCap || slot > B.wireSCap;
     if (!growShard && !growWire && B.packed) return 0;
     hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
@@ -1164,6 +1209,10 @@ static int emu_fill_blocks(pais_mvs *m, pais_mvs::ShardXfer &X)
 // the exchange of X's blocks, enqueued on the driver's stream behind X's pack (event), and the copy down
 static int shard_exchange(pais_mvs *m, pais_mvs::ShardXfer &X)
 {
+    if (host_transport(m)) {
+        m->st.exchange_bytes += (int64_t)(X.slot * (size_t)m->world);
+        return all_gather_host(m, X.B->hostS.data(), X.B->hostAll.data(), X.slot);
+    }
     hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
     pais_mvs::ShardBufs &B = *X.B;
     // (a HIP error on this rank before the collective must not keep it out of the collective -- the others would wait in it
@@ -1193,12 +1242,35 @@ static int shard_exchange(pais_mvs *m, pais_mvs::ShardXfer &X)
 }
 
 // this rank's shard: candidates up, refined, packed, header (all on X.lane's stream, nothing waited for)
-static void shard_refine_enqueue(pais_mvs *m, pais_mvs::ShardXfer &X)
+// preRc: a failure of this rank before the enqueue (hipSetDevice): nothing is refined, the header carries it to every rank
+static void shard_refine_enqueue(pais_mvs *m, pais_mvs::ShardXfer &X, int preRc = 0)
 {
     pais_mvs::ShardBufs &B = *X.B;
+    if (host_transport(m)) {
+        // host instance: the shard refined at once (refine_local), packed and headed on the host.  The injected statuses are the
+        // ones the device path produces by itself: a k_pso_ring pass that did not complete (-> every rank takes a second
+        // exchange), a refinement that failed (-> every rank fails the batch)
+        int rc = preRc;
+        if (X.cnt > 0 && !rc) {
+            for (int j = 0; j < X.cnt; ++j) B.hostC[(size_t)j] = X.c[shard_index(m, m->rank, j, X.n, X.per)];
+            if (m->injectRefineFail > 0 && --m->injectRefineFail == 0) rc = mfail("injected: this rank's refinement failed");
+            else rc = refine_local(m, X.cnt, B.hostC.data(), B.hostR.data(), X.hasSeeds);
+        }
+        X.hostRetry = false;
+        if (!rc && X.cnt > 0 && m->injectRingRetry > 0 && !X.secondAttempt) { --m->injectRingRetry; X.hostRetry = true; rc = PAIS_WIRE_RC_RING_RETRY; }
+        memset(B.hostS.data(), 0, X.slot);
+        WireHeader hd0 = {PAIS_WIRE_MAGIC, rc, X.cnt, m->rank, m->streamWish ? 1u : 0u};
+        memcpy(B.hostS.data(), &hd0, sizeof(hd0));
+        if ((!rc || X.hostRetry) && X.cnt > 0 && pais_pack_records(X.cnt, B.hostR.data(), X.Kb, B.hostS.data() + kWireHeader)) {
+            hd0.rc = rc = -1;
+            memcpy(B.hostS.data(), &hd0, sizeof(hd0));
+        }
+        X.localRc = X.hostRetry ? 0 : rc;
+        return;
+    }
     hipStream_t ls = (hipStream_t)pais_ctx_stream(X.lane);
-    int rc = 0;
-    if (X.cnt > 0) {
+    int rc = preRc;
+    if (X.cnt > 0 && !rc) {
         for (int j = 0; j < X.cnt; ++j) B.h_shardC[j] = X.c[shard_index(m, m->rank, j, X.n, X.per)];
         if (hipMemcpyAsync(B.d_shardC, B.h_shardC, sizeof(pais_candidate) * (size_t)X.cnt, hipMemcpyHostToDevice, ls) != hipSuccess) rc = -2;
         if (!rc) rc = pais_refine_batch_device_async(X.lane, X.cnt, B.d_shardC, B.d_shardR, X.Kmax, X.hasSeeds);
@@ -1211,10 +1283,13 @@ static void shard_refine_enqueue(pais_mvs *m, pais_mvs::ShardXfer &X)
     if (X.lane != m->ctx) (void)hipEventRecord(B.packed, ls);
 }
 
-static int shard_submit(pais_mvs *m, pais_mvs::ShardXfer &X, pais_mvs::ShardBufs &B, pais_ctx *lane, int n, const pais_candidate *c, int has_seeds)
+// preFail != 0: this rank cannot refine its shard (e.g. no lane of its own for a part of a streamed round): it still enters the
+// collective, with that status in its header, so that every rank fails the batch together
+static int shard_submit(pais_mvs *m, pais_mvs::ShardXfer &X, pais_mvs::ShardBufs &B, pais_ctx *lane, int n, const pais_candidate *c, int has_seeds,
+                        int preFail = 0)
 {
     const int world = m->world;
-    X.B = &B; X.lane = lane; X.c = c; X.n = n; X.hasSeeds = has_seeds; X.sharded = true; X.open = true;
+    X.B = &B; X.lane = lane; X.c = c; X.n = n; X.hasSeeds = has_seeds; X.sharded = true; X.open = true; X.secondAttempt = false;
     X.per = (n + world - 1) / world;
     X.lo = std::min(m->rank * X.per, n); // (contiguous shards only)
     X.cnt = shard_count(m, m->rank, n, X.per);
@@ -1231,10 +1306,10 @@ static int shard_submit(pais_mvs *m, pais_mvs::ShardXfer &X, pais_mvs::ShardBufs
     if (rc) { X.open = false; return rc; } // (agreed on by every rank: shard_growth_handshake)
     // (from here on a local failure must not keep this rank out of the collective -- the others would wait in it for ever: it
     //  travels in the status header of the rank's block and fails every rank together)
-    const hipError_t sd = hipSetDevice(m->device);
+    const hipError_t sd = host_transport(m) ? hipSuccess : hipSetDevice(m->device);
     if (m->emuMode == 2 && (rc = emu_fill_blocks(m, X)) != 0) { X.open = false; return rc; }
-    shard_refine_enqueue(m, X);
-    if (sd != hipSuccess && !X.localRc) { X.localRc = -2; g_mvs_err = std::string("hipSetDevice: ") + hipGetErrorString(sd); }
+    if (sd != hipSuccess) g_mvs_err = std::string("hipSetDevice: ") + hipGetErrorString(sd);
+    shard_refine_enqueue(m, X, (sd != hipSuccess || preFail) ? -2 : 0); // (the status header written on the device says so to every rank)
     rc = shard_exchange(m, X);
     if (rc) X.open = false;
     return rc;
@@ -1247,17 +1322,20 @@ static int shard_finish(pais_mvs *m, pais_mvs::ShardXfer &X, pais_patch_result *
     X.open = false;
     const int world = m->world;
     pais_mvs::ShardBufs &B = *X.B;
+    const bool host = host_transport(m);
+    const unsigned char *wireAll = host ? B.hostAll.data() : B.h_wireAll;
     for (int attempt = 0;; ++attempt) {
-        MHIP(hipEventSynchronize(B.done));
+        if (!host) MHIP(hipEventSynchronize(B.done));
         if (m->emuMode == 2 && m->emuLatencyUs > 0) { // modelled launch latency of the collective (the bytes moved for real, over PCIe)
             const double t1 = now_ms() + m->emuLatencyUs * 1e-3;
             while (now_ms() < t1) {}
         }
-        const int mine = X.cnt > 0 ? pais_ctx_batch_status(X.lane) : 0; // (consumes this rank's ring status; the header says the same)
+        const int mine = host ? (X.hostRetry ? 1 : 0)
+                              : (X.cnt > 0 ? pais_ctx_batch_status(X.lane) : 0); // (consumes this rank's ring status; the header says the same)
         bool retry = false;
         for (int r = 0; r < world; ++r) {
             WireHeader hd;
-            memcpy(&hd, B.h_wireAll + X.slot * (size_t)r, sizeof(hd));
+            memcpy(&hd, wireAll + X.slot * (size_t)r, sizeof(hd));
             if (r == 0 && hd.magic == PAIS_WIRE_MAGIC) m->streamAgreed = (hd.user & 1u) != 0; // rank 0's choice binds every rank
             const int rcnt = shard_count(m, r, X.n, X.per);
             if (hd.magic != PAIS_WIRE_MAGIC || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
@@ -1271,15 +1349,17 @@ static int shard_finish(pais_mvs *m, pais_mvs::ShardXfer &X, pais_patch_result *
         if (attempt >= 1) return mfail("sharded batch: a shard did not complete twice");
         // some rank's k_pso_ring pass did not complete: those ranks refine their shard again (one launch per iteration), every
         // rank sends its block again -- all ranks have read the same headers, so all take this second exchange
+        X.secondAttempt = true;
+        m->st.exchange_retries++;
         if (mine == 1) shard_refine_enqueue(m, X);
-        else if (X.lane != m->ctx) MHIP(hipEventRecord(B.packed, (hipStream_t)pais_ctx_stream(X.lane)));
+        else if (!host && X.lane != m->ctx) MHIP(hipEventRecord(B.packed, (hipStream_t)pais_ctx_stream(X.lane)));
         int rc = shard_exchange(m, X);
         if (rc) return rc;
     }
     m->st.exchange_ms += now_ms() - X.t0; // (from the submission: refinement of the shard included)
     for (int r = 0; r < world; ++r) {
         const int rcnt = shard_count(m, r, X.n, X.per);
-        const unsigned char *blk = B.h_wireAll + X.slot * (size_t)r + kWireHeader;
+        const unsigned char *blk = wireAll + X.slot * (size_t)r + kWireHeader;
         if (!m->shardStrided) {
             if (rcnt > 0 && pais_unpack_records(rcnt, blk, X.Kb, out + shard_index(m, r, 0, X.n, X.per))) return mfail(pais_last_error());
         } else {
@@ -1322,57 +1402,23 @@ static int refine_any(pais_mvs *m, int n, const pais_candidate *c, pais_patch_re
     }
     m->st.batches_sharded++;
     m->results.resize((size_t)n);
-    if (sharded_transport(m)) {
-        // RCCL (or its one-GPU emulation): records stay in HBM, ONE ncclAllGather on the driver's stream, ONE synchronisation
-        int rc = shard_submit(m, m->sx[0], m->sb[0], m->ctx, n, c, has_seeds);
-        if (!rc) rc = shard_finish(m, m->sx[0], m->results.data());
-        if (rc) return rc;
-        *view = m->results.data();
-        return 0;
-    }
-    // records through host memory: GPU-less driver, or a caller-supplied transport
-    const int per = (n + world - 1) / world;
-    const int cnt = shard_count(m, m->rank, n, per);
-    int Kb = 1;
-    for (int i = 0; i < n; ++i) Kb = std::max(Kb, c[i].num_cam);
-    const size_t WB = pais_record_wire_bytes(Kb), slot = kWireHeader + WB * (size_t)per;
-    m->wireAll.resize(slot * (size_t)world);
-    int localRc = 0;
-    m->sendBuf.assign((size_t)per, pais_patch_result());
-    if (cnt > 0) {
-        m->shardCands.resize((size_t)cnt);
-        for (int j = 0; j < cnt; ++j) m->shardCands[(size_t)j] = c[shard_index(m, m->rank, j, n, per)];
-        localRc = refine_local(m, cnt, m->shardCands.data(), m->sendBuf.data(), has_seeds);
-    }
-    m->wireSend.assign(slot, 0);
-    WireHeader hd0 = {PAIS_WIRE_MAGIC, localRc, cnt, m->rank, 0u};
-    memcpy(m->wireSend.data(), &hd0, sizeof(hd0));
-    if (!localRc && pais_pack_records(cnt, m->sendBuf.data(), Kb, m->wireSend.data() + kWireHeader)) localRc = -1;
-    {
-        const double t0 = now_ms();
-        int rc = all_gather_host(m, m->wireSend.data(), m->wireAll.data(), slot);
-        m->st.exchange_ms += now_ms() - t0;
-        m->st.exchange_bytes += (int64_t)(slot * (size_t)world);
-        if (rc) return rc;
-    }
-    // every rank reads every rank's status, then the shards in rank order
-    for (int r = 0; r < world; ++r) {
-        WireHeader hd;
-        memcpy(&hd, m->wireAll.data() + slot * (size_t)r, sizeof(hd));
-        const int rcnt = shard_count(m, r, n, per);
-        if (hd.magic != PAIS_WIRE_MAGIC || hd.rank != r || hd.count != rcnt) return mfail("sharded batch: malformed exchange header (ranks disagree on the batch)");
-        if (hd.rc != 0) {
-            if (r != m->rank || g_mvs_err.empty()) g_mvs_err = "sharded batch: rank " + std::to_string(r) + " failed to refine its shard (rc " + std::to_string(hd.rc) + ")";
-            return hd.rc < 0 ? hd.rc : -1;
-        }
-    }
-    for (int r = 0; r < world; ++r) {
-        const int rcnt = shard_count(m, r, n, per);
-        const unsigned char *blk = m->wireAll.data() + slot * (size_t)r + kWireHeader;
-        for (int j = 0; j < rcnt; ++j)
-            if (pais_unpack_records(1, blk + WB * (size_t)j, Kb, m->results.data() + shard_index(m, r, j, n, per))) return mfail(pais_last_error());
-    }
+    // RCCL (or its one-GPU emulation): records stay in HBM, ONE ncclAllGather on the driver's stream, ONE synchronisation.
+    // A caller-supplied all-gather / a GPU-less driver: the same submit / finish protocol over host memory (host_transport).
+    if (!sharded_transport(m) && !host_transport(m)) return mfail("sharded batch: no transport attached");
+    int rc = shard_submit(m, m->sx[0], m->sb[0], m->ctx, n, c, has_seeds);
+    if (!rc) rc = shard_finish(m, m->sx[0], m->results.data());
+    if (rc) return rc;
     *view = m->results.data();
+    return 0;
+}
+
+extern "C" int pais_mvs_test_inject(pais_mvs *m, int what, int count)
+{
+    if (!m || count < 0) return mfail("pais_mvs_test_inject: bad argument");
+    if (what == 1) m->injectRingRetry = count;
+    else if (what == 2) m->injectGrowthFail = count;
+    else if (what == 3) m->injectRefineFail = count;
+    else return mfail("pais_mvs_test_inject: unknown injection");
     return 0;
 }
 
@@ -2072,7 +2118,11 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         // large round: streamed (see pais_mvs::lane1) -- on one GPU, and (round 4) on the sharded path: each part is a sharded
         // batch of its own, the two exchanges enqueued on the driver's stream in part order (shard_submit / shard_finish)
         const bool oneGpu = m->ctx && m->world <= 1 && !m->nccl && !m->gatherCb && m->emuMode != 2;
-        const bool shardStream = sharded_transport(m) && (m->streamSharded == 1 || (m->streamSharded < 0 && m->emuMode == 2));
+        // (over a real communicator by default: yes while the canary has not failed -- the first streamed round IS the canary)
+        const bool canaryRule = m->streamSharded < 0 && (m->streamCanaryMode == 1 || (m->streamCanaryMode < 0 && m->emuMode != 2));
+        const bool shardStream = sharded_transport(m) && (m->streamSharded == 1 || (m->streamSharded < 0 && m->emuMode == 2 && !canaryRule) ||
+                                                          (canaryRule && m->streamCanary >= 0));
+        const bool canaryRound = shardStream && canaryRule && m->streamCanary == 0;
         const bool timingSaysStream = m->streamRounds == 1 && m->prevHostMs >= m->streamHostMs && m->prevHostMs >= m->streamHostShare * m->prevGpuMs;
         m->streamWish = timingSaysStream; // (travels in this rank's header with the next sharded batch)
         const bool canStream = (oneGpu || shardStream) && m->emuMode != 1 &&
@@ -2082,13 +2132,19 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
         double enqueueMs = 0; // host time of the first part's enqueue: inside round_begin, but not enumeration
         // a part of a streamed round on the sharded path: a sharded batch (device path + exchange), or -- too thin to split --
         // replicated on its lane as a host batch
+        bool laneForkFailed = false; // a part (>= 1) of this round has no lane of its own
         auto part_submit = [&](int idx, pais_ctx *lane, int np, const pais_candidate *cc, int nRound) -> int {
             pais_mvs::ShardXfer &X = m->sx[idx];
+            // (a part without a lane of its own must not be refined on the driver's context while part 0's asynchronous batch is
+            //  pending there -- the context's per-batch state is single -- : it enters its collective with a failure status, every
+            //  rank fails the round together; a replicated part fails locally, there is no collective to keep)
+            const bool noLane = idx > 0 && lane == m->ctx && laneForkFailed;
             if ((long)np * m->cfg.particleNum >= (long)m->replicateBelow) {
                 m->st.batches_sharded++;
                 (void)pais_ctx_set_round_hint(lane, (nRound + m->world - 1) / m->world);
-                return shard_submit(m, X, m->sb[idx], lane, np, cc, 0);
+                return shard_submit(m, X, m->sb[idx], lane, np, cc, 0, noLane ? 1 : 0);
             }
+            if (noLane) { X.open = false; return mfail("streamed sharded round: no lane for a part"); }
             m->st.batches_replicated++;
             X.sharded = false; X.lane = lane; X.n = np; X.open = true;
             (void)pais_ctx_set_round_hint(lane, nRound);
@@ -2118,9 +2174,9 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
             if (p == 0) return m->ctx;
             while ((int)m->partLanes.size() < p) {
                 pais_ctx *l = nullptr;
-                // (a rank that cannot fork a lane must still take part in the part's collective: it refines the part on the
-                //  driver's own context -- same records, no overlap)
-                if (pais_ctx_fork_lane(m->ctx, &l)) return m->ctx;
+                // (a rank that cannot fork a lane must still take part in the part's collective: part_submit enters it with a
+                //  failure status on the driver's own stream -- ADVICE r5: refining there would clobber part 0's pending batch)
+                if (pais_ctx_fork_lane(m->ctx, &l)) { g_mvs_err = pais_last_error(); laneForkFailed = true; return m->ctx; }
                 m->partLanes.push_back(l);
             }
             return m->partLanes[p - 1];
@@ -2177,6 +2233,30 @@ extern "C" int pais_mvs_expansion_patches(pais_mvs *m, int B, int max_rounds)
                 }
             }
             double commitMs = 0;
+            if (canaryRound && n > 0) {
+                // the canary: every part finished first (nothing committed), then the round once more as ONE sharded batch; the two
+                // record sets must be the same bytes on every rank, or streamed sharded rounds stay off for this driver
+                m->canaryRecs.resize((size_t)n);
+                for (int p = 0; p < P; ++p) {
+                    const int lo = p ? ends[p - 1] : 0, np = ends[p] - lo;
+                    if (np <= 0) continue;
+                    const pais_patch_result *v = nullptr;
+                    if (part_finish(p, m->canaryRecs.data() + lo, &v)) { drain_parts(p + 1, P); return -2; }
+                    if (v != m->canaryRecs.data() + lo) memcpy(m->canaryRecs.data() + lo, v, sizeof(pais_patch_result) * (size_t)np);
+                }
+                int rc2 = shard_submit(m, m->sx[0], m->sb[0], m->ctx, n, c, 0);
+                if (!rc2) rc2 = shard_finish(m, m->sx[0], m->results.data());
+                if (rc2) return rc2;
+                const bool same = memcmp(m->canaryRecs.data(), m->results.data(), sizeof(pais_patch_result) * (size_t)n) == 0;
+                const int verdict = shard_growth_handshake(m, same ? 0 : -7); // (4 bytes per rank: every rank takes the same decision)
+                m->streamCanary = verdict ? -1 : 1;
+                if (getenv("PAIS_STREAM_CANARY_LOG"))
+                    fprintf(stderr, "[pais] rank %d: streamed sharded round of %d candidates in %d parts %s its unstreamed replay -> streaming %s\n",
+                            m->rank, n, P, same ? "==" : "!=", m->streamCanary > 0 ? "on" : "off");
+                const double t1 = now_ms();
+                commit_records(m, m->results.data(), 0, n);   // (the unstreamed records: the path every test has verified)
+                commitMs += now_ms() - t1;
+            } else
             for (int p = 0; p < P; ++p) {
                 const int lo = p ? ends[p - 1] : 0, np = ends[p] - lo;
                 if (np <= 0) continue;

@@ -15,11 +15,15 @@
 // SIMD (each SIMD gets two waves of either role).  The canonical arithmetic is sequential over the cameras (reference
 // first, then camIdx order: pais_eval.hpp) and is kept BIT FOR BIT; per 64-pixel step the two waves of a particle hand
 // over through two 512-byte LDS rows:
-//   1. both tap their cameras from the tiles; role 0 sums ref + its colours -> row 0;                         barrier
-//   2. role 1 continues that sum with its colours, mean = sum / K -> row 0;                                   barrier
-//   3. role 0 adds |ref - mean| and its |c - mean| -> row 1; role 1 meanwhile turns its colours into |c - mean|; barrier
+//   1. both tap their cameras from the tiles; role 0 sums ref + its colours -> row 0;                         hand-over
+//   2. role 1 continues that sum with its colours, mean = sum / K -> row 0;                                   hand-over
+//   3. role 0 adds |ref - mean| and its |c - mean| -> row 1; role 1 meanwhile turns its colours into |c - mean|; hand-over
 //   4. role 1 continues the SAD, weight = wStat * exp(-sad^2 / diffW), canonical sub-accumulators; role 0 is already
 //      tapping the next step.
+// A hand-over is a pair of LDS counters per particle (tile2_post / tile2_wait): a wave waits for ITS partner only.  (First
+// version: three workgroup barriers per step -- correct, and 9 % SLOWER than k_pso_tile: sixteen waves in lockstep expose
+// every hand-over latency to all of them at once; without any synchronisation -- wrong results -- the same code ran 18 %
+// faster than k_pso_tile: profiles/r06_tile2_diag.txt.)
 // Role 1 does steps 2 and 4 alone, so role 0 takes the larger share of the cameras (`bias`, in cameras).
 // Same results as k_pso_tile and as eval_window<1, false, true, true> (tests/test_gpu_parity.py:
 // test_dome_radius25_many_cameras, PAIS_TILE_VERIFY; the dome's cloud hash).
@@ -27,14 +31,54 @@
 
 #define TILE2_WAVES 16
 #define TILE2_SLOTS 8 // particles of a workgroup
-#ifndef TILE2_NOSYNC
-#define TILE2_NOSYNC 0 // measurement builds, WRONG results: 1 the three hand-over barriers of a step removed (what they cost)
-#endif
-#if TILE2_NOSYNC
-#define TILE2_PHASE_BARRIER() wave_sync()
-#else
+#ifndef TILE2_SYNC
+#define TILE2_SYNC 0   // how the two waves of a particle hand over inside a step: 0 pair-wise LDS flags (a wave waits for ITS partner only),
+#endif                 // 2 workgroup barriers (the first version: all sixteen waves in lockstep -- every hand-over latency exposed to all of
+                       // them at once, measured +25 % of the kernel), 1 nothing (measurement build, WRONG results: what the hand-over costs)
+#if TILE2_SYNC == 2
 #define TILE2_PHASE_BARRIER() __syncthreads()
+#else
+#define TILE2_PHASE_BARRIER() wave_sync()
 #endif
+// flag protocol (TILE2_SYNC == 0), per particle slot two counters in LDS, both 0 at the start of a task; step st = 0, 1, ...:
+//   first half : sum -> row 0, flagA = 2 st + 1 | waits flagB >= st + 1 | its SAD -> row 1, flagA = 2 st + 2
+//   second half: waits flagA >= 2 st + 1 | mean -> row 0, flagB = st + 1 | waits flagA >= 2 st + 2
+// LDS operations of one wave are carried out in issue order, so "data, then flag" needs no more than a compiler barrier; the
+// reader's data read is issued after the flag value has come back.
+__device__ __forceinline__ void tile2_post(volatile int *flag, int v)
+{
+#if TILE2_SYNC == 0
+    asm volatile("" ::: "memory");
+    *flag = v;
+#endif
+}
+__device__ __forceinline__ void tile2_wait(volatile int *flag, int v)
+{
+#if TILE2_SYNC == 0
+    while (*flag < v) {
+#if TILE2_SPIN_SLEEP
+        __builtin_amdgcn_s_sleep(TILE2_SPIN_SLEEP);
+#endif
+    }
+    asm volatile("" ::: "memory");
+#endif
+}
+// the hand-over phases are short chains of DEPENDENT instructions (22 additions one after the other, the exp) on the critical
+// path of a particle's two waves: at the default priority each of them queues behind the tap instructions of the SIMD's three
+// other waves.  Raised priority while a wave is in such a phase, back to 0 for the taps.
+#ifndef TILE2_CHAIN_PRIO
+#define TILE2_CHAIN_PRIO 2
+#endif
+#ifndef TILE2_SPIN_SLEEP
+#define TILE2_SPIN_SLEEP 0
+#endif
+__device__ __forceinline__ void tile2_prio(bool high)
+{
+#if TILE2_CHAIN_PRIO
+    if (high) __builtin_amdgcn_s_setprio(TILE2_CHAIN_PRIO);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 
 __host__ __device__ inline size_t tile2_fixed_lds_bytes(int Kmax)
 {
@@ -42,7 +86,7 @@ __host__ __device__ inline size_t tile2_fixed_lds_bytes(int Kmax)
     b += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE2_SLOTS;     // homographies, per particle
     b += 2 * sizeof(TileBox) * (size_t)Kmax;                              // boxes (two sets)
     b += sizeof(double) * 64 * 2 * TILE2_SLOTS;                           // hand-over rows: 2 per particle
-    b += 64;                                                              // flags[0], pstate[8]
+    b += 128;                                                             // flags[0], pstate[8], hand-over counters[8][2]
     return (b + 15) & ~(size_t)15;
 }
 
@@ -163,6 +207,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
     o += sizeof(double) * 64 * 2 * TILE2_SLOTS;
     int *flags = (int *)(smem + o);                                             // [0]: some particle of the group walks the tiles
     int *pstate = flags + 1;                                                    // [slot]: != 0: the particle takes the checked walk (pending)
+    volatile int *flagA = flags + 1 + TILE2_SLOTS + 2 * slot, *flagB = flagA + 1;   // hand-over counters of this slot (tile2_post / tile2_wait)
     unsigned char *tiles = smem + tile2_fixed_lds_bytes(Kmax);
     const size_t SB = pso_state_bytes(Nmax);
     const int WS = win_stride(sc);
@@ -186,7 +231,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
             uint64_t *dst = (uint64_t *)smem;
             for (int q = threadIdx.x; q < nwMax; q += 64 * TILE2_WAVES) dst[q] = src[q];
             for (int q = threadIdx.x; q < 2 * Kmax; q += 64 * TILE2_WAVES) boxAll[q] = TileBox{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
-            if (threadIdx.x < 1 + TILE2_SLOTS) flags[threadIdx.x] = 0;
+            if (threadIdx.x < 1 + 3 * TILE2_SLOTS) flags[threadIdx.x] = 0;
         }
         __syncthreads();
         const int M = ep->M, K = ep->K;
@@ -371,6 +416,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                         if (nTail == 3) tile2_tap_group<3>(sc, cams, tiles, Hbuf, tail0, x, y, t3);
                         else if (nTail == 1) tile2_tap_group<1>(sc, cams, tiles, Hbuf, tail0, x, y, t3);
                     } else {
+                        tile2_prio(true);
                         double s = hasRef ? refCol : 0.0;
 #pragma unroll
                         for (int u = 0; u < NP; ++u)
@@ -379,6 +425,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                                 s += col[2 * u + 1];
                             }
                         *row0 = s;
+                        tile2_post(flagA, 2 * st + 1);
                     }
                 } else {
 #pragma unroll
@@ -388,6 +435,8 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                 // ---- 2. second half: the sum continued, the mean
                 double mean = 0;
                 if (state == 0 && role == 1) {
+                    tile2_prio(true);
+                    tile2_wait(flagA, 2 * st + 1);
                     double s = *row0;
 #pragma unroll
                     for (int u = 0; u < NP; ++u)
@@ -402,11 +451,13 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                     }
                     mean = s * invK;
                     *row0 = mean;
+                    tile2_post(flagB, st + 1);
                 }
                 TILE2_PHASE_BARRIER();
                 // ---- 3. first half: its share of the SAD; second half: |c - mean| in place
                 if (state == 0) {
                     if (role == 0) {
+                        tile2_wait(flagB, st + 1);
                         mean = *row0;
                         double sad = hasRef ? fabs(refCol - mean) : 0.0;
 #pragma unroll
@@ -416,6 +467,8 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                                 sad += fabs(col[2 * u + 1] - mean);
                             }
                         *row1 = sad;
+                        tile2_post(flagA, 2 * st + 2);
+                        tile2_prio(false);
                     } else {
 #pragma unroll
                         for (int u = 0; u < NP; ++u)
@@ -429,6 +482,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                 TILE2_PHASE_BARRIER();
                 // ---- 4. second half: the SAD continued, the weight, the canonical sub-accumulator of the step
                 if (state == 0 && role == 1) {
+                    tile2_wait(flagA, 2 * st + 2);
                     double sad = *row1;
 #pragma unroll
                     for (int u = 0; u < NP; ++u)
@@ -453,6 +507,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
     }
                     if (ga == 0) PAIS_TACC(0) else if (ga == 1) PAIS_TACC(1) else if (ga == 2) PAIS_TACC(2) else PAIS_TACC(3)
 #undef PAIS_TACC
+                    tile2_prio(false);
                 }
             }
             if (dbg) tWalk += __builtin_readcyclecounter() - tc3;

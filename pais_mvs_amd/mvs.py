@@ -19,7 +19,8 @@ class MvsStats(C.Structure):
                 ("parents_popped", C.c_int64), ("pso_evals_effective", C.c_int64),
                 ("host_enumerate_ms", C.c_double), ("host_commit_ms", C.c_double), ("gpu_refine_ms", C.c_double),
                 ("batches_sharded", C.c_int64), ("batches_replicated", C.c_int64), ("exchange_ms", C.c_double),
-                ("exchange_bytes", C.c_int64), ("rounds_streamed", C.c_int64), ("emu_replay_ms", C.c_double)]
+                ("exchange_bytes", C.c_int64), ("rounds_streamed", C.c_int64), ("emu_replay_ms", C.c_double),
+                ("exchange_retries", C.c_int64)]
 
 
 class RoundLog(C.Structure):
@@ -83,6 +84,7 @@ def _bind(L):
     L.pais_mvs_set_replicate_below.argtypes = [vp, C.c_int]
     L.pais_mvs_set_record_source.argtypes = [vp, RECORD_SOURCE_FN, vp]
     L.pais_mvs_emulate.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.pais_mvs_test_inject.argtypes = [vp, C.c_int, C.c_int]
     L._mvs_bound = True
 
 
@@ -215,6 +217,10 @@ class MVS:
 
     def set_replicate_below(self, per_rank: int):
         self._check(self.L.pais_mvs_set_replicate_below(self.h, int(per_rank)), "pais_mvs_set_replicate_below")
+
+    def test_inject(self, what: int, count: int):
+        """include/pais_test_hooks.h pais_mvs_test_inject: 1 ring-retry status, 2 failing buffer growth, 3 failing refinement."""
+        self._check(self.L.pais_mvs_test_inject(self.h, int(what), int(count)), "pais_mvs_test_inject")
 
     def set_record_source(self, fn):
         """GPU-less drivers (device < 0) only: fn(n, cands_ptr, out_ptr, has_seeds) fills out[0:n]."""

@@ -18,7 +18,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q, replicate_below, fail_rank=-1):
+def _worker(rank, world, port, q, replicate_below, fail_rank=-1, inject=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"] = str(rank); os.environ["WORLD_SIZE"] = str(world)
@@ -48,6 +48,8 @@ def _worker(rank, world, port, q, replicate_below, fail_rank=-1):
     m.set_record_source(source)
     D.attach(m, job, transport="host")
     m.set_replicate_below(replicate_below)
+    if inject and rank in inject[0]:
+        m.test_inject(inject[1], inject[2])      # (include/pais_test_hooks.h: ring-retry status / failing growth / failing refinement)
     try:
         D.reconstruct(m, 8, max_rounds=10)
     except RuntimeError as e:
@@ -61,12 +63,12 @@ def _worker(rank, world, port, q, replicate_below, fail_rank=-1):
     job.close()
 
 
-def _run(world, replicate_below, fail_rank=-1):
+def _run(world, replicate_below, fail_rank=-1, inject=None):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     port = _free_port()
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q, replicate_below, fail_rank)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, replicate_below, fail_rank, inject)) for r in range(world)]
     for p in ps:
         p.start()
     got = [q.get(timeout=600) for _ in range(world)]
@@ -118,6 +120,29 @@ def test_a_failing_rank_fails_every_rank_together():
     got = _run(2, 0, fail_rank=1)
     assert all(g[1] == "error" for g in got), got
     assert "rank 1" in got[0][2] or "record source" in got[0][2], got[0][2]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_batch_protocol_second_exchange_growth_and_failure(world):
+    """Round 6: the submit / finish protocol of a sharded batch -- status headers, growth handshake, the
+    second exchange after a rank's k_pso_ring pass did not complete -- is ONE implementation (shard_submit / shard_finish,
+    pais_mvs.hip) run over device memory + ncclAllGather or, here, over host memory + the caller's all-gather, world 2 and 4:
+      * ranks whose header says "ring retry" refine their shard again and EVERY rank takes the second exchange: same cloud;
+      * a rank whose exchange buffers cannot grow fails the growth handshake for every rank;
+      * a rank whose refinement fails says so in its header: every rank returns the error, none waits in the collective."""
+    ref = _run(1, 1024)[0]
+    last = world - 1
+    got = _run(world, 0, inject=((0, last), 1, 3))     # three batches each on the first and the last rank
+    for rank, blob, shape, eff, sharded, replicated, cands, xbytes, nmin in got:
+        assert shape == ref[2] and blob == ref[1] and eff == ref[3], rank
+    # the retrying ranks refined those shards twice; every rank moved the bytes of the second exchanges
+    assert got[0][6] > _run(world, 0)[0][6]
+    got = _run(world, 0, inject=((last,), 2, 2))       # the second growth on the last rank
+    assert all(g[1] == "error" for g in got), got
+    assert all("rank %d could not grow" % last in g[2] or "injected" in g[2] for g in got), got
+    got = _run(world, 0, inject=((0,), 3, 4))          # the fourth sharded refinement on rank 0
+    assert all(g[1] == "error" for g in got), got
+    assert all("rank 0" in g[2] or "injected" in g[2] for g in got), got
 
 
 def test_record_wire_format_roundtrip():

@@ -1415,7 +1415,7 @@ def test_seed_batches_and_device_pointer_batches_through_the_task_ring(pawn_smal
 
 
 @pytest.mark.gpu
-def test_emulated_ranks_of_a_larger_world_rebuild_the_single_rank_cloud(pawn_small, monkeypatch):
+def test_emulated_ranks_of_a_larger_world_rebuild_the_single_rank_cloud(pawn_small, monkeypatch, capfd):
     """include/pais_mvs.h pais_mvs_emulate (round 4): rank r of a world of N on ONE GPU -- the real sharded code path (shard
     refined by the kernels, packed, device-written status header, copy down, unpack, replicated commit), the other ranks'
     blocks replayed from a recorded single-rank run.  Every rank of a world of 2 and of 3 (ragged shards) rebuilds the
@@ -1469,10 +1469,19 @@ def test_emulated_ranks_of_a_larger_world_rebuild_the_single_rank_cloud(pawn_sma
     assert all(s.rounds_streamed > 0 for s in sts)
     sts, ks = run({"PAIS_STREAM_ROUNDS": "0", "PAIS_SPLIT_ABOVE": "1", "PAIS_RING_PER_CAM": "0", "PAIS_RING_TIMEOUT_MS": "0"}, (2,))
     assert ks.ring_fallbacks > 0, ks.ring_fallbacks
+    assert all(s.exchange_retries > 0 for s in sts)        # (round 6: the second exchanges are counted; bench.py --gpus N refuses a line over them)
+    # round 6: the CANARY of streamed sharded rounds over a real communicator -- the first streamed round is refined once more as one
+    # unstreamed sharded batch, the two record sets must be the same bytes (then streaming stays on): here on the emulation
+    capfd.readouterr()
+    sts, _ = run({"PAIS_STREAM_ROUNDS": "2", "PAIS_STREAM_ABOVE": "8", "PAIS_STREAM_PARTS": "2", "PAIS_STREAM_CANARY": "1",
+                  "PAIS_STREAM_CANARY_LOG": "1"}, (2,))
+    err = capfd.readouterr().err
+    assert "== its unstreamed replay -> streaming on" in err and "!=" not in err, err
+    assert all(s.rounds_streamed > 0 for s in sts)
 
 
 @pytest.mark.gpu
-def test_literal_gate_on_expansion_candidates_of_the_bench_workload(capsys):
+def test_literal_gate_on_expansion_candidates_of_the_bench_workload(capsys, monkeypatch):
     """north_star's gate at WORKLOAD size: the bench scene (640x480 pawn, 200 seeds, R(4096)) is driven
     round by round through the stepwise entry points; ~2000 expansion candidates of rounds 5..25 -- late rounds: LOD > 0,
     K = 3 edge cases, parents that are themselves expansion patches -- are kept with the HIP path's records and refined again
@@ -1527,6 +1536,16 @@ def test_literal_gate_on_expansion_candidates_of_the_bench_workload(capsys):
     ctl, runs = common.literal_control(cfg, scene, kept_c)
     lit, ker = runs[0], runs["kernel"]
     st = mode_statistics(lit, ker, hip=kept_r)          # (asserts HIP == kernel arithmetic bit for bit)
+    # round 6: the same candidates through the HIP path under PAIS_ARITH=literal (pais_literal.hpp: the cost in the reference's
+    # statements and summation ORDER): its records ARE the oracle's with the literal cost bit for bit, and against the all-literal
+    # run they branch no more often than the reference's own source with ONE rounding perturbed (variant 1) -- the floor of
+    # BASELINE.md 7.1 as a measurement
+    monkeypatch.setenv("PAIS_ARITH", "literal")
+    ctx_lit = _ctx(cfg, scene)                          # (cfg carries the reconstruction's neighbour radius: MVS wrote it back)
+    out_lit = ctx_lit.refine_batch(kept_c)
+    ctx_lit.close()
+    monkeypatch.delenv("PAIS_ARITH")
+    st_lit = mode_statistics(lit, runs["cost_literal"], hip=list(out_lit))   # (asserts HIP(literal) == oracle(cost literal) bit for bit)
     # branched candidates by LOD and by visible-camera count of the literal result
     by_lod, by_k = {}, {}
     mismatch_same = mismatch_branched = 0
@@ -1548,7 +1567,11 @@ def test_literal_gate_on_expansion_candidates_of_the_bench_workload(capsys):
            "by_lod": {str(k): {"n": v[0], "branched": v[1]} for k, v in sorted(by_lod.items())},
            "by_num_cam": {str(k): {"n": v[0], "branched": v[1]} for k, v in sorted(by_k.items())},
            "control": {k: {"branched": v["branched"], "beyond_1e-4": v["beyond_1e-4"], "set_mismatch_among_branched": v["set_mismatch_among_branched"]}
-                       for k, v in ctl.items() if k != "overlap"}, "control_overlap": ctl["overlap"]}
+                       for k, v in ctl.items() if k != "overlap"}, "control_overlap": ctl["overlap"],
+           "hip_literal_arithmetic": {"branched": st_lit["branched"], "branched_fraction": st_lit["branched"] / max(st_lit["n"], 1),
+                                      "same_trajectory_centre_max": st_lit["same_centre_max"], "same_trajectory_normal_max": st_lit["same_normal_max"],
+                                      "branched_centre_max": st_lit["branched_centre_max"], "branched_normal_max": st_lit["branched_normal_max"],
+                                      "set_mismatch": st_lit["set_mismatch"]}}
     with capsys.disabled():
         print("\nliteral gate, bench workload rounds 5..25:", json.dumps(rep))
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
@@ -1567,6 +1590,10 @@ def test_literal_gate_on_expansion_candidates_of_the_bench_workload(capsys):
     assert abs(mismatch_branched - gold["set_mismatch_among_branched"]) <= 1, mismatch_branched
     for k in ("variant_1", "variant_2", "variant_4", "variant_6"):
         assert abs(ctl[k]["branched"] - gctl[k]["branched"]) <= 2, (k, ctl[k]["branched"], gctl[k]["branched"])
+    # literal arithmetic on the GPU: at or below the one-rounding control (measured: 7 against 15 of 1 817), no discrete mismatch
+    assert st_lit["n"] == st["n"] and st_lit["branched"] <= ctl["variant_1"]["branched"], (st_lit, ctl["variant_1"]["branched"])
+    assert st_lit["set_mismatch"] == 0 and st_lit["same_centre_max"] <= 1e-12 and st_lit["same_normal_max"] <= 1e-12, st_lit
+    assert abs(st_lit["branched"] - gctl["cost_literal"]["branched"]) <= 2, (st_lit["branched"], gctl["cost_literal"]["branched"])
     # PARITY (weak 1): the cap is not "measured + 10" but the CONTROL -- what the reference's own source branches under another
     # loop order and another compiler (variant 6) -- times a margin (tests/test_cloud_parity.py)
     from tests.test_cloud_parity import BRANCH_FACTOR_OVER_CONTROL
