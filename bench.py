@@ -456,6 +456,49 @@ def main():
     m.L.pais_ctx_set_fine_timing(m.ctx_handle, 0)
     m.L.pais_get_kernel_stats(m.ctx_handle, C.byref(ks), 0)
 
+    # PAIS_ARITH=literal (pais_literal.hpp, round 6): the same reconstruction with the cost in the reference's own statements and
+    # summation ORDER -- a second driver over the same scene, one warm-up and two timed reconstructions, outside `value`
+    literal_arith = None
+    if rank == 0 and world == 1 and args.scene == "pawn" and not args.max_rounds and os.environ.get("PAIS_ARITH") != "literal" \
+            and os.environ.get("PAIS_BENCH_LITERAL", "1") != "0":
+        try:
+            os.environ["PAIS_ARITH"] = "literal"
+            m2 = MVS(cfg, scene.cameras, device=local, seed=42)
+            del os.environ["PAIS_ARITH"]
+
+            def step2():
+                m2.reset()
+                for X, vis in scene.seeds:
+                    m2.add_seed(X, vis)
+                m2.refineSeedPatches()
+                m2.expansionPatches(B, args.max_rounds)
+                return m2.stats()
+            step2()
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            ul = 0
+            for _ in range(2):
+                sl = step2()
+                ul += sl.seeds_refined + sl.candidates_effective
+            torch.cuda.synchronize()
+            dl = time.perf_counter() - tl
+            lg_b = None
+            try:
+                lc = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_control_bench_workload.json")))
+                lg_b = {"candidates": lc["cost_literal"]["n"], "branched": lc["cost_literal"]["branched"],
+                        "default_arithmetic_branched": lc["kernel"]["branched"], "one_rounding_control_branched": lc["variant_1"]["branched"]}
+            except Exception:
+                pass
+            literal_arith = {"value": ul / dl, "unit": "patches/s", "ms_per_step": dl / 2 * 1e3, "patches_per_step": ul // 2,
+                             "accepted_patches": int(m2.num_patches()), "cloud_sha1": m2.cloud_sha1(),
+                             "literal_gate": lg_b,
+                             "note": "PAIS_ARITH=literal: every batch through k_pso_eval_lit + k_pso_step; per candidate the records ARE the "
+                                     "CPU restatement's with the literal cost, bit for bit (tests/test_gpu_parity.py); branched = PSO "
+                                     "trajectories that differ from the all-literal CPU run (platform libm) on the 1 817 sampled candidates"}
+            m2.close()
+        except Exception as e:
+            os.environ.pop("PAIS_ARITH", None)
+            literal_arith = {"error": str(e)}
     scaling_model = None
     if rank == 0:
         scaling_model = predicted_speedup(m.round_log(), cfg.particleNum, (ks.pso_algorithmic_bytes / ks.pso_evals) if ks.pso_evals else 23000.0)
@@ -606,6 +649,31 @@ def main():
                                                    "set_mismatch_among_branched", "control_literal_y_outer_and_fused", "workload")}
             except Exception:
                 pass
+        # WHAT BINDS.  The tier's convention prices the kernel against HBM (`frac`); the kernel itself is bound
+        # by the vector ALU.  Two more fractions of the same launches, from the same HIP-event durations:
+        #   fp64_flops_frac : SURVEY 8(d)'s F_eval = S^2 (38 K + 30) flop per evaluation (K from the launches' own algorithmic bytes)
+        #                     x evaluations / time / 78.6 TFLOP/s (MI355X FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
+        #   valu_issue_frac : VALU instructions per evaluation (PMC SQ_INSTS_VALU of this kernel on this scene, committed under
+        #                     profiles/valu_model.json by scripts/valu_per_eval.sh) x evaluations x 4 cycles per wave64 instruction
+        #                     (scripts/ubench/inst_rate.hip, profiles/r06_inst_rate.txt: FP64 and 32-bit instructions of this mix alike
+        #                     occupy a 16-lane-per-clock slot) / (time x 1024 SIMDs x 2.4 GHz)
+        S2 = (2 * cfg.patchRadius + 1) ** 2
+        b_px = (e2_bytes / e2_evals / S2) if e2_evals else 0.0
+        k_eff = max((b_px - 1 - 8 * int(bool(cfg.adaptiveDistanceEnable)) - 8 * int(bool(cfg.adaptiveGradientEnable))) / 4.0, 0.0)
+        flop_eval = S2 * (38.0 * k_eff + 30.0)
+        FP64_PEAK, SIMDS, CLK = 78.6e12, 1024, 2.4e9
+        fp64_frac = (flop_eval * e2_evals / (e2_ms / 1e3) / FP64_PEAK) if e2_ms > 0 else None
+        valu_frac, valu_ipe, valu_src = None, None, None
+        try:
+            vm = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
+            ent = vm.get(args.scene, {}).get(dom)
+            if ent:
+                valu_ipe, valu_src = float(ent["valu_insts_per_eval"]), ent.get("source")
+                valu_frac = (valu_ipe * e2_evals * 4.0 / ((e2_ms / 1e3) * SIMDS * CLK)) if e2_ms > 0 else None
+        except Exception:
+            pass
+        fracs = {"hbm": e2_gbs / HBM_PEAK_GBS, "fp64": fp64_frac or 0.0, "valu_issue": valu_frac or 0.0}
+        bound = max(fracs, key=fracs.get)
         mb = None
         try:   # saturated rate of the same evaluation code (scripts/microbench_eval.py under profiles/)
             mb = json.load(open(os.path.join(ROOT, "profiles", "microbench_eval.json")))["evals_per_s"]
@@ -640,13 +708,21 @@ def main():
                        "stream_rounds_mode": os.environ.get("PAIS_STREAM_ROUNDS", "1 (adaptive: a round is streamed when the previous round's host "
                                                                                        "work was >= 0.9 ms and >= 4 % of its GPU time)"),
                        "literal_gate": literal_gate,
+                       "literal_arithmetic": literal_arith,
                        "cloud_vs_literal": cloud_vs_literal,
                        "predicted_speedup_at": scaling_model,
                        "emulated_speedup_at": emulated,
                        "parallelism": "1 process per GPU, candidates of a round sharded over %d GPU(s), one ncclAllGather of the "
                                       "records per sharded round (thin rounds replicated)" % world},
-            "roofline": {"bound": "hbm",
-                         "kernel": {"tile": "k_pso_tile (PAIS::getFitness, one workgroup per candidate x 8 particles, camera footprints staged in LDS; "
+            "roofline": {"bound": bound, "bound_by_convention": "hbm",
+                         "fp64_flops_frac": fp64_frac, "valu_issue_frac": valu_frac,
+                         "what_binds": {"fractions_of_peak": fracs, "fp64_flop_per_eval": flop_eval, "cameras_per_eval": k_eff,
+                                        "fp64_peak_tflops": FP64_PEAK / 1e12, "valu_insts_per_eval": valu_ipe, "valu_insts_source": valu_src,
+                                        "cycles_per_valu_inst": 4, "simds": SIMDS, "clock_ghz": CLK / 1e9,
+                                        "note": "`frac` (HBM, the tier's convention) counts algorithmic bytes that the caches serve; the binding "
+                                                "resource is the larger of the two vector-ALU fractions: valu_issue_frac (every VALU instruction of "
+                                                "the kernel, FP64 or not, takes a 4-cycle issue slot) contains fp64_flops_frac (the useful flops)"},
+                         "kernel": {"tile": "k_pso_tile / k_pso_tile2 (PAIS::getFitness, one workgroup per candidate x 8 particles, camera footprints staged in LDS; "
                                             "%d of the %d evaluation launches of the large batches, the rest its pending-only k_pso_eval2 launches)"
                                             % (int(ks.tile_launches), e2_n),
                                     "ring": "k_pso_ring ALONE (PAIS::getFitness + PsoSolver::run of a large batch as ONE launch: resident waves pop "

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                             }
                         *row0 = s;
                         tile2_post(flagA, 2 * st + 1);
+                        tile2_prio(false);
                     }
                 } else {
 #pragma unroll
@@ -435,8 +436,8 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                 // ---- 2. second half: the sum continued, the mean
                 double mean = 0;
                 if (state == 0 && role == 1) {
-                    tile2_prio(true);
                     tile2_wait(flagA, 2 * st + 1);
+                    tile2_prio(true); // (after the wait: a wave that spins at raised priority takes issue slots from its partner's taps)
                     double s = *row0;
 #pragma unroll
                     for (int u = 0; u < NP; ++u)
@@ -452,12 +453,14 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                     mean = s * invK;
                     *row0 = mean;
                     tile2_post(flagB, st + 1);
+                    tile2_prio(false);
                 }
                 TILE2_PHASE_BARRIER();
                 // ---- 3. first half: its share of the SAD; second half: |c - mean| in place
                 if (state == 0) {
                     if (role == 0) {
                         tile2_wait(flagB, st + 1);
+                        tile2_prio(true);
                         mean = *row0;
                         double sad = hasRef ? fabs(refCol - mean) : 0.0;
 #pragma unroll
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                 // ---- 4. second half: the SAD continued, the weight, the canonical sub-accumulator of the step
                 if (state == 0 && role == 1) {
                     tile2_wait(flagA, 2 * st + 2);
+                    tile2_prio(true);
                     double sad = *row1;
 #pragma unroll
                     for (int u = 0; u < NP; ++u)
