@@ -368,6 +368,9 @@ __device__ __forceinline__ void tap_group(const DevScene &sc, const EvalCam *cam
 //   NS 1, register accumulators  beyond                          the colour rows (NS x M x 512 B) cap the occupancy
 // pairs of cameras per trip of the one-pixel kernels' camera loop (dome, K <= 32: 2 with 2 waves / SIMD requested
 // +5.8 % patches/s -- the waves wait 60 % of their cycles at the 1.75 waves / SIMD the colour rows leave; 3 and 4 no better)
+#ifndef PAIS_WAVE_SUM8
+#define PAIS_WAVE_SUM8 1 // 0: eight separate wave_sum_x at the end of an evaluation (round 5; A/B builds)
+#endif
 #ifndef PAIS_NS1_UNROLL
 #define PAIS_NS1_UNROLL 2
 #endif
@@ -615,6 +618,56 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
             }
         }
     }
+    // one wave computes all four sub-accumulators: their eight butterflies as one (wave_sum8: same pairs, same bits)
+#if PAIS_WAVE_SUM8
+    if (nparts == 1) {
+        double a8[8], t8[8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            a8[a] = ACCREG ? accF[a] : myacc[a * 128];
+            a8[4 + a] = ACCREG ? accW[a] : myacc[a * 128 + 64];
+        }
+        wave_sum8(a8, t8);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f4[a] = t8[a];
+            w4[a] = t8[4 + a];
+        }
+        return 0;
+    }
+    if (nparts == 2) { // sub-accumulators part and part + 2
+        double a4[4], t4[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            // (part is wave-uniform: the selects below are scalar)
+            const double fA = ACCREG ? (part == 0 ? accF[2 * k] : accF[2 * k + 1]) : myacc[(part + 2 * k) * 128];
+            const double wA = ACCREG ? (part == 0 ? accW[2 * k] : accW[2 * k + 1]) : myacc[(part + 2 * k) * 128 + 64];
+            a4[k] = fA;
+            a4[2 + k] = wA;
+        }
+        wave_sum4(a4, t4);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if ((a & 1) == part) {
+                f4[a] = t4[a >> 1];
+                w4[a] = t4[2 + (a >> 1)];
+            }
+        return 0;
+    }
+    if (nparts == 4) { // sub-accumulator part
+        double a2[2], t2[2];
+        a2[0] = ACCREG ? (part == 0 ? accF[0] : part == 1 ? accF[1] : part == 2 ? accF[2] : accF[3]) : myacc[part * 128];
+        a2[1] = ACCREG ? (part == 0 ? accW[0] : part == 1 ? accW[1] : part == 2 ? accW[2] : accW[3]) : myacc[part * 128 + 64];
+        wave_sum2(a2, t2);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a == part) {
+                f4[a] = t2[0];
+                w4[a] = t2[1];
+            }
+        return 0;
+    }
+#endif
     // butterflies only for this wave's sub-accumulators (uniform conditions)
     if (ACCREG) {
 #pragma unroll

@@ -141,6 +141,66 @@ __device__ __forceinline__ double wave_sum_x(double v)
     v += wsum_dpp<0xB1>(v);                   // quad_perm [1, 0, 3, 2]  l ^ 1
     return v;
 }
+// EIGHT butterflies at once (round 6): the (fitness, weight) pairs of an evaluation's four canonical sub-accumulators.  As eight
+// wave_sum_x they were ~200 VALU instructions at the end of every evaluation (80 DPP moves, 32 permlane swaps, 48 additions, the
+// moves around them) -- 6 % of an evaluation at five cameras.  A level of the butterfly leaves the same sum in BOTH partners, so one
+// of them is free to carry another value: v_permlane32_swap(x, y) puts {x[l], x[l + 32]} into the lower 32 lanes and {y[l - 32], y[l]}
+// into the upper 32 -- ONE addition then holds the m = 32 level of x below and of y above; v_permlane16_swap does the same for the
+// 16-lane rows.  Two levels turn eight values into two registers (four additions + two instead of sixteen); the levels m = 8 ... 1 run
+// as before on those two; the eight totals are read from lanes 0 / 16 / 32 / 48.  The SAME pairs are added at every level of every
+// value (IEEE addition commutes): the bits of wave_sum_x.  ALL 64 lanes must be active.
+__device__ __forceinline__ double wsum_swapadd32(double x, double y)
+{
+    const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+__device__ __forceinline__ double wsum_swapadd16(double x, double y)
+{
+    const auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+__device__ __forceinline__ double wsum_const_lane(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+// a[0 .. 7] per lane -> t[j] = wave_sum_x(a[j]), wave-uniform
+__device__ __forceinline__ void wave_sum8(const double *a, double *t)
+{
+    // m = 32: lanes 0..31 hold the level of a[j], lanes 32..63 that of a[j + 4]
+    const double z0 = wsum_swapadd32(a[0], a[4]), z1 = wsum_swapadd32(a[1], a[5]);
+    const double z2 = wsum_swapadd32(a[2], a[6]), z3 = wsum_swapadd32(a[3], a[7]);
+    // m = 16: rows 0 / 1 / 2 / 3 of w0 hold a[0] / a[2] / a[4] / a[6], of w1 a[1] / a[3] / a[5] / a[7]
+    double w0 = wsum_swapadd16(z0, z2), w1 = wsum_swapadd16(z1, z3);
+    w0 += wsum_dpp<0x128>(w0);                  w1 += wsum_dpp<0x128>(w1);                  // l ^ 8
+    w0 += wsum_dpp<0x1B>(wsum_dpp<0x141>(w0));  w1 += wsum_dpp<0x1B>(wsum_dpp<0x141>(w1));  // l ^ 4
+    w0 += wsum_dpp<0x4E>(w0);                   w1 += wsum_dpp<0x4E>(w1);                   // l ^ 2
+    w0 += wsum_dpp<0xB1>(w0);                   w1 += wsum_dpp<0xB1>(w1);                   // l ^ 1
+    t[0] = wsum_const_lane(w0, 0);  t[2] = wsum_const_lane(w0, 16); t[4] = wsum_const_lane(w0, 32); t[6] = wsum_const_lane(w0, 48);
+    t[1] = wsum_const_lane(w1, 0);  t[3] = wsum_const_lane(w1, 16); t[5] = wsum_const_lane(w1, 32); t[7] = wsum_const_lane(w1, 48);
+}
+// the same for FOUR values (an evaluation shared by two waves: two sub-accumulators each) and for TWO (four waves)
+__device__ __forceinline__ void wave_sum4(const double *a, double *t)
+{
+    const double z0 = wsum_swapadd32(a[0], a[2]), z1 = wsum_swapadd32(a[1], a[3]); // lanes 0..31: a[0] / a[1], lanes 32..63: a[2] / a[3]
+    double w = wsum_swapadd16(z0, z1);                                              // rows 0 / 1 / 2 / 3: a[0] / a[1] / a[2] / a[3]
+    w += wsum_dpp<0x128>(w);
+    w += wsum_dpp<0x1B>(wsum_dpp<0x141>(w));
+    w += wsum_dpp<0x4E>(w);
+    w += wsum_dpp<0xB1>(w);
+    t[0] = wsum_const_lane(w, 0); t[1] = wsum_const_lane(w, 16); t[2] = wsum_const_lane(w, 32); t[3] = wsum_const_lane(w, 48);
+}
+__device__ __forceinline__ void wave_sum2(const double *a, double *t)
+{
+    double w = wsum_swapadd32(a[0], a[1]); // lanes 0..31: a[0], lanes 32..63: a[1]
+    w = wsum_swapadd16(w, w);
+    w += wsum_dpp<0x128>(w);
+    w += wsum_dpp<0x1B>(wsum_dpp<0x141>(w));
+    w += wsum_dpp<0x4E>(w);
+    w += wsum_dpp<0xB1>(w);
+    t[0] = wsum_const_lane(w, 0); t[1] = wsum_const_lane(w, 32);
+}
 __device__ __forceinline__ int wave_sum_i(int v)
 {
 #pragma unroll
