@@ -667,12 +667,14 @@ static int fit_pixel(const fit_px_ctx *f, double x, double y, double distW, doub
 /*    distance / gradient weights of every window pixel;                      */
 /*  * homography rows with fma, ONE reciprocal per group of the other cameras */
 /*    (pairs, one triple for an odd count), bilinear as three lerps,          */
-/*    colours summed reference first, mean / SAD scaled by 1/K, polynomial    */
-/*    exp, weight = (dist * grad) * diff;                                     */
+/*    colours summed reference first (from 13 cameras on in TWO groups: the  */
+/*    reference + the first 2*((M+4)/4) cameras, then the rest -- round 6),   */
+/*    mean / SAD scaled by 1/K, polynomial exp, weight = (dist * grad) * diff;*/
 /*  * pixel k = yi*S + xi goes to lane k%64 of sub-accumulator (k/64)%4; each */
 /*    (sub-accumulator, lane) adds its pixels in increasing k; wave64         */
 /*    butterfly per sub-accumulator, then ((a0 + a1) + a2) + a3.              */
 /* ------------------------------------------------------------------------ */
+#define PO_TWO_LEVEL_K 13 /* == PAIS_TWO_LEVEL_K of the HIP path (pais_eval.hpp) */
 static double lerp3_u8(const uint8_t *img, int cols, int qx, int qy, double bx, double by)
 {
     const uint8_t *r0 = img + (size_t)qy * cols + qx, *r1 = r0 + cols;
@@ -752,7 +754,12 @@ static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const
         const double refCol = lerp3_u8(refImg, refCols, qx0, qy0, x - (double)qx0, y - (double)qy0);
         double ws = s->cfg.adaptiveDistanceEnable ? s->gauss[xi * S + yi] : 1.0;
         if (s->cfg.adaptiveGradientEnable) ws *= po_det_exp_poly(-1.0 / (edgeImg[(size_t)ry * refCols + rx] * s->cfg.gradientWeighting));
-        double sum = hasRef ? refCol : 0.0;
+        /* round 6: patches seen by 13 or more cameras sum their colours (and the absolute deviations below) in TWO groups --
+         * the reference colour and the first h = 2 * ((M + 4) / 4) other cameras, then the remaining ones, each group sequentially,
+         * the two group sums added once -- so that two waves of the HIP path can each own a group (pais_tile2.hpp) */
+        const int twoLevel = K >= PO_TWO_LEVEL_K;
+        const int hSplit = twoLevel ? 2 * ((M + 4) / 4) : M;
+        double sum = hasRef ? refCol : 0.0, sum2 = 0.0;
         for (int i0 = 0; i0 < M;) {
             const int left = M - i0;
             const int g = (left >= 4 || left == 2) ? 2 : (left == 3 ? 3 : 1);
@@ -784,13 +791,17 @@ static double get_fitness_kernel(const po_scene *s, const po_patch *patch, const
                 if (!fast && !(jx >= 2 && jx < cols - 3 && jy >= 2 && jy < rows - 3)) return DBL_MAX; /* :999 -- whole call */
                 const int qx = (int)jx, qy = (int)jy;
                 c[i0 + u] = lerp3_u8(cam->img[LOD], cols, qx, qy, jx - (double)qx, jy - (double)qy);
-                sum += c[i0 + u];
+                if (i0 + u < hSplit) sum += c[i0 + u];
+                else sum2 += c[i0 + u];
             }
             i0 += g;
         }
+        if (twoLevel) sum += sum2;
         const double mean = sum * invK;
-        double sad = hasRef ? fabs(refCol - mean) : 0.0;
-        for (int i = 0; i < M; ++i) sad += fabs(c[i] - mean);
+        double sad = hasRef ? fabs(refCol - mean) : 0.0, sad2 = 0.0;
+        for (int i = 0; i < hSplit; ++i) sad += fabs(c[i] - mean);
+        for (int i = hSplit; i < M; ++i) sad2 += fabs(c[i] - mean);
+        if (twoLevel) sad += sad2;
         sad *= invK;
         double weight = ws;
         if (s->cfg.adaptiveDifferenceEnable) weight *= po_det_exp_poly(-(sad * sad) * invDiffW);

@@ -114,11 +114,9 @@ struct pais_ctx {
     int tileStrip2 = 14, tileStrip1 = 24; // 64-pixel steps per strip of the two instantiations (PAIS_TILE_STRIP2 / PAIS_TILE_STRIP1)
     int arithLiteral = 0;               // PAIS_ARITH=literal: the cost in the reference's own statements and summation order (pais_literal.hpp);
                                         // every batch then runs the launch-per-iteration pipeline k_pso_eval_lit + k_pso_step
-    int tileSplit = 0;                  // PAIS_TILE_SPLIT: 0 k_pso_tile (default); 1 the sixteen-wave kernel (pais_tile2.hpp: a particle's cameras
-                                        // shared by two waves) for every tile batch, k > 1 for batches of >= k cameras.  Same bits; measured
-                                        // 3 % SLOWER than k_pso_tile on the dome although it runs 18 % faster without the hand-over between
-                                        // the two waves (profiles/r06_tile2_diag.txt): the hand-over chain eats the occupancy it buys
-    int tileStripSplit = 24, tileBias = 3; // PAIS_TILE_STRIP_SPLIT / PAIS_TILE_BIAS: its strip length; cameras the first half takes beyond an even share
+    int tileSplit = 1;                  // PAIS_TILE_SPLIT: 1 (default) the sixteen-wave kernel of pais_tile2.hpp for every tile batch (a particle's cameras
+                                        // shared by two waves: <= 128 VGPRs, 4 waves / SIMD), k > 1 for batches of >= k cameras, 0 k_pso_tile.  Same bits.
+    int tileStripSplit = 16, tileBias = 3; // PAIS_TILE_STRIP_SPLIT / PAIS_TILE_BIAS: its strip length; cameras the first half takes beyond an even share
     int tileForceNs1 = 0;               // PAIS_TILE_FORCE_NS1 (tests): the one-pixel instantiation also for batches of <= 32 cameras
     unsigned char *d_tileH = nullptr;   // homography scratch of the tile kernel (pais_tile.hpp PAIS_TILE_SCALAR_H): 16 regions of tileHSlice bytes
     size_t tileHBytes = 0, tileHSlice = 0;

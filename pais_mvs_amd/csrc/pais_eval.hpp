@@ -17,7 +17,7 @@
 // "Kernel arithmetic" v5 (the CPU checker mirrors it statement by statement in its kernel-arithmetic
 // mode): homography rows with fma; ONE reciprocal per camera group (pairs, one triple for an odd count); tap bounds
 // tested on the truncated integer coordinate; bilinear as three lerps a + f (b - a); colours summed reference first,
-// then the other cameras in camIdx order; mean and SAD scaled by 1/K; weight = wStat * exp_poly(-sad^2 / diffW);
+// then the other cameras in camIdx order (from 13 cameras on in two groups: PAIS_TWO_LEVEL_K below); mean and SAD scaled by 1/K; weight = wStat * exp_poly(-sad^2 / diffW);
 // lane partial sums into four canonical sub-accumulators (64-pixel step mod 4), wave64 xor butterfly,
 // ((a0 + a1) + a2) + a3.
 #pragma once
@@ -35,6 +35,15 @@ struct EvalCam {        // one visible camera other than (the first occurrence o
 struct TapInfo { uint64_t imgOff; int w; uint32_t qpack; };
 static_assert(sizeof(EvalCam) == 128 && offsetof(EvalCam, imgOff) == 96, "EvalCam layout");
 #define PAIS_H_STRIDE 10 // doubles per homography in LDS: 9 + 1 padding, so that rows are 16-byte aligned (ds_read_b128)
+// Kernel arithmetic, round 6: a patch seen by PAIS_TWO_LEVEL_K or more cameras sums its colours -- and their absolute deviations
+// from the mean -- in TWO groups: the reference colour and the first h = 2 * ((M + 4) / 4) of the M other cameras, then the
+// remaining ones (the second group is about two cameras smaller: its owner in the split tile kernel also finishes the pixel);
+// each group sequentially in camIdx order, the two group sums added once.  (Fewer cameras: one sequential sum,
+// as before -- every golden vector of the pawn and ring scenes is unchanged.)  Why: two waves can then each own a group of a
+// particle's cameras and exchange two partial sums per pixel step instead of handing a running sum back and forth three times
+// (pais_tile2.hpp; the sequential form cost the split kernel everything its occupancy bought: profiles/r06_tile2_diag.txt).
+#define PAIS_TWO_LEVEL_K 13
+__host__ __device__ inline int two_level_split(int K, int M) { return K >= PAIS_TWO_LEVEL_K ? 2 * ((M + 4) / 4) : M; }
 struct EvalPatch {
     double ray[3], Cref[3], optNref[3], KRref[9], KTref[3];
     double lodScale;
@@ -526,6 +535,8 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
     const bool useDiff = sc.cfg.adaptiveDifferenceEnable != 0;
     const bool hasRef = ep->hasRef != 0;
     const double invK = 1.0 / (double)K;
+    const bool twoLevel = K >= PAIS_TWO_LEVEL_K;      // (wave-uniform)
+    const int hSplit = two_level_split(K, M);
     double *myc = cbuf + lane;
     constexpr bool ACCREG = ACCR;
     double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0}; // the lane's sub-accumulators (ACCREG)
@@ -566,6 +577,14 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
         }
 #pragma unroll
         for (int q = 0; q < NS; ++q) sum[q] = hasRef ? wp[q].refCol : 0.0;
+        // (two-level sums, K >= PAIS_TWO_LEVEL_K -- one-pixel kernels only: the two-pixel shapes are chosen for batches of <= 12
+        //  cameras.  Groups never straddle hSplit: it is even, the groups are pairs from 0 and one tail group at the end.  When the
+        //  walk reaches camera hSplit the first group's sum is set aside and the accumulator restarts from 0: 0 + c == c exactly)
+        double sumFirst[NS];
+#define PAIS_AT_SPLIT(c)                                                       \
+    if (NS == 1 && twoLevel && (c) == hSplit) {                                \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) { sumFirst[q] = sum[q]; sum[q] = 0.0; } \
+    }
         int c0 = 0;
 #if PAIS_NS1_UNROLL > 1
         // many cameras, one pixel per lane: PAIS_NS1_UNROLL pairs per trip, so that the loads of the later pairs are in flight
@@ -574,23 +593,42 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
         if (NS == 1)
             for (; M - c0 >= 2 * PAIS_NS1_UNROLL + 2 || M - c0 == 2 * PAIS_NS1_UNROLL; c0 += 2 * PAIS_NS1_UNROLL) {
 #pragma unroll
-                for (int u = 0; u < PAIS_NS1_UNROLL; ++u)
+                for (int u = 0; u < PAIS_NS1_UNROLL; ++u) {
+                    PAIS_AT_SPLIT(c0 + 2 * u)
                     tap_group<2, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0 + 2 * u, x, y, badBits, sum);
+                }
             }
 #endif
-        for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // pairs
+        for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) { // pairs
+            PAIS_AT_SPLIT(c0)
+            tap_group<2, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);
+        }
+        PAIS_AT_SPLIT(c0)
         if (M - c0 == 3) tap_group<3, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);      // odd count: one triple
         else if (M - c0 == 1) tap_group<1, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum); // a single camera
+#undef PAIS_AT_SPLIT
         // mean and mean absolute deviation of the K colours: one pass over the cameras serves the lane's NS pixels
         double mean[NS], sad[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
+            if (NS == 1 && twoLevel) sum[q] = sumFirst[q] + sum[q];
             mean[q] = sum[q] * invK;
             sad[q] = hasRef ? fabs(wp[q].refCol - mean[q]) : 0.0;
         }
-        for (int c = 0; c < M; ++c) {
+        for (int c = 0; c < hSplit; ++c) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) sad[q] += fabs(myc[(c * NS + q) * 64] - mean[q]);
+        }
+        if (NS == 1 && twoLevel) {
+            double sadB[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) sadB[q] = 0.0;
+            for (int c = hSplit; c < M; ++c) {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) sadB[q] += fabs(myc[(c * NS + q) * 64] - mean[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < NS; ++q) sad[q] += sadB[q];
         }
 #pragma unroll
         for (int q = 0; q < NS; ++q) {

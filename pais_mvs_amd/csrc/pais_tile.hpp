@@ -39,7 +39,8 @@
 #endif
 #ifndef TILE_EXP_DUP
 #define TILE_EXP_DUP 0            // measurement builds (scripts/dome_dup_profile.sh): ONE component of the walk executed twice, same results:
-#endif                            // 1 homography reads, 2 byte taps, 3 a whole camera group, 4 the per-pixel tail (mean, SAD, exp, accumulate), 5 WinPix loads
+#endif                            // 1 homography reads, 2 byte taps, 5 WinPix loads (3 a whole camera group, 4 the per-pixel tail: round 5's builds, retired
+                                  // with the two-group registers of round 6; profiles/r05_dome_tile_dup_profile.txt has their figures)
 #ifndef TILE_EXP_SKIP
 #define TILE_EXP_SKIP 0           // measurement builds, WRONG results (timing of the first seed pass only, scripts/dome_skip_profile.sh):
 #endif                            // 1 four of the five homography reads per camera replaced by constants, 2 the byte taps, 3 the exp of the tail
@@ -258,6 +259,10 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
         __syncthreads();
         const int M = ep->M, K = ep->K;
         const WinPix *wbase = win + (size_t)c * WS;
+        const int nPairs = (M >= 2) ? ((M & 1) ? (M - 3) / 2 : M / 2) : 0; // cameras 0 .. 2 nPairs - 1 in pairs, then a tail of 3, 1 or 0
+        const int tail0 = 2 * nPairs, nTail = M - tail0;
+        const bool twoLevel = K >= PAIS_TWO_LEVEL_K;
+        const int pA = twoLevel ? two_level_split(K, M) / 2 : nPairs, pB = nPairs - pA; // pairs of the first / second group
 
         // ---- the particle: normal, early exits, homographies (the statements of eval_fitness_parts)
         int state = have ? 0 : 3; // 0: walks the tiles, 1: DBL_MAX, 2: pending (checked walk by k_pso_eval2), 3: no particle
@@ -293,6 +298,9 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                 }
                 wave_sync();
                 if (!corners_inside(ep, cams, Hbuf, S, lane)) state = 2;
+                // (a group of more pairs than this instantiation's registers hold -- a patch of exactly 4 HP cameras none of which is
+                //  the reference camera: left to the checked walk like a particle that grazes an image border)
+                if (pA > NP / 2 || pB > NP / 2) state = 2;
             }
             if (lane == 0) {
                 if (state == 1) A.fit[i] = DBL_MAX;
@@ -325,8 +333,6 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
         const bool hasRef = ep->hasRef != 0;
         const double invK = uniform_d(1.0 / (double)K);
         double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0};
-        const int nPairs = (M >= 2) ? ((M & 1) ? (M - 3) / 2 : M / 2) : 0; // cameras 0 .. 2 nPairs - 1 in pairs, then a tail of 3, 1 or 0
-        const int tail0 = 2 * nPairs, nTail = M - tail0;
 
         // stage(strip, half): boxes -> layout -> LDS-DMA of the strip's tiles into `half`.  Two workgroup barriers inside;
         // every wave calls it with the same arguments.
@@ -484,66 +490,88 @@ __global__ __launch_bounds__(64 * TILE_WAVES, 2) void k_pso_tile(DevScene sc, un
                             y[q] = nopix ? ys : y[q];
                         }
                     }
-                    double col[2 * NP][NS], t3[3][NS];
+                    // The colours of the lane's pixels in registers, in the TWO groups of the kernel arithmetic (pais_eval.hpp, PAIS_TWO_LEVEL_K:
+                    // from 13 cameras on the reference colour + the first hSplit cameras are summed as one group, the rest as another; with
+                    // fewer cameras everything is the first group): group A = pairs 0 .. pA - 1, group B = pairs pA .. nPairs - 1, each with
+                    // its own statically indexed registers and its own running sum -- no test between two tap groups, no select.
+                    constexpr int HP = NP / 2; // pairs per group: pA = (M + 4) / 4 <= HP and nPairs - pA <= HP for every M < 4 HP (else: pending, above)
+                    double colA[2 * HP][NS], colB[2 * HP][NS], t3[3][NS];
+                    double sumB[NS], sumTail[NS]; // (sum[] is group A's, started from the reference colour above; the tail's is formed below)
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) t3[0][q] = t3[1][q] = t3[2][q] = 0;
+                    for (int q = 0; q < NS; ++q) {
+                        t3[0][q] = t3[1][q] = t3[2][q] = 0;
+                        sumB[q] = 0;
+                        sumTail[q] = 0;
+                    }
 #pragma unroll
-                    for (int u = 0; u < NP; ++u) {
-                        if (u < nPairs) {
-#if TILE_EXP_DUP == 3
-                            {
-                                double sumd[NS], cold[2][NS];
-#pragma unroll
-                                for (int q = 0; q < NS; ++q) sumd[q] = 0;
-                                tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, cold, sumd);
-#pragma unroll
-                                for (int q = 0; q < NS; ++q) asm volatile("" ::"v"(sumd[q]), "v"(cold[0][q]), "v"(cold[1][q]));
-                            }
-#endif
-                            tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, &col[2 * u], sum);
+                    for (int u = 0; u < HP; ++u) {
+                        if (u < pA) {
+                            tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * u, x, y, &colA[2 * u], sum);
                         } else {
 #pragma unroll
-                            for (int q = 0; q < NS; ++q) col[2 * u][q] = col[2 * u + 1][q] = 0;
+                            for (int q = 0; q < NS; ++q) colA[2 * u][q] = colA[2 * u + 1][q] = 0;
                         }
                     }
-                    if (nTail == 3) tile_tap_group<3, NS, SH>(sc, cams, tiles, Hbuf, hs, tail0, x, y, t3, sum);
-                    else if (nTail == 1) tile_tap_group<1, NS, SH>(sc, cams, tiles, Hbuf, hs, tail0, x, y, t3, sum);
+#pragma unroll
+                    for (int u = 0; u < HP; ++u) {
+                        if (u < pB) {
+                            tile_tap_group<2, NS, SH>(sc, cams, tiles, Hbuf, hs, 2 * (pA + u), x, y, &colB[2 * u], sumB);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < NS; ++q) colB[2 * u][q] = colB[2 * u + 1][q] = 0;
+                        }
+                    }
+                    if (nTail == 3) tile_tap_group<3, NS, SH>(sc, cams, tiles, Hbuf, hs, tail0, x, y, t3, sumTail);
+                    else if (nTail == 1) tile_tap_group<1, NS, SH>(sc, cams, tiles, Hbuf, hs, tail0, x, y, t3, sumTail);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) {
                         if (st + q >= s1) break; // uniform: the strip (the window) has no such step
-                        const double mean = sum[q] * invK;
-                        double sad = hasRef ? fabs(wp[q].refCol - mean) : 0.0;
-#pragma unroll
-                        for (int u = 0; u < NP; ++u) {
-                            if (u < nPairs) {
-                                sad += fabs(col[2 * u][q] - mean);
-                                sad += fabs(col[2 * u + 1][q] - mean);
+                        // the tail group continues the LAST group's sum (camIdx order): B's with two groups, else A's
+                        double sA = sum[q], sB = sumB[q];
+                        if (twoLevel) {
+                            if (nTail >= 1) sB += t3[0][q];
+                            if (nTail == 3) {
+                                sB += t3[1][q];
+                                sB += t3[2][q];
+                            }
+                            sA += sB; // (first group + second group)
+                        } else {
+                            if (nTail >= 1) sA += t3[0][q];
+                            if (nTail == 3) {
+                                sA += t3[1][q];
+                                sA += t3[2][q];
                             }
                         }
-                        if (nTail >= 1) sad += fabs(t3[0][q] - mean);
-                        if (nTail == 3) {
-                            sad += fabs(t3[1][q] - mean);
-                            sad += fabs(t3[2][q] - mean);
-                        }
-#if TILE_EXP_DUP == 4
-                        {
-                            double m2 = sum[q];
-                            asm volatile("" : "+v"(m2));
-                            const double mean2 = m2 * invK;
-                            double sad2 = hasRef ? fabs(wp[q].refCol - mean2) : 0.0;
+                        const double mean = sA * invK;
+                        double sad = hasRef ? fabs(wp[q].refCol - mean) : 0.0, sadB = 0.0;
 #pragma unroll
-                            for (int u = 0; u < NP; ++u) {
-                                if (u < nPairs) {
-                                    sad2 += fabs(col[2 * u][q] - mean2);
-                                    sad2 += fabs(col[2 * u + 1][q] - mean2);
-                                }
+                        for (int u = 0; u < HP; ++u) {
+                            if (u < pA) {
+                                sad += fabs(colA[2 * u][q] - mean);
+                                sad += fabs(colA[2 * u + 1][q] - mean);
                             }
-                            const double sq2 = sad2 * invK;
-                            double w2 = wp[q].wStat;
-                            if (useDiff) w2 *= det_exp_poly(mul_uniform(-(sq2 * sq2), invDiffW));
-                            asm volatile("" ::"v"(w2));
                         }
-#endif
+#pragma unroll
+                        for (int u = 0; u < HP; ++u) {
+                            if (u < pB) {
+                                sadB += fabs(colB[2 * u][q] - mean);
+                                sadB += fabs(colB[2 * u + 1][q] - mean);
+                            }
+                        }
+                        if (twoLevel) {
+                            if (nTail >= 1) sadB += fabs(t3[0][q] - mean);
+                            if (nTail == 3) {
+                                sadB += fabs(t3[1][q] - mean);
+                                sadB += fabs(t3[2][q] - mean);
+                            }
+                            sad += sadB;
+                        } else {
+                            if (nTail >= 1) sad += fabs(t3[0][q] - mean);
+                            if (nTail == 3) {
+                                sad += fabs(t3[1][q] - mean);
+                                sad += fabs(t3[2][q] - mean);
+                            }
+                        }
                         const bool act = wp[q].wStat >= 0.0;
                         const double sadq = sad * invK;
                         double weight = wp[q].wStat;

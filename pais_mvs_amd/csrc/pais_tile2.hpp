@@ -2,49 +2,52 @@
 // pais_tile.hpp with the cameras of a particle SPLIT over two waves (round 6).  Device-only; included by pais_kernels.hip
 // after pais_tile.hpp (whose staging -- boxes, layout, LDS-DMA -- it shares statement for statement).
 //
-// Why (profiles/r05_pmc_dome.txt, DESIGN.md 4.3).  k_pso_tile keeps the colours of ALL of a pixel's cameras in registers
+// Why (profiles/r05_pmc_dome.txt, DESIGN.md 4.4).  k_pso_tile keeps the colours of ALL of a pixel's cameras in registers
 // (mean first, then sum |c - mean|: two passes over the same colours, patch.cpp:1022-1027): 128 VGPRs of colours, 256 VGPRs
 // per wave, 2 waves per SIMD -- and the walk is a chain of exposed LDS round trips (homography read -> 40 instructions ->
 // byte taps -> 100 instructions) that two waves cannot cover: SQ_WAIT_ANY 47-50 % of the wave cycles with the VALU 35-49 % and
-// the LDS pipe 18-31 % busy.  Six tunings of that kernel moved nothing.  What it needs is more waves per SIMD, i.e. fewer
+// the LDS pipe 18-31 % busy.  Eleven tunings of that kernel moved nothing.  What it needs is more waves per SIMD, i.e. fewer
 // colours per wave.
 //
 // Mapping.  One workgroup = one candidate x 8 particles of one PSO iteration as before, but SIXTEEN waves: particle slot
-// p = wave & 7 is served by wave p ("first half", role 0: camera pairs 0 .. pA-1) and wave p + 8 ("second half", role 1:
-// pairs pA .. nPairs-1 and the odd tail).  One pixel per lane; a wave holds at most 2 NP colours, <= 128 VGPRs, 4 waves per
-// SIMD (each SIMD gets two waves of either role).  The canonical arithmetic is sequential over the cameras (reference
-// first, then camIdx order: pais_eval.hpp) and is kept BIT FOR BIT; per 64-pixel step the two waves of a particle hand
-// over through two 512-byte LDS rows:
-//   1. both tap their cameras from the tiles; role 0 sums ref + its colours -> row 0;                         hand-over
-//   2. role 1 continues that sum with its colours, mean = sum / K -> row 0;                                   hand-over
-//   3. role 0 adds |ref - mean| and its |c - mean| -> row 1; role 1 meanwhile turns its colours into |c - mean|; hand-over
-//   4. role 1 continues the SAD, weight = wStat * exp(-sad^2 / diffW), canonical sub-accumulators; role 0 is already
-//      tapping the next step.
-// A hand-over is a pair of LDS counters per particle (tile2_post / tile2_wait): a wave waits for ITS partner only.  (First
-// version: three workgroup barriers per step -- correct, and 9 % SLOWER than k_pso_tile: sixteen waves in lockstep expose
-// every hand-over latency to all of them at once; without any synchronisation -- wrong results -- the same code ran 18 %
-// faster than k_pso_tile: profiles/r06_tile2_diag.txt.)
-// Role 1 does steps 2 and 4 alone, so role 0 takes the larger share of the cameras (`bias`, in cameras).
+// p = wave & 7 is served by wave p ("first half", role 0) and wave p + 8 ("second half", role 1).  One pixel per lane; a wave
+// holds at most 2 NP colours, <= 128 VGPRs, 4 waves per SIMD (each SIMD gets two waves of either role).
+//
+// Arithmetic.  The kernel arithmetic sums the colours of a patch seen by >= 13 cameras in two groups (pais_eval.hpp,
+// PAIS_TWO_LEVEL_K): the reference colour + the first h = 2 * ((M + 4) / 4) cameras, then the rest; likewise the absolute
+// deviations.  The first half owns the first group, the second half the second (and the odd tail).  Per 64-pixel step:
+//   1. both tap their cameras from the tiles and sum their group;
+//   2. both post their group sum (a 512-byte LDS row + a counter), read the partner's, and compute the SAME mean
+//      (sumFirst + sumSecond) / K;
+//   3. both sum |c - mean| over their group; the first half posts its share and goes on to the next step;
+//   4. the second half adds the two shares, weight = wStat * exp(-sad^2 / diffW), canonical sub-accumulators.
+// A hand-over is a pair of LDS counters per particle (tile2_post / tile2_wait): a wave waits for ITS partner only, and only for
+// its ARRIVAL -- no wave waits for arithmetic the other one has yet to do on its behalf.  (The first two versions of this kernel
+// kept ONE sequential colour sum: the running sum went first -> second, the mean back, the SAD first -> second -- three hops per
+// step with ~100 dependent FP64 instructions on the critical path of BOTH waves.  Correct, and 3-10 % SLOWER than k_pso_tile,
+// although the same code without any hand-over -- wrong results -- ran 19.5 % faster: profiles/r06_tile2_diag.txt.  Hence the
+// two-level sums.)  A patch of fewer than 13 cameras inside a many-camera batch has one group: the first half taps it all, the
+// second half adds exact zeros and finishes.
 // Same results as k_pso_tile and as eval_window<1, false, true, true> (tests/test_gpu_parity.py:
 // test_dome_radius25_many_cameras, PAIS_TILE_VERIFY; the dome's cloud hash).
 #pragma once
 
 #define TILE2_WAVES 16
 #define TILE2_SLOTS 8 // particles of a workgroup
-#ifndef TILE2_SYNC
-#define TILE2_SYNC 0   // how the two waves of a particle hand over inside a step: 0 pair-wise LDS flags (a wave waits for ITS partner only),
-#endif                 // 2 workgroup barriers (the first version: all sixteen waves in lockstep -- every hand-over latency exposed to all of
-                       // them at once, measured +25 % of the kernel), 1 nothing (measurement build, WRONG results: what the hand-over costs)
-#if TILE2_SYNC == 2
-#define TILE2_PHASE_BARRIER() __syncthreads()
-#else
-#define TILE2_PHASE_BARRIER() wave_sync()
+#ifndef TILE2_LAYOUT_INTERLEAVED
+#define TILE2_LAYOUT_INTERLEAVED 1
 #endif
-// flag protocol (TILE2_SYNC == 0), per particle slot two counters in LDS, both 0 at the start of a task; step st = 0, 1, ...:
-//   first half : sum -> row 0, flagA = 2 st + 1 | waits flagB >= st + 1 | its SAD -> row 1, flagA = 2 st + 2
-//   second half: waits flagA >= 2 st + 1 | mean -> row 0, flagB = st + 1 | waits flagA >= 2 st + 2
+#ifndef TILE2_SYNC
+#define TILE2_SYNC 0   // 0 pair-wise LDS counters; 1 nothing (measurement build, WRONG results: what the hand-over costs)
+#endif
+// counter protocol, per particle slot two counters in LDS, both 0 at the start of a task; step st = 0, 1, ...:
+//   first half : group sum -> rowAsum[st & 1], flagA = 2 st + 1 | waits flagB >= st + 1 | its SAD share -> rowAsad, flagA = 2 st + 2
+//   second half: group sum -> rowBsum, flagB = st + 1 | waits flagA >= 2 st + 1 | ... | waits flagA >= 2 st + 2
 // LDS operations of one wave are carried out in issue order, so "data, then flag" needs no more than a compiler barrier; the
-// reader's data read is issued after the flag value has come back.
+// reader's data read is issued after the flag value has come back.  Re-use of the rows: rowBsum (st + 1) is written after the
+// second half has finished step st, which needed flagA = 2 st + 2, posted after the first half read rowBsum (st); rowAsad (st + 1)
+// is written after flagB >= st + 2, posted after the second half read rowAsad (st); rowAsum alternates by step parity -- the first
+// half may write its next sum while the second half has not yet read this one.
 __device__ __forceinline__ void tile2_post(volatile int *flag, int v)
 {
 #if TILE2_SYNC == 0
@@ -85,20 +88,9 @@ __host__ __device__ inline size_t tile2_fixed_lds_bytes(int Kmax)
     size_t b = eval_block_bytes(Kmax);                                    // EvalPatch + EvalCam[Kmax], shared by the waves
     b += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE2_SLOTS;     // homographies, per particle
     b += 2 * sizeof(TileBox) * (size_t)Kmax;                              // boxes (two sets)
-    b += sizeof(double) * 64 * 2 * TILE2_SLOTS;                           // hand-over rows: 2 per particle
+    b += sizeof(double) * 64 * 4 * TILE2_SLOTS;                           // hand-over rows: 4 per particle
     b += 128;                                                             // flags[0], pstate[8], hand-over counters[8][2]
     return (b + 15) & ~(size_t)15;
-}
-
-// pairs of cameras the first-half wave takes: its share is `bias` cameras larger than the second half's, which also does
-// steps 2 and 4 (NP: the colours of at most NP pairs fit a wave)
-__host__ __device__ inline int tile2_pairs_first(int M, int nPairs, int bias, int NP)
-{
-    int pA = (M + bias + 2) / 4;
-    if (pA > nPairs) pA = nPairs;
-    if (pA > NP) pA = NP;
-    if (nPairs - pA > NP) pA = nPairs - NP;
-    return pA < 0 ? 0 : pA;
 }
 
 // one camera group of the lane's pixel from the tiles: the statements of tile_tap_group<G, 1, false> without the running sum
@@ -202,9 +194,10 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
     size_t o = eval_block_bytes(Kmax);
     double *Hbuf = (double *)(smem + o) + (size_t)slot * Kmax * PAIS_H_STRIDE; o += sizeof(double) * PAIS_H_STRIDE * (size_t)Kmax * TILE2_SLOTS;
     TileBox *boxAll = (TileBox *)(smem + o);                                    o += 2 * sizeof(TileBox) * (size_t)Kmax; // [2][Kmax]
-    double *row0 = (double *)(smem + o) + (size_t)slot * 128 + lane;            // sum of the first half, then the mean
-    double *row1 = row0 + 64;                                                   // SAD of the first half
-    o += sizeof(double) * 64 * 2 * TILE2_SLOTS;
+    double *rowAsum = (double *)(smem + o) + (size_t)slot * 256 + lane;         // group sum of the first half: [2][64], by step parity
+    double *rowBsum = rowAsum + 128;                                            // group sum of the second half
+    double *rowAsad = rowAsum + 192;                                            // SAD share of the first half
+    o += sizeof(double) * 64 * 4 * TILE2_SLOTS;
     int *flags = (int *)(smem + o);                                             // [0]: some particle of the group walks the tiles
     int *pstate = flags + 1;                                                    // [slot]: != 0: the particle takes the checked walk (pending)
     volatile int *flagA = flags + 1 + TILE2_SLOTS + 2 * slot, *flagB = flagA + 1;   // hand-over counters of this slot (tile2_post / tile2_wait)
@@ -240,8 +233,14 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
         // the first-half wave takes pairs 0 .. pA - 1, the second-half wave the rest
         const int nPairs = (M >= 2) ? ((M & 1) ? (M - 3) / 2 : M / 2) : 0;
         const int tail0 = 2 * nPairs, nTail = M - tail0;
-        const int pA = tile2_pairs_first(M, nPairs, bias, NP);
-        const int cLo = role ? 2 * pA : 0, cHi = role ? M : 2 * pA; // this wave's cameras
+        // (the canonical two-level split of pais_eval.hpp: the first half owns the first group -- reference colour + hSplit cameras --,
+        //  the second half the second group and the odd tail.  A patch of fewer than PAIS_TWO_LEVEL_K cameras has ONE group: the first
+        //  half taps everything, the second half contributes the exact zeros 0.0 to sum and SAD and does the finishing)
+        const bool twoLevel = K >= PAIS_TWO_LEVEL_K;
+        const int pA = twoLevel ? two_level_split(K, M) / 2 : nPairs;
+        const int tailRole = twoLevel ? 1 : 0;
+        (void)bias;
+        const int cLo = role ? (twoLevel ? 2 * pA : M) : 0, cHi = role ? M : (twoLevel ? 2 * pA : M); // this wave's cameras
         const int myPairs = role ? (nPairs - pA) : pA;
 
         // ---- the particle: normal, early exits, this wave's homographies (the statements of eval_fitness_parts)
@@ -275,7 +274,9 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                     for (int q = 0; q < 9; ++q) Hbuf[cc * PAIS_H_STRIDE + q] = H[q];
                 }
                 wave_sync();
-                if (!corners_inside_range(ep, cams, Hbuf, S, lane, cLo, cHi) && lane == 0) atomicOr(&pstate[slot], 1);
+                // (more pairs in a group than this instantiation holds: cannot happen for Kmax <= 4 NP; left to the pending-only launch)
+                if ((pA > NP || nPairs - pA > NP || !corners_inside_range(ep, cams, Hbuf, S, lane, cLo, cHi)) && lane == 0)
+                    atomicOr(&pstate[slot], 1);
             }
         }
         __syncthreads();
@@ -332,6 +333,22 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
             }
             const int szFull = (th > 0 && tw > (tileBytes + 1) / th) ? tileBytes + 1 : tw * th;
             const int sz = min(szFull, tileBytes + 1);
+#if TILE2_LAYOUT_INTERLEAVED
+            // Which cameras get a tile when the area runs out must not be one half's problem: the area is handed out in the order
+            // first-group camera 0, second-group camera 0, first-group camera 1, ... (a camera that does not fit is tapped in global
+            // memory -- several times slower -- and a wave waits for its partner every step).  Exclusive prefix of the sizes in that
+            // order: every lane adds the sizes of the cameras that come before its own (wave-uniform broadcasts; once per strip).
+            const int hA = 2 * pA; // cameras of the first group (all of them without two levels)
+            const int myKey = lane < hA ? 2 * lane : 2 * (lane - hA) + 1;
+            int off = 0;
+            for (int j = 0; j < M; ++j) {
+                const int szj = __builtin_amdgcn_readlane(sz, j);
+                const int kj = j < hA ? 2 * j : 2 * (j - hA) + 1;
+                off += (kj < myKey) ? szj : 0; // (sizes are saturated at tileBytes + 1 and there are <= 64 of them: no overflow)
+            }
+            const int incl = off + sz;
+            const bool fits = sz > 0 && incl <= tileBytes;
+#else
             int incl = sz;
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) {
@@ -340,6 +357,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
             }
             const int off = incl - sz;
             const bool fits = sz > 0 && incl <= tileBytes;
+#endif
             if (!fits) { tw = 0; th = 0; }
             if (lane < M) {
                 // (the tile word of camera `lane` goes into this particle's record of it: written by the wave that taps it)
@@ -394,125 +412,100 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
             const int qA = 64 / S, rA = 64 - qA * S;
             const double xs = a0 + (double)((64 * s0) % S), ys = b0 + (double)((64 * s0) / S); // the strip's first pixel
             for (int st = s0; st < s1; ++st) {
+                if (state != 0) continue; // (no workgroup barrier inside a step: a particle's two waves synchronise with each other only)
                 double col[2 * NP], t3[3] = {0, 0, 0};
-                double refCol = 0, wStat = -1.0;
                 // ---- 1. this wave's taps of the step
-                if (state == 0) {
-                    const WinPix wp = wbase[64 * st + lane]; // (the padding lanes of the last step are masked entries)
-                    refCol = wp.refCol;
-                    wStat = wp.wStat;
-                    // lanes without a pixel tap the strip's first pixel: an address inside the tiles
-                    const bool nopix = 64 * st + lane >= S2;
-                    double x = nopix ? xs : a0 + (double)xw, y = nopix ? ys : b0 + (double)yw;
-                    xw += rA; yw += qA;
-                    yw += (xw >= S) ? 1 : 0;
-                    xw -= (xw >= S) ? S : 0;
+                const WinPix wp = wbase[64 * st + lane]; // (the padding lanes of the last step are masked entries)
+                // lanes without a pixel tap the strip's first pixel: an address inside the tiles
+                const bool nopix = 64 * st + lane >= S2;
+                double x = nopix ? xs : a0 + (double)xw, y = nopix ? ys : b0 + (double)yw;
+                xw += rA; yw += qA;
+                yw += (xw >= S) ? 1 : 0;
+                xw -= (xw >= S) ? S : 0;
 #pragma unroll
-                    for (int u = 0; u < NP; ++u) {
-                        if (u < myPairs) tile2_tap_group<2>(sc, cams, tiles, Hbuf, cLo + 2 * u, x, y, &col[2 * u]);
-                        else col[2 * u] = col[2 * u + 1] = 0;
-                    }
-                    if (role == 1) {
-                        if (nTail == 3) tile2_tap_group<3>(sc, cams, tiles, Hbuf, tail0, x, y, t3);
-                        else if (nTail == 1) tile2_tap_group<1>(sc, cams, tiles, Hbuf, tail0, x, y, t3);
-                    } else {
-                        tile2_prio(true);
-                        double s = hasRef ? refCol : 0.0;
-#pragma unroll
-                        for (int u = 0; u < NP; ++u)
-                            if (u < myPairs) {
-                                s += col[2 * u];
-                                s += col[2 * u + 1];
-                            }
-                        *row0 = s;
-                        tile2_post(flagA, 2 * st + 1);
-                        tile2_prio(false);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 2 * NP; ++u) col[u] = 0;
+                for (int u = 0; u < NP; ++u) {
+                    if (u < myPairs) tile2_tap_group<2>(sc, cams, tiles, Hbuf, cLo + 2 * u, x, y, &col[2 * u]);
+                    else col[2 * u] = col[2 * u + 1] = 0;
                 }
-                TILE2_PHASE_BARRIER();
-                // ---- 2. second half: the sum continued, the mean
-                double mean = 0;
-                if (state == 0 && role == 1) {
-                    tile2_wait(flagA, 2 * st + 1);
-                    tile2_prio(true); // (after the wait: a wave that spins at raised priority takes issue slots from its partner's taps)
-                    double s = *row0;
+                if (role == tailRole) {
+                    if (nTail == 3) tile2_tap_group<3>(sc, cams, tiles, Hbuf, tail0, x, y, t3);
+                    else if (nTail == 1) tile2_tap_group<1>(sc, cams, tiles, Hbuf, tail0, x, y, t3);
+                }
+                // ---- 2. this wave's group sum (pais_eval.hpp, two-level sums: the first group starts from the reference colour, the
+                // second from 0), handed to the partner; the partner's; the mean -- the same operands in the same order in both waves
+                tile2_prio(true);
+                double sOwn = (role == 0 && hasRef) ? wp.refCol : 0.0;
 #pragma unroll
-                    for (int u = 0; u < NP; ++u)
-                        if (u < myPairs) {
-                            s += col[2 * u];
-                            s += col[2 * u + 1];
-                        }
-                    if (nTail >= 1) s += t3[0];
-                    if (nTail == 3) {
-                        s += t3[1];
-                        s += t3[2];
+                for (int u = 0; u < NP; ++u)
+                    if (u < myPairs) {
+                        sOwn += col[2 * u];
+                        sOwn += col[2 * u + 1];
                     }
-                    mean = s * invK;
-                    *row0 = mean;
+                if (role == tailRole) { // (the tail continues the last group's sum)
+                    if (nTail >= 1) sOwn += t3[0];
+                    if (nTail == 3) {
+                        sOwn += t3[1];
+                        sOwn += t3[2];
+                    }
+                }
+                double sA, sB;
+                if (role == 0) {
+                    rowAsum[(st & 1) * 64] = sOwn;
+                    tile2_post(flagA, 2 * st + 1);
+                    tile2_prio(false); // (a wave that spins at raised priority takes issue slots from its partner's taps)
+                    tile2_wait(flagB, st + 1);
+                    tile2_prio(true);
+                    sA = sOwn;
+                    sB = *rowBsum;
+                } else {
+                    *rowBsum = sOwn;
                     tile2_post(flagB, st + 1);
                     tile2_prio(false);
-                }
-                TILE2_PHASE_BARRIER();
-                // ---- 3. first half: its share of the SAD; second half: |c - mean| in place
-                if (state == 0) {
-                    if (role == 0) {
-                        tile2_wait(flagB, st + 1);
-                        tile2_prio(true);
-                        mean = *row0;
-                        double sad = hasRef ? fabs(refCol - mean) : 0.0;
-#pragma unroll
-                        for (int u = 0; u < NP; ++u)
-                            if (u < myPairs) {
-                                sad += fabs(col[2 * u] - mean);
-                                sad += fabs(col[2 * u + 1] - mean);
-                            }
-                        *row1 = sad;
-                        tile2_post(flagA, 2 * st + 2);
-                        tile2_prio(false);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < NP; ++u)
-                            if (u < myPairs) {
-                                col[2 * u] = fabs(col[2 * u] - mean);
-                                col[2 * u + 1] = fabs(col[2 * u + 1] - mean);
-                            }
-                        t3[0] = fabs(t3[0] - mean); t3[1] = fabs(t3[1] - mean); t3[2] = fabs(t3[2] - mean);
-                    }
-                }
-                TILE2_PHASE_BARRIER();
-                // ---- 4. second half: the SAD continued, the weight, the canonical sub-accumulator of the step
-                if (state == 0 && role == 1) {
-                    tile2_wait(flagA, 2 * st + 2);
+                    tile2_wait(flagA, 2 * st + 1);
                     tile2_prio(true);
-                    double sad = *row1;
+                    sA = rowAsum[(st & 1) * 64];
+                    sB = sOwn;
+                }
+                const double mean = (sA + sB) * invK;
+                // ---- 3. this wave's share of the SAD; the first half hands its share over and goes on to the next step
+                double sadOwn = (role == 0 && hasRef) ? fabs(wp.refCol - mean) : 0.0;
 #pragma unroll
-                    for (int u = 0; u < NP; ++u)
-                        if (u < myPairs) {
-                            sad += col[2 * u];
-                            sad += col[2 * u + 1];
-                        }
-                    if (nTail >= 1) sad += t3[0];
-                    if (nTail == 3) {
-                        sad += t3[1];
-                        sad += t3[2];
+                for (int u = 0; u < NP; ++u)
+                    if (u < myPairs) {
+                        sadOwn += fabs(col[2 * u] - mean);
+                        sadOwn += fabs(col[2 * u + 1] - mean);
                     }
-                    const bool act = wStat >= 0.0;
-                    const double sadq = sad * invK;
-                    double weight = wStat;
-                    if (useDiff) weight *= det_exp_poly(mul_uniform(-(sadq * sadq), invDiffW));
-                    const int ga = st & 3; // (uniform)
+                if (role == tailRole) {
+                    if (nTail >= 1) sadOwn += fabs(t3[0] - mean);
+                    if (nTail == 3) {
+                        sadOwn += fabs(t3[1] - mean);
+                        sadOwn += fabs(t3[2] - mean);
+                    }
+                }
+                if (role == 0) {
+                    *rowAsad = sadOwn;
+                    tile2_post(flagA, 2 * st + 2);
+                    tile2_prio(false);
+                    continue;
+                }
+                // ---- 4. second half: the two shares added, the weight, the canonical sub-accumulator of the step
+                tile2_prio(false);
+                tile2_wait(flagA, 2 * st + 2);
+                tile2_prio(true);
+                const double sad = *rowAsad + sadOwn;
+                const bool act = wp.wStat >= 0.0;
+                const double sadq = sad * invK;
+                double weight = wp.wStat;
+                if (useDiff) weight *= det_exp_poly(mul_uniform(-(sadq * sadq), invDiffW));
+                const int ga = st & 3; // (uniform)
 #define PAIS_TACC(a)                                          \
     {                                                         \
         accW[a] = act ? (accW[a] + weight) : accW[a];         \
         accF[a] = act ? fma(weight, sadq, accF[a]) : accF[a]; \
     }
-                    if (ga == 0) PAIS_TACC(0) else if (ga == 1) PAIS_TACC(1) else if (ga == 2) PAIS_TACC(2) else PAIS_TACC(3)
+                if (ga == 0) PAIS_TACC(0) else if (ga == 1) PAIS_TACC(1) else if (ga == 2) PAIS_TACC(2) else PAIS_TACC(3)
 #undef PAIS_TACC
-                    tile2_prio(false);
-                }
+                tile2_prio(false);
             }
             if (dbg) tWalk += __builtin_readcyclecounter() - tc3;
         }
