@@ -37,6 +37,9 @@
 #ifndef TILE2_LAYOUT_INTERLEAVED
 #define TILE2_LAYOUT_INTERLEAVED 1
 #endif
+#ifndef TILE2_PAIR_MAP
+#define TILE2_PAIR_MAP 0
+#endif
 #ifndef TILE2_SYNC
 #define TILE2_SYNC 0   // 0 pair-wise LDS counters; 1 nothing (measurement build, WRONG results: what the hand-over costs)
 #endif
@@ -55,6 +58,9 @@ __device__ __forceinline__ void tile2_post(volatile int *flag, int v)
     *flag = v;
 #endif
 }
+#ifndef TILE2_WAIT_PROFILE
+#define TILE2_WAIT_PROFILE 0 // measurement builds: cycles the first-half / second-half wave of slot 0 spends waiting -> debug words 7 / 8
+#endif
 __device__ __forceinline__ void tile2_wait(volatile int *flag, int v)
 {
 #if TILE2_SYNC == 0
@@ -66,6 +72,16 @@ __device__ __forceinline__ void tile2_wait(volatile int *flag, int v)
     asm volatile("" ::: "memory");
 #endif
 }
+#if TILE2_WAIT_PROFILE
+#define TILE2_WAIT(flag, v)                                                                                         \
+    {                                                                                                               \
+        const unsigned long long t_ = __builtin_readcyclecounter();                                                 \
+        tile2_wait(flag, v);                                                                                        \
+        if (dbg && slot == 0 && lane == 0) atomicAdd(&dbg[7 + role], __builtin_readcyclecounter() - t_);            \
+    }
+#else
+#define TILE2_WAIT(flag, v) tile2_wait(flag, v)
+#endif
 // the hand-over phases are short chains of DEPENDENT instructions (22 additions one after the other, the exp) on the critical
 // path of a particle's two waves: at the default priority each of them queues behind the tap instructions of the SIMD's three
 // other waves.  Raised priority while a wave is in such a phase, back to 0 for the taps.
@@ -73,7 +89,7 @@ __device__ __forceinline__ void tile2_wait(volatile int *flag, int v)
 #define TILE2_CHAIN_PRIO 2
 #endif
 #ifndef TILE2_SPIN_SLEEP
-#define TILE2_SPIN_SLEEP 0
+#define TILE2_SPIN_SLEEP 3 // (0 / 1 / 3: 2 352 / 2 349 / 2 338 ms per dome reconstruction: profiles/r06_tile2_diag.txt)
 #endif
 __device__ __forceinline__ void tile2_prio(bool high)
 {
@@ -188,7 +204,11 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if TILE2_PAIR_MAP == 1
+    const int slot = wave >> 1, role = wave & 1;                 // (experiment: a particle's two waves on different SIMDs)
+#else
     const int slot = wave & (TILE2_SLOTS - 1), role = wave >> 3; // (a SIMD's waves w, w + 4, w + 8, w + 12: two of either role)
+#endif
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     size_t o = eval_block_bytes(Kmax);
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                     rowAsum[(st & 1) * 64] = sOwn;
                     tile2_post(flagA, 2 * st + 1);
                     tile2_prio(false); // (a wave that spins at raised priority takes issue slots from its partner's taps)
-                    tile2_wait(flagB, st + 1);
+                    TILE2_WAIT(flagB, st + 1);
                     tile2_prio(true);
                     sA = sOwn;
                     sB = *rowBsum;
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                     *rowBsum = sOwn;
                     tile2_post(flagB, st + 1);
                     tile2_prio(false);
-                    tile2_wait(flagA, 2 * st + 1);
+                    TILE2_WAIT(flagA, 2 * st + 1);
                     tile2_prio(true);
                     sA = rowAsum[(st & 1) * 64];
                     sB = sOwn;
@@ -490,7 +510,7 @@ __global__ __launch_bounds__(64 * TILE2_WAVES) void k_pso_tile2(DevScene sc, uns
                 }
                 // ---- 4. second half: the two shares added, the weight, the canonical sub-accumulator of the step
                 tile2_prio(false);
-                tile2_wait(flagA, 2 * st + 2);
+                TILE2_WAIT(flagA, 2 * st + 2);
                 tile2_prio(true);
                 const double sad = *rowAsad + sadOwn;
                 const bool act = wp.wStat >= 0.0;
