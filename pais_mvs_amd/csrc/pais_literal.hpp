@@ -15,8 +15,8 @@
 //     that order (:1029-1038), with fdlibm's exp (det_exp: the platform libm of the reference's MSVC build is not
 //     reproducible anywhere else; the CPU checker of the tests uses the same function);
 //   * sumWeight += weight; fitness += weight * avgSad over the pixels in the reference's x-outer / y-inner order (:979-1041):
-//     a wave computes 64 consecutive pixels of that order at a time, parks (weight, weight * avgSad) in LDS and every lane
-//     adds them one after the other (wave-uniform broadcast reads) -- a strict sequential sum, bit for bit the CPU's.
+//     a wave computes 64 consecutive pixels of that order at a time and every lane adds the 64 (weight, weight * avgSad) one after
+//     the other (v_readlane broadcasts) -- a strict sequential sum, bit for bit the CPU's.
 // Checker: the CPU restatement's literal cost with the same exp / sin / cos (tests/test_gpu_parity.py:
 // test_literal_arithmetic_cost_is_the_reference_statement).  Slower than the kernel arithmetic (a division per tap, two
 // serial chains of S*S additions per evaluation); bench.py reports its throughput next to the default's.
@@ -150,17 +150,15 @@ __device__ double eval_fitness_literal(const DevScene &sc, const EvalPatch *ep, 
             const double e = refEdge ? refEdge[(size_t)ry * refW + rx] : edge_on_the_fly(refImg, refW, refH, rx, ry, eMin, eMax);
             weight *= det_exp(-1.0 / (e * gradW)); // :1037
         }
-        // the 64 pixels of this trip, added in the reference's order by every lane alike
-        wave_sync();
-        srow[lane] = weight;
-        srow[64 + lane] = weight * avgSad;
-        wave_sync();
+        // the 64 pixels of this trip, added in the reference's order by every lane alike: lane j's (weight, weight * avgSad) are
+        // broadcast with v_readlane (an SGPR lane index: no LDS round trip inside the two serial chains of additions)
+        const double wf = weight * avgSad;
         unsigned long long todo = __ballot(live);
         while (todo) {
             const int j = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            sumWeight += srow[j];       // :1040
-            fitness += srow[64 + j];    // :1041
+            sumWeight += lane_get(weight, j); // :1040
+            fitness += lane_get(wf, j);       // :1041
         }
     }
     return fitness / sumWeight; // :1046 (NaN when every pixel was masked)

@@ -310,9 +310,6 @@ struct pais_mvs {
     std::unordered_map<uint64_t, uint32_t> emuIndex;               // candidate key -> position in emuRecs
     std::vector<pais_patch_result> emuRecs;
     double emuLatencyUs = 25.0;                                    // PAIS_EMU_LATENCY_US: modelled launch latency of the collective
-    std::vector<pais_patch_result> sendBuf;
-    std::vector<pais_candidate> shardCands; // this rank's candidates of a batch on the host-transport path, gathered (strided shards)
-    std::vector<unsigned char> wireSend, wireAll;
     std::vector<HostCamera> cams;
     std::vector<HostPatch *> patches; // index == id; nullptr once deleted  (map<int,Patch>, mvs.h:86)
     int alive = 0;

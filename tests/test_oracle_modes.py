@@ -54,6 +54,35 @@ def test_cost_modes_agree_to_rounding(pawn_small):
     assert n > 100 and worst <= 1e-12, worst
 
 
+def test_two_level_sums_of_many_camera_patches_agree_with_the_literal_cost(dome_small):
+    """Round 6: from 13 cameras on the kernel arithmetic sums the colours (and their absolute deviations) in two groups
+    (pais_eval.hpp PAIS_TWO_LEVEL_K == oracle PO_TWO_LEVEL_K): the same real-number function -- the cost agrees with the literal
+    statement to rounding on patches of 13 ... 20 cameras, r = 25, all weights."""
+    from oracle import po
+    from pais_mvs_amd.config import readme_config
+    L = po.lib()
+    rng = np.random.default_rng(8)
+    cfg = readme_config(patchRadius=25, distWeighting=25 / 3.0, reduceNormalRange=4.0, adaptiveGradientEnable=True, visibleCorrelation=0.6)
+    S = common.oracle_scene(cfg, dome_small)
+    worst, n, kmax = 0.0, 0, 0
+    for i, (X, vis) in enumerate(dome_small.seeds[:10]):
+        p = S.seed_patch(X, vis, key=i)
+        L.po_set_reference_camera(S.ptr, C.byref(p)); L.po_set_depth_and_ray(S.ptr, C.byref(p))
+        L.po_set_depth_range(S.ptr, C.byref(p)); L.po_set_lod(S.ptr, C.byref(p))
+        if p.drop or p.numCam < 13:
+            continue
+        kmax = max(kmax, p.numCam)
+        for j in range(4):
+            pos = [p.normalS[0] + rng.normal(0, .1), p.normalS[1] + rng.normal(0, .1), p.depth + rng.normal(0, .005)]
+            S.set_kernel_arithmetic(False); a = S.fitness(p, pos)
+            S.set_kernel_arithmetic(True); b = S.fitness(p, pos)
+            if a == common.DBL_MAX or b == common.DBL_MAX:
+                assert a == b
+                continue
+            worst = max(worst, abs(a - b) / abs(a)); n += 1
+    assert n >= 12 and kmax >= 13 and worst <= 1e-12, (n, kmax, worst)
+
+
 def test_literal_cost_with_deterministic_libm_is_the_literal_cost_up_to_the_libm(pawn_small):
     """po_scene.costLiteral (the checker of the HIP path's PAIS_ARITH=literal): the reference's cost statements and summation
     order with fdlibm's exp / sin / cos instead of the platform's -- the same values up to the libm's last bits, and far
