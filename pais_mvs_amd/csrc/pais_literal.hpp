@@ -21,6 +21,9 @@
 // test_literal_arithmetic_cost_is_the_reference_statement).  Slower than the kernel arithmetic (a division per tap, two
 // serial chains of S*S additions per evaluation); bench.py reports its throughput next to the default's.
 #pragma once
+#ifndef PAIS_LIT_SUM_LDS
+#define PAIS_LIT_SUM_LDS 0
+#endif
 
 // LDS of one evaluating wave: [EvalPatch][EvalCam x Kmax] [H: Kmax x 9] [colour rows: Kmax x 64] [xs, ys: 2 x 64] [w, wf: 2 x 64]
 __host__ __device__ inline size_t literal_lds_bytes(int Kmax)
@@ -154,12 +157,25 @@ __device__ double eval_fitness_literal(const DevScene &sc, const EvalPatch *ep, 
         // broadcast with v_readlane (an SGPR lane index: no LDS round trip inside the two serial chains of additions)
         const double wf = weight * avgSad;
         unsigned long long todo = __ballot(live);
+#if PAIS_LIT_SUM_LDS // (A/B build: the 64 values parked in LDS and read back with wave-uniform reads)
+        wave_sync();
+        srow[lane] = weight;
+        srow[64 + lane] = wf;
+        wave_sync();
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            sumWeight += srow[j];
+            fitness += srow[64 + j];
+        }
+#else
         while (todo) {
             const int j = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             sumWeight += lane_get(weight, j); // :1040
             fitness += lane_get(wf, j);       // :1041
         }
+#endif
     }
     return fitness / sumWeight; // :1046 (NaN when every pixel was masked)
 }
