@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpais_hip.so")
 
 HIP_SOURCES = ["pais_kernels.hip", "pais_capi.hip", "pais_mvs.hip", "pais_io.hip", "pais_pyramid.hip", "pais_seed.hip"]  # pais_mvs.hip: host scheduler
-HEADERS = ["pais_dev.hpp", "pais_detmath.hpp", "pais_internal.h", "pais_eval.hpp", "pais_tile.hpp", os.path.join("..", "..", "include", "pais_hip.h"),
+HEADERS = ["pais_dev.hpp", "pais_detmath.hpp", "pais_internal.h", "pais_eval.hpp", "pais_tile.hpp", "pais_tile2.hpp", "pais_literal.hpp", "pais_pre.hpp", os.path.join("..", "..", "include", "pais_hip.h"),
            os.path.join("..", "..", "include", "pais_mvs.h"), os.path.join("..", "..", "include", "pais_io.h"),
            os.path.join("..", "..", "include", "pais_pyramid.h"), os.path.join("..", "..", "include", "pais_seed.h")]
 # -ffp-contract=off: the PSO position/velocity update and the per-tap arithmetic keep

@@ -56,6 +56,8 @@ struct PassPlan {
     struct Slice { int lo, hi, parts; hipStream_t st; bool own; };
     int n = 0, Nmax = 0, Kmax = 0, maxIt = 0, nSl = 0, S = 1, afterGrid = 0, itNext = 0;
     bool useIter = false, useTile = false, useRing = false, hasSeeds = false, hostBatch = false;
+    bool usePre = false; // the swarm step writes the evaluations' set-up records (pais_pre.hpp): k_pso_ring / k_pso_eval2 + k_pso_step passes
+    size_t PB = 0;       // bytes of records per candidate
     int ringCUs = 0; // CUs' worth of resident waves the ring launch may take (a part of a streamed round: its share)
     Slice sl[16];
     int *cnt = nullptr, *nextCnt = nullptr;
@@ -153,6 +155,9 @@ struct pais_ctx {
     // k_pso_ring (pais_kernels.hip): the PSO pass of a large expansion batch as ONE launch over a device-side task ring
     double ringPerCam = 1843.0;         // PAIS_RING_PER_CAM: 9216 waves per iteration at five cameras
     int ringMode = 1;                   // PAIS_PSO_RING=0: large batches take the per-iteration launches (k_pso_eval2 + k_pso_step) instead
+    int preMode = 1;                    // PAIS_PRE_SETUP=0: every evaluation wave sets itself up (round 5 behaviour; A/B, tests)
+    double *d_pre = nullptr;            // per candidate and particle {status, homographies} (pais_pre.hpp)
+    size_t preBytes = 0;
     unsigned *d_ring = nullptr;         // task ring
     size_t ringBytes = 0;
     unsigned *d_ringCtl = nullptr;      // head, tail, done, error
@@ -388,6 +393,7 @@ static int ctx_init_work(pais_ctx *ctx)
     if (const char *e = getenv("PAIS_PSO_MINPER")) { int v = atoi(e); if (v >= 1) ctx->psoMinPer = v; }
     if (const char *e = getenv("PAIS_PSO_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 16) ctx->psoStreams = v; }
     if (const char *e = getenv("PAIS_PSO_RING")) ctx->ringMode = atoi(e);
+    if (const char *e = getenv("PAIS_PRE_SETUP")) ctx->preMode = atoi(e);
     if (const char *e = getenv("PAIS_RING_PER_CAM")) ctx->ringPerCam = atof(e);
     if (const char *e = getenv("PAIS_RING_TIMEOUT_MS")) {
         // 0 is the tests' hook (every ring pass "times out" and is re-run launch by launch); anything else must be a finite wait
@@ -461,6 +467,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     for (auto ev : ctx->subDone) (void)hipEventDestroy(ev);
     if (ctx->forkEv) (void)hipEventDestroy(ctx->forkEv);
     if (ctx->refEv) (void)hipEventDestroy(ctx->refEv);
+    (void)hipFree(ctx->d_pre);
     (void)hipFree(ctx->d_ring); (void)hipFree(ctx->d_ringCtl); (void)hipFree(ctx->d_arrive); (void)hipFree(ctx->d_tileH);
     if (ctx->h_ringCtl) (void)hipHostFree(ctx->h_ringCtl);
     (void)hipFree(ctx->d_cams); (void)hipFree(ctx->d_img); (void)hipFree(ctx->d_imgF); (void)hipFree(ctx->d_edge); (void)hipFree(ctx->d_gauss);
@@ -731,6 +738,13 @@ static int pass_open(pais_ctx *ctx, PassPlan &P, int pass, int againCount)
         if (grow(ctx, ctx->d_ring, ctx->ringBytes, ringNeed)) return -2;
         if (grow(ctx, ctx->d_arrive, ctx->arriveBytes, sizeof(int) * PAIS_ARRIVE_STRIDE * (size_t)n)) return -2;
     }
+    // the large-batch pipelines of the kernel arithmetic read the evaluations' set-up from records the swarm step writes
+    P.usePre = ctx->preMode != 0 && !ctx->arithLiteral && !P.useIter && !P.useTile && !(P.useRing && !pais_launch::pre_ring_ok(P.Kmax));
+    P.PB = pais_launch::pre_bytes_per_candidate(Nmax, P.Kmax);
+    if (P.usePre) {
+        if (grow(ctx, ctx->d_pre, ctx->preBytes, P.PB * (size_t)n)) return -2;
+        HIPCHK(pais_launch::pso_setup0(sc, ctx->d_psoStates, n, Nmax, P.Kmax, ctx->d_evalBlocks, ctx->d_pre, ctx->stream));
+    }
     if (P.useTile) { // homography scratch of the tile kernel's waves: a region per slice, 1024 workgroups' worth each
         const size_t slice = sizeof(double) * 10 * (size_t)PAIS_MAX_VIS * 8 * (PAIS_TILE_SCALAR_H ? 1024 : 1); // (unused unless the variant is built)
         if (grow(ctx, ctx->d_tileH, ctx->tileHBytes, slice * 16)) return -2;
@@ -778,11 +792,11 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
         if (P.itNext == 0 && itEnd > 0) {
             const unsigned long long ticks = (unsigned long long)(ctx->ringTimeoutMs * 1e5); // s_memrealtime counts at 100 MHz
             HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
-                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 0, ticks, ctx->stream));
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 0, ticks, ctx->stream, P.usePre ? ctx->d_pre : nullptr));
             Timed te; // (the kernel alone)
             if (te.begin(ctx, ctx->stream, &ctx->evRing)) return -2;
             HIPCHK(pais_launch::pso_ring(sc, P.d_out, ctx->d_psoStates, P.n, P.Nmax, P.Kmax, P.maxIt, ctx->d_evalBlocks, ctx->d_win, ctx->d_ring,
-                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 1, ticks, ctx->stream));
+                                         ctx->d_ringCtl, ctx->d_arrive, ctx->d_stat, P.ringCUs, 1, ticks, ctx->stream, P.usePre ? ctx->d_pre : nullptr));
             if (te.end()) return -2;
             HIPCHK(hipMemcpyAsync(ctx->h_ringCtl, ctx->d_ringCtl, PAIS_RING_CTL_BYTES * PAIS_RINGS, hipMemcpyDeviceToHost, ctx->stream));
             ctx->ringUsed = true;
@@ -818,12 +832,15 @@ static int pass_iterations(pais_ctx *ctx, PassPlan &P, int itEnd)
                 HIPCHK(pais_launch::pso_eval_literal(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo, q.st));
             else
                 HIPCHK(pais_launch::pso_eval(sc, stp, q.hi - q.lo, P.Nmax, P.Kmax, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
-                                             ctx->d_win + P.WB * (size_t)q.lo, 0, nullptr, q.st));
+                                             ctx->d_win + P.WB * (size_t)q.lo, 0, nullptr, q.st,
+                                             P.usePre ? (const double *)((const unsigned char *)ctx->d_pre + P.PB * (size_t)q.lo) : nullptr));
             if (te.end()) return -2;
             ctx->evalLaunches++;
             if (!P.useIter) ctx->eval2Launches++;
             if (P.useTile) ctx->tileLaunches++;
-            if (!P.useIter) HIPCHK(pais_launch::pso_step(sc, P.d_out + q.lo, stp, q.hi - q.lo, P.Nmax, ctx->d_stat, q.st));
+            if (!P.useIter)
+                HIPCHK(pais_launch::pso_step(sc, P.d_out + q.lo, stp, q.hi - q.lo, P.Nmax, ctx->d_stat, q.st, ctx->d_evalBlocks + P.EB * (size_t)q.lo,
+                                             P.usePre ? (double *)((unsigned char *)ctx->d_pre + P.PB * (size_t)q.lo) : nullptr, P.Kmax));
         }
     }
     if (itEnd > P.itNext) P.itNext = itEnd;

@@ -99,7 +99,12 @@ size_t pso_state_bytes_host(int Nmax);
 hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, unsigned char *states, int Nmax, int *activeList,
                     int *activeCount, unsigned char *evalBlocks, void *win, int Kmax, hipStream_t stream);
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int pendingOnly, unsigned long long *verify, hipStream_t stream);
+                    int pendingOnly, unsigned long long *verify, hipStream_t stream, const double *pre = nullptr);
+                    // pre: evaluation records of the slice's first candidate (pais_pre.hpp); nullptr: the evaluation sets itself up
+size_t pre_bytes_per_candidate(int Nmax, int Kmax);
+bool pre_ring_ok(int Kmax);
+hipError_t pso_setup0(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, double *pre,
+                      hipStream_t stream);
 bool tile_eligible(int Kmax);
 hipError_t pso_tile(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
                     int strip2, int strip1, int forceNs1, int split, int stripSplit, int bias, unsigned long long *dbg, double *hscr,
@@ -110,11 +115,11 @@ hipError_t pso_iter(const DevScene &sc, unsigned char *states, const int *active
                     int listHi, int Nmax, int Kmax, pais_patch_result *recs, unsigned long long *stat, int L, int finishOnly,
                     int nparts, const unsigned char *evalBlocks, const void *win, hipStream_t stream);
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
-                    unsigned long long *stat, hipStream_t stream);
+                    unsigned long long *stat, hipStream_t stream, const unsigned char *evalBlocks = nullptr, double *pre = nullptr, int Kmax = 1);
 size_t ring_words(int n, int Nmax, int maxIt);
 hipError_t pso_ring(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
                     const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive, unsigned long long *stat,
-                    int waves, int phase, unsigned long long timeoutTicks, hipStream_t stream); // phase 0: rings and counters prepared; 1: the launch
+                    int waves, int phase, unsigned long long timeoutTicks, hipStream_t stream, double *pre = nullptr); // phase 0: rings and counters prepared; 1: the launch
                     // timeoutTicks: longest wait of a wave for a ring entry, in ticks of the 100 MHz s_memrealtime counter
 hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpScratch, int grid, int *counters,
                  unsigned long long *stat, int Kmax, double *ratios, int *nextCounters, hipStream_t stream);

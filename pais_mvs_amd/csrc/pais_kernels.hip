@@ -832,15 +832,41 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
         pso_init_candidate(sc, &recs[c], c, states, Nmax, activeList, activeCount, evalBlocks, evalBlockBytes, win, lane);
 }
 
+// Device-coherent access to the swarm state (k_pso_ring: the state of a candidate is handed from wave to wave INSIDE a launch,
+// across XCDs with their own L2): agent-scope relaxed atomics compile to plain loads / stores with the sc1 bit -- served
+// at the device's coherence point, no fence, no cache invalidation under the image taps.
+__device__ __forceinline__ double cload(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void cstore(double *p, double v)
+{
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int cload(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool COH, class T> __device__ __forceinline__ T sload(const T *p) { return COH ? cload(p) : *p; }
+template <bool COH, class T> __device__ __forceinline__ void sstore(T *p, T v)
+{
+    if (COH) cstore(p, v);
+    else *p = v;
+}
+
+#include "pais_pre.hpp"
+
+// LDS of one swarm step: the swarm (Nmax * 14 doubles) + the scratch of swarm_eval_setup behind it
+__host__ __device__ inline size_t step_lds_bytes(int Nmax) { return sizeof(double) * (size_t)Nmax * (3 * 4 + 2) + pre_scratch_bytes(Nmax); }
+
 // The evaluation launch of large batches (split pipeline): one wave per (candidate, particle), nothing but the cost.
 // The candidate's constants come from the block k_pso_init prepared; positions from swarm buffer 0 (k_pso_step).
-template <int NS, bool BYTES, bool ACCR>
+template <int NS, bool BYTES, bool ACCR, bool PRE>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *states, int n, int Nmax, int Kmax,
                                                                     const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win,
-                                                                    int pendingOnly, unsigned long long *verify)
+                                                                    int pendingOnly, unsigned long long *verify, const double *pre)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
     unsigned char *smem = smem0 + (threadIdx.x >> 6) * eval_lds_bytes(NS, Kmax, ACCR); // wave-private scratch
+    const size_t preD = pre_rec_doubles(Kmax);
     EvalPatch *ep = (EvalPatch *)smem;
     EvalCam *cams = (EvalCam *)(smem + sizeof(EvalPatch));
     double *Hbuf = (double *)(smem + eval_block_bytes(Kmax));
@@ -861,6 +887,13 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
         const int active = hd->active, Nrun = hd->N;
         const double p0 = A.pos[iLoad][0], p1 = A.pos[iLoad][1], p2 = A.pos[iLoad][2];
         const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0;
+        // pre: the particle's record {status, homographies} written by the swarm step (pais_pre.hpp) instead of its position
+        const double *rec = PRE ? pre + preD * ((size_t)c * Nmax + iLoad) : nullptr;
+        double status0 = 0.0, hv = 0.0;
+        if (PRE) {
+            status0 = rec[0];
+            hv = lane < PAIS_H_STRIDE * Kmax ? rec[PAIS_PRE_HDR + lane] : 0.0;
+        }
         // pendingOnly: the launch behind k_pso_tile (pais_tile.hpp) -- only the particles it flagged for the checked walk
         const double pend = pendingOnly ? A.part[iLoad][0] : 1.0;
         if (!active || i >= Nrun || (pend != 1.0 && pendingOnly != 2)) continue;
@@ -868,7 +901,9 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_eval2(DevScene sc, unsigned char *sta
         stage_eval_block(smem, src, nwMax, lane, v0, v1);
         wave_sync();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
+        int st;
+        if (PRE) st = eval_fitness_pre<NS, BYTES, ACCR, false>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, rec, status0, hv, lane, f4, w4);
+        else st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
         if (lane == 0) {
             const double v = st ? DBL_MAX : combine_parts(f4, w4);
             // PAIS_TILE_VERIFY: the tile kernel's value against this walk's; mismatches are counted (and the first one kept)
@@ -1524,30 +1559,13 @@ __global__ PAIS_ITER_BOUNDS(nparts, NS) void k_pso_iter(DevScene sc, unsigned ch
 // Everything of PsoSolver::run() between two fitness passes, for ONE candidate, by one wave.
 // smem: Nmax*(3*4+2) doubles of LDS scratch.
 // Everything it reads was written by a previous launch.  Returns 1 if the run continues.
-// Device-coherent access to the swarm state (k_pso_ring: the state of a candidate is handed from wave to wave INSIDE a launch,
-// across XCDs with their own L2): agent-scope relaxed atomics compile to plain loads / stores with the sc1 bit -- served
-// at the device's coherence point, no fence, no cache invalidation under the image taps.
-__device__ __forceinline__ double cload(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void cstore(double *p, double v)
-{
-    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int cload(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool COH, class T> __device__ __forceinline__ T sload(const T *p) { return COH ? cload(p) : *p; }
-template <bool COH, class T> __device__ __forceinline__ void sstore(T *p, T v)
-{
-    if (COH) cstore(p, v);
-    else *p = v;
-}
-
 // COH: the state was written by another wave of THIS launch (k_pso_ring) and is read / written coherently
+// pre != nullptr: the records of the moved swarm's evaluations (pais_pre.hpp) are written as well -- preEp / preCams: the
+// candidate's evaluation block in LDS; pre: the candidate's first record; preD: doubles per record
 template <bool COH = false>
 __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax,
-                               unsigned char *smem, unsigned long long *stat, int lane)
+                               unsigned char *smem, unsigned long long *stat, int lane, const EvalPatch *preEp = nullptr,
+                               const EvalCam *preCams = nullptr, double *pre = nullptr, size_t preD = 0)
 {
     double(*pos)[3] = (double(*)[3])smem;
     double(*vec)[3] = pos + Nmax;
@@ -1646,6 +1664,7 @@ __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c,
             }
             sstore<COH>(&A.pBestFit[i], pBestFit[i]);
         }
+        if (pre) swarm_eval_setup<COH>(sc, preEp, preCams, pos, N, pBestFit + Nmax, pre, preD, lane);
         if (lane == 0) {
             sstore<COH>(&hd->iteration, it);
             sstore<COH>(&hd->gIdx, g);
@@ -1705,15 +1724,21 @@ __device__ int pso_step_wave(const DevScene &sc, pais_patch_result *recs, int c,
 __attribute__((noinline))
 #endif
 __device__ int pso_step_wave_ring(const DevScene &sc, pais_patch_result *recs, int c, PsoState *hd, int Nmax, unsigned char *smem,
-                                  unsigned long long *stat, int lane)
+                                  unsigned long long *stat, int lane, const EvalPatch *preEp, const EvalCam *preCams, double *pre, size_t preD)
 {
-    return pso_step_wave<true>(sc, recs, c, hd, Nmax, smem, stat, lane);
+    return pso_step_wave<true>(sc, recs, c, hd, Nmax, smem, stat, lane, preEp, preCams, pre, preD);
 }
 // the step kernel of large batches: one wave per candidate
+// pre != nullptr: the step also writes the evaluation records of the moved swarm (pais_pre.hpp) from the candidate's evaluation
+// block, which it stages in front of its scratch
 __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result *recs, unsigned char *states, int n,
-                                                 int Nmax, unsigned long long *stat)
+                                                 int Nmax, unsigned long long *stat, const unsigned char *evalBlocks, size_t evalBlockBytes,
+                                                 double *pre, int Kmax)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
+    unsigned char *smem = smem0 + (pre ? evalBlockBytes : 0);
+    const size_t preD = pre_rec_doubles(Kmax);
+    const int nwMax = (int)(evalBlockBytes / 8);
     // the step of one slice runs while the other slice's evaluation launch fills the GPU; its few waves sit on the
     // critical path of their own slice (next evaluation launch), so they take issue priority over the evaluation waves
     __builtin_amdgcn_s_setprio(3);
@@ -1722,7 +1747,41 @@ __global__ __launch_bounds__(64) void k_pso_step(DevScene sc, pais_patch_result 
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         if (!hd->active) continue;
-        pso_step_wave(sc, recs, c, hd, Nmax, smem, stat, lane);
+        if (pre) {
+            const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+            wave_sync();
+            stage_eval_block(smem0, src, nwMax, lane, lane < nwMax ? src[lane] : 0, lane + 64 < nwMax ? src[lane + 64] : 0);
+            wave_sync();
+        }
+        pso_step_wave(sc, recs, c, hd, Nmax, smem, stat, lane, (const EvalPatch *)smem0, (const EvalCam *)(smem0 + sizeof(EvalPatch)),
+                      pre ? pre + preD * (size_t)Nmax * (size_t)c : nullptr, preD);
+    }
+}
+
+// the records of the INITIAL swarm (k_begin / k_pso_init wrote the positions and the evaluation block): one wave per candidate
+__global__ __launch_bounds__(64) void k_pso_setup0(DevScene sc, unsigned char *states, int n, int Nmax, const unsigned char *evalBlocks,
+                                                   size_t evalBlockBytes, double *pre, int Kmax)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
+    double(*pos)[3] = (double(*)[3])(smem0 + evalBlockBytes);
+    double *scr = (double *)(pos + Nmax);
+    const int lane = threadIdx.x;
+    const size_t SB = pso_state_bytes(Nmax);
+    const size_t preD = pre_rec_doubles(Kmax);
+    const int nwMax = (int)(evalBlockBytes / 8);
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        PsoState *hd = (PsoState *)(states + SB * (size_t)c);
+        if (!hd->active) continue;
+        PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
+        const int N = hd->N;
+        const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
+        wave_sync();
+        stage_eval_block(smem0, src, nwMax, lane, lane < nwMax ? src[lane] : 0, lane + 64 < nwMax ? src[lane + 64] : 0);
+        for (int i = lane; i < N; i += 64)
+            for (int d = 0; d < 3; ++d) pos[i][d] = A.pos[i][d];
+        wave_sync();
+        swarm_eval_setup<false>(sc, (const EvalPatch *)smem0, (const EvalCam *)(smem0 + sizeof(EvalPatch)), pos, N, scr,
+                                pre + preD * (size_t)Nmax * (size_t)c, preD, lane);
     }
 }
 
@@ -1772,12 +1831,13 @@ __global__ __launch_bounds__(256) void k_ring_init(unsigned char *states, int n,
     for (int j = 0; j < N; ++j) seg[base + j] = ((unsigned)c << 8) | (unsigned)j;
 }
 
-template <int NS, bool BYTES, bool ACCR>
+template <int NS, bool BYTES, bool ACCR, bool PRE>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax,
                                                 const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win, unsigned *ringAll,
                                                 unsigned segWords, RingCtl *ctlAll, int *arrive, unsigned long long *stat, size_t ldsPerWave,
-                                                unsigned long long timeoutTicks)
+                                                unsigned long long timeoutTicks, double *pre)
 {
+    const size_t preD = pre_rec_doubles(Kmax);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
     unsigned char *smem = smem0 + (threadIdx.x >> 6) * ldsPerWave; // wave-private scratch (evaluation; the step reuses it)
     EvalPatch *ep = (EvalPatch *)smem;
@@ -1821,14 +1881,25 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
         const uint64_t *src = (const uint64_t *)(evalBlocks + evalBlockBytes * (size_t)c);
-        const double p0 = cload(&A.pos[i][0]), p1 = cload(&A.pos[i][1]), p2 = cload(&A.pos[i][2]);
+        // pre: the particle's record {status, homographies} written by the swarm step / k_pso_setup0 (pais_pre.hpp) instead of its position
+        double *crec = PRE ? pre + preD * (size_t)Nmax * (size_t)c : nullptr;
+        const double *rec = PRE ? crec + preD * (size_t)i : nullptr;
+        double p0 = 0, p1 = 0, p2 = 0, status0 = 0, hv = 0;
+        if (PRE) {
+            status0 = cload(&rec[0]);
+            hv = lane < PAIS_H_STRIDE * Kmax ? cload(&rec[PAIS_PRE_HDR + lane]) : 0.0;
+        } else {
+            p0 = cload(&A.pos[i][0]); p1 = cload(&A.pos[i][1]); p2 = cload(&A.pos[i][2]);
+        }
         const uint64_t v0 = lane < nwMax ? src[lane] : 0, v1 = lane + 64 < nwMax ? src[lane + 64] : 0;
         const int N = hd->N; // (written by k_begin, before this launch)
         wave_sync();
         stage_eval_block(smem, src, nwMax, lane, v0, v1);
         wave_sync();
         double f4[4], w4[4];
-        const int st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
+        int st;
+        if (PRE) st = eval_fitness_pre<NS, BYTES, ACCR, true>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, rec, status0, hv, lane, f4, w4);
+        else st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
         int old = 0;
         if (lane == 0) {
             cstore(&A.fit[i], st ? DBL_MAX : combine_parts(f4, w4));
@@ -1841,7 +1912,9 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         __builtin_amdgcn_s_setprio(3); // the step sits on the candidate's critical path
         if (lane == 0) cstore(&arrive[(size_t)c * PAIS_ARRIVE_STRIDE], 0);
         wave_sync();
-        const int cont = pso_step_wave_ring(sc, recs, c, hd, Nmax, smem, stat, lane);
+        // (with records: the step's scratch lies behind the evaluation block, which swarm_eval_setup reads -- this wave has just
+        //  evaluated a particle of candidate c, so the block in its LDS is c's)
+        const int cont = pso_step_wave_ring(sc, recs, c, hd, Nmax, smem + (PRE ? eval_block_bytes(Kmax) : 0), stat, lane, ep, cams, crec, preD);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every lane's part of the new swarm (and the counter reset) is out
         wave_sync();
         if (__builtin_amdgcn_readfirstlane(cont)) {
@@ -2302,25 +2375,45 @@ hipError_t pso_init(const DevScene &sc, const pais_patch_result *recs, int n, un
 }
 template <int NS, bool BYTES, bool ACCR>
 static hipError_t pso_eval2_launch(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks,
-                                   const void *win, int pendingOnly, unsigned long long *verify, hipStream_t stream)
+                                   const void *win, int pendingOnly, unsigned long long *verify, const double *pre, hipStream_t stream)
 {
     static LdsAttr attr;
     const size_t lds = eval_lds_bytes(NS, Kmax, ACCR) * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_pso_eval2<NS, BYTES, ACCR>, lds);
+    static LdsAttr attrPre;
+    hipError_t e = pre ? attrPre.ensure((const void *)k_pso_eval2<NS, BYTES, ACCR, true>, lds) : attr.ensure((const void *)k_pso_eval2<NS, BYTES, ACCR, false>, lds);
     if (e != hipSuccess) return e;
     // pending-only (behind k_pso_tile): a handful of particles at most -- a few waves scan the flags (grid-stride loop);
     // one workgroup per particle would queue tens of thousands of workgroups, each asking for LDS, behind the tile
     // kernel of the other sub-stream, which holds every CU's LDS (measured: 2.2 ms per launch spent waiting)
     const int grid = pendingOnly == 1 ? (int)(((long)n * Nmax < 256) ? (long)n * Nmax : 256) : eval_grid((long)n * Nmax);
-    hipLaunchKernelGGL((k_pso_eval2<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win, pendingOnly, verify);
+    if (pre)
+        hipLaunchKernelGGL((k_pso_eval2<NS, BYTES, ACCR, true>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+                           eval_block_bytes(Kmax), (const WinPix *)win, pendingOnly, verify, pre);
+    else
+        hipLaunchKernelGGL((k_pso_eval2<NS, BYTES, ACCR, false>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, states, n, Nmax, Kmax, evalBlocks,
+                           eval_block_bytes(Kmax), (const WinPix *)win, pendingOnly, verify, pre);
     return hipGetLastError();
 }
 // the evaluation launch of large batches: `states`, `evalBlocks`, `win` point at the slice's first candidate
 hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, const void *win,
-                    int pendingOnly, unsigned long long *verify, hipStream_t stream)
+                    int pendingOnly, unsigned long long *verify, hipStream_t stream, const double *pre)
 {
-    PAIS_SHAPE_DISPATCH(pso_eval2_launch, sc, states, n, Nmax, Kmax, evalBlocks, win, pendingOnly, verify, stream);
+    PAIS_SHAPE_DISPATCH(pso_eval2_launch, sc, states, n, Nmax, Kmax, evalBlocks, win, pendingOnly, verify, pre, stream);
+}
+// the evaluation records of the initial swarm of every active candidate (pais_pre.hpp); behind k_begin / k_pso_init
+size_t pre_bytes_per_candidate(int Nmax, int Kmax) { return pre_rec_bytes(Kmax) * (size_t)Nmax; }
+// (the one-pixel ring kernel with the step's record code needs 177 VGPRs -- 2 waves / SIMD instead of 3: it keeps setting itself up)
+bool pre_ring_ok(int Kmax) { return eval_shape(Kmax) != 2; }
+hipError_t pso_setup0(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, double *pre,
+                      hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    static LdsAttr attr;
+    const size_t lds = eval_block_bytes(Kmax) + sizeof(double) * 3 * (size_t)Nmax + pre_scratch_bytes(Nmax);
+    hipError_t e = attr.ensure((const void *)k_pso_setup0, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pso_setup0, dim3(n < 65536 ? n : 65536), dim3(64), lds, stream, sc, states, n, Nmax, evalBlocks, eval_block_bytes(Kmax), pre, Kmax);
+    return hipGetLastError();
 }
 // the evaluation launch of a PSO iteration under PAIS_ARITH=literal (pais_literal.hpp)
 hipError_t pso_eval_literal(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, hipStream_t stream)
@@ -2434,15 +2527,17 @@ size_t ring_words(int n, int Nmax, int maxIt) { return ring_seg_words(n, Nmax, m
 template <int NS, bool BYTES, bool ACCR>
 static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
                                   const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive,
-                                  unsigned long long *stat, int waves, int phase, unsigned long long timeoutTicks, hipStream_t stream)
+                                  unsigned long long *stat, int waves, int phase, unsigned long long timeoutTicks, double *pre, hipStream_t stream)
 {
     static LdsAttr attr;
     size_t per = eval_lds_bytes(NS, Kmax, ACCR);
-    const size_t stepBytes = sizeof(double) * (size_t)Nmax * (3 * 4 + 2) + 16;
+    // (with records the step's scratch lies behind the evaluation block and includes the scratch of swarm_eval_setup)
+    const size_t stepBytes = pre ? eval_block_bytes(Kmax) + step_lds_bytes(Nmax) : sizeof(double) * (size_t)Nmax * (3 * 4 + 2) + 16;
     if (per < stepBytes) per = stepBytes;
     per = (per + 15) & ~(size_t)15;
     const size_t lds = per * PAIS_WG_WAVES;
-    hipError_t e = attr.ensure((const void *)k_pso_ring<NS, BYTES, ACCR>, lds);
+    static LdsAttr attrPre;
+    hipError_t e = pre ? attrPre.ensure((const void *)k_pso_ring<NS, BYTES, ACCR, true>, lds) : attr.ensure((const void *)k_pso_ring<NS, BYTES, ACCR, false>, lds);
     if (e != hipSuccess) return e;
     const size_t words = ring_words(n, Nmax, maxIt), seg = ring_seg_words(n, Nmax, maxIt);
     if (seg >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
@@ -2460,22 +2555,29 @@ static hipError_t pso_ring_launch(const DevScene &sc, pais_patch_result *recs, u
     waves *= (NS == 1 ? 4 * PAIS_NS1_WAVES : 4 * PAIS_NS2_WAVES); // `waves` arrives as the number of CUs: resident waves per CU by shape
     int grid = (int)(tasks < waves ? tasks : waves);
     grid = (grid + PAIS_RINGS - 1) / PAIS_RINGS * PAIS_RINGS;
-    hipLaunchKernelGGL((k_pso_ring<NS, BYTES, ACCR>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, recs, states, n, Nmax, Kmax, evalBlocks,
-                       eval_block_bytes(Kmax), (const WinPix *)win, ring, (unsigned)seg, (RingCtl *)ctl, arrive, stat, per, timeoutTicks);
+    if (pre)
+        hipLaunchKernelGGL((k_pso_ring<NS, BYTES, ACCR, true>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, recs, states, n, Nmax, Kmax, evalBlocks,
+                           eval_block_bytes(Kmax), (const WinPix *)win, ring, (unsigned)seg, (RingCtl *)ctl, arrive, stat, per, timeoutTicks, pre);
+    else
+        hipLaunchKernelGGL((k_pso_ring<NS, BYTES, ACCR, false>), dim3(grid), dim3(64 * PAIS_WG_WAVES), lds, stream, sc, recs, states, n, Nmax, Kmax, evalBlocks,
+                           eval_block_bytes(Kmax), (const WinPix *)win, ring, (unsigned)seg, (RingCtl *)ctl, arrive, stat, per, timeoutTicks, pre);
     return hipGetLastError();
 }
 hipError_t pso_ring(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax, int maxIt,
                     const unsigned char *evalBlocks, const void *win, unsigned *ring, unsigned *ctl, int *arrive, unsigned long long *stat,
-                    int waves, int phase, unsigned long long timeoutTicks, hipStream_t stream)
+                    int waves, int phase, unsigned long long timeoutTicks, hipStream_t stream, double *pre)
 {
-    PAIS_SHAPE_DISPATCH(pso_ring_launch, sc, recs, states, n, Nmax, Kmax, maxIt, evalBlocks, win, ring, ctl, arrive, stat, waves, phase, timeoutTicks, stream);
+    PAIS_SHAPE_DISPATCH(pso_ring_launch, sc, recs, states, n, Nmax, Kmax, maxIt, evalBlocks, win, ring, ctl, arrive, stat, waves, phase, timeoutTicks, pre, stream);
 }
 hipError_t pso_step(const DevScene &sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax,
-                    unsigned long long *stat, hipStream_t stream)
+                    unsigned long long *stat, hipStream_t stream, const unsigned char *evalBlocks, double *pre, int Kmax)
 {
     int grid = n < 65536 ? n : 65536;
-    size_t lds = sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
-    hipLaunchKernelGGL(k_pso_step, dim3(grid), dim3(64), lds, stream, sc, recs, states, n, Nmax, stat);
+    static LdsAttr attr;
+    const size_t lds = pre ? eval_block_bytes(Kmax) + step_lds_bytes(Nmax) : sizeof(double) * (size_t)Nmax * (3 * 4 + 2);
+    hipError_t e = attr.ensure((const void *)k_pso_step, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pso_step, dim3(grid), dim3(64), lds, stream, sc, recs, states, n, Nmax, stat, evalBlocks, eval_block_bytes(Kmax), pre, Kmax);
     return hipGetLastError();
 }
 
