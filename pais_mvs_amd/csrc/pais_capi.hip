@@ -467,6 +467,7 @@ extern "C" void pais_ctx_destroy(pais_ctx *ctx)
     for (auto ev : ctx->subDone) (void)hipEventDestroy(ev);
     if (ctx->forkEv) (void)hipEventDestroy(ctx->forkEv);
     if (ctx->refEv) (void)hipEventDestroy(ctx->refEv);
+    pais_launch::ring_profile_print();
     (void)hipFree(ctx->d_pre);
     (void)hipFree(ctx->d_ring); (void)hipFree(ctx->d_ringCtl); (void)hipFree(ctx->d_arrive); (void)hipFree(ctx->d_tileH);
     if (ctx->h_ringCtl) (void)hipHostFree(ctx->h_ringCtl);

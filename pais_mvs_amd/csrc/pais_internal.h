@@ -103,6 +103,7 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
                     // pre: evaluation records of the slice's first candidate (pais_pre.hpp); nullptr: the evaluation sets itself up
 size_t pre_bytes_per_candidate(int Nmax, int Kmax);
 bool pre_ring_ok(int Kmax);
+void ring_profile_print(); // (measurement builds: -DPAIS_RING_PROFILE=1)
 hipError_t pso_setup0(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, double *pre,
                       hipStream_t stream);
 bool tile_eligible(int Kmax);

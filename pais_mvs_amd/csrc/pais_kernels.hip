@@ -1831,6 +1831,18 @@ __global__ __launch_bounds__(256) void k_ring_init(unsigned char *states, int n,
     for (int j = 0; j < N; ++j) seg[base + j] = ((unsigned)c << 8) | (unsigned)j;
 }
 
+// MEASUREMENT BUILDS ONLY (-DPAIS_RING_PROFILE=1, profiles/r06_ring_group_ab.txt): where a ring wave's time goes -- s_memtime at the phase
+// boundaries of every task, summed over all waves: [0] index (head atomic) [1] entry wait [2] loads + staging [3] evaluation
+// [4] fitness store + arrival [5] swarm step + publish [6] tasks [7] steps; printed when a context is destroyed
+#ifndef PAIS_RING_PROFILE
+#define PAIS_RING_PROFILE 0
+#endif
+#if PAIS_RING_PROFILE
+__device__ unsigned long long g_ringProf[8];
+#define PAIS_RP_MARK(v) const unsigned long long v = __builtin_amdgcn_s_memtime();
+#else
+#define PAIS_RP_MARK(v)
+#endif
 template <int NS, bool BYTES, bool ACCR, bool PRE>
 __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *recs, unsigned char *states, int n, int Nmax, int Kmax,
                                                 const unsigned char *evalBlocks, size_t evalBlockBytes, const WinPix *win, unsigned *ringAll,
@@ -1854,10 +1866,12 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
     const unsigned cap = segWords;
     const unsigned total = ctl->total; // (written by k_ring_init, before this launch)
     for (;;) {
+        PAIS_RP_MARK(rpA)
         unsigned idx = 0;
         if (lane == 0) idx = __hip_atomic_fetch_add(&ctl->head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
         if (idx >= cap) break;
+        PAIS_RP_MARK(rpB)
         unsigned e = PAIS_RING_EMPTY;
         unsigned long long t0 = 0;
         for (int spins = 0;; ++spins) {
@@ -1877,6 +1891,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         }
         e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
         if (e == PAIS_RING_EMPTY) break;
+        PAIS_RP_MARK(rpC)
         const int c = (int)(e >> 8), i = (int)(e & 255u);
         PsoState *hd = (PsoState *)(states + SB * (size_t)c);
         PsoArrays A = pso_arrays((unsigned char *)hd, Nmax);
@@ -1896,17 +1911,32 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         wave_sync();
         stage_eval_block(smem, src, nwMax, lane, v0, v1);
         wave_sync();
+#if PAIS_RING_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PAIS_RP_MARK(rpD)
         double f4[4], w4[4];
         int st;
         if (PRE) st = eval_fitness_pre<NS, BYTES, ACCR, true>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, rec, status0, hv, lane, f4, w4);
         else st = eval_fitness_parts<NS, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win + (size_t)c * WS, p0, p1, p2, lane, 0, 1, f4, w4);
         int old = 0;
+        PAIS_RP_MARK(rpE)
         if (lane == 0) {
             cstore(&A.fit[i], st ? DBL_MAX : combine_parts(f4, w4));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the fitness is at the coherence point before it is counted
             old = __hip_atomic_fetch_add(&arrive[(size_t)c * PAIS_ARRIVE_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         old = __builtin_amdgcn_readfirstlane(old);
+#if PAIS_RING_PROFILE
+        {
+            const unsigned long long rpF = __builtin_amdgcn_s_memtime();
+            if (lane == 0) {
+                atomicAdd(&g_ringProf[0], rpB - rpA); atomicAdd(&g_ringProf[1], rpC - rpB); atomicAdd(&g_ringProf[2], rpD - rpC);
+                atomicAdd(&g_ringProf[3], rpE - rpD); atomicAdd(&g_ringProf[4], rpF - rpE); atomicAdd(&g_ringProf[6], 1ULL);
+            }
+        }
+        PAIS_RP_MARK(rpG)
+#endif
         if (old != N - 1) continue;
         // this wave completed the candidate's iteration: its swarm step, then the next iteration's tasks (or the result)
         __builtin_amdgcn_s_setprio(3); // the step sits on the candidate's critical path
@@ -1930,6 +1960,12 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
             __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_s_setprio(0);
+#if PAIS_RING_PROFILE
+        {
+            const unsigned long long rpH = __builtin_amdgcn_s_memtime();
+            if (lane == 0) { atomicAdd(&g_ringProf[5], rpH - rpG); atomicAdd(&g_ringProf[7], 1ULL); }
+        }
+#endif
     }
 }
 
@@ -2604,4 +2640,19 @@ hipError_t after(const DevScene &sc, pais_patch_result *recs, int n, double *hpS
     return hipGetLastError();
 }
 
+void ring_profile_print()
+{
+#if PAIS_RING_PROFILE
+    unsigned long long h[8] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ringProf), sizeof(h)) != hipSuccess || h[6] == 0) return;
+    const char *nm[6] = {"index (head atomic)", "entry wait", "loads + staging", "evaluation", "fitness store + arrival", "swarm step + publish"};
+    double tot = 0;
+    for (int k = 0; k < 6; ++k) tot += (double)h[k];
+    fprintf(stderr, "[ring profile] %llu tasks, %llu steps; s_memtime ticks per task:\n", h[6], h[7]);
+    for (int k = 0; k < 6; ++k)
+        fprintf(stderr, "[ring profile]   %-26s %10.1f  (%5.1f %%)%s\n", nm[k], (double)h[k] / (double)h[6], 100.0 * (double)h[k] / tot,
+                k == 5 ? "  (per step: see steps)" : "");
+    fprintf(stderr, "[ring profile]   per step %.1f ticks\n", h[7] ? (double)h[5] / (double)h[7] : 0.0);
+#endif
+}
 } // namespace pais_launch
