@@ -523,11 +523,270 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
     return eval_window<NS, true, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
 }
 
+// ---- round 6: the walk of the two-pixel kernels with the taps of the NEXT trip in flight under the tail of this one ----
+// A trip of eval_window is: homographies (LDS) -> tap addresses -> 8..12 gathers -> s_waitcnt -> lerps -> mean / deviations / exp
+// -> accumulate.  The gathers are L2 hits whose whole latency the wave sat out (SQ_WAIT_ANY 45-50 % of the wave cycles at
+// 3 waves / SIMD, VALU issue 63-70 %: profiles/r06_pre_setup_ab.txt).  Rotated: the first camera group of trip t + 1 is
+// addressed and requested BEFORE the tail of trip t (its ~100 VALU instructions and LDS round trips then run under the
+// gathers), and finished at the top of the next iteration.  The same loads, the same operations on the same operands in the
+// same order per value: same bits.  The group is taken with a wave-uniform size (1, 2 or 3 cameras: the first group of the
+// partition tap_group's callers use), so one copy of the code serves every camera count.
+#ifndef PAIS_PIPE_TAPS
+#define PAIS_PIPE_TAPS 1
+#endif
+#ifndef PAIS_PIPE_CAP
+#define PAIS_PIPE_CAP 3 // cameras of the group in flight under the tail (3: also the triple of a 4-camera patch; 2: pairs and singles only)
+#endif
+template <int NS, bool BYTES> struct TapPend {
+    typename Tap<BYTES>::Row r0[NS][PAIS_PIPE_CAP], r1[NS][PAIS_PIPE_CAP];
+    double bx[NS][PAIS_PIPE_CAP], by[NS][PAIS_PIPE_CAP];
+};
+// G (wave-uniform, 1..3) cameras from c0 on: everything of tap_group up to and including the loads
+template <int NS, bool CHECK, bool BYTES>
+__device__ __forceinline__ void tap_issue(const DevScene &sc, const EvalCam *cams, const double *Hbuf, int c0, int G, double *x, double *y,
+                                          uint32_t *badBits, TapPend<NS, BYTES> &P)
+{
+#pragma unroll
+    for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(x[q]), "+v"(y[q]));
+    typedef typename Tap<BYTES>::Row RowTap;
+    constexpr uint32_t kElem = Tap<BYTES>::kElem;
+    double nx[NS][PAIS_PIPE_CAP], ny[NS][PAIS_PIPE_CAP], w[NS][PAIS_PIPE_CAP], rw[NS][PAIS_PIPE_CAP];
+    uint64_t tapWord[PAIS_PIPE_CAP];
+#pragma unroll
+    for (int u = 0; u < PAIS_PIPE_CAP; ++u) {
+        if (u < G) {
+            const double2 *H2 = (const double2 *)__builtin_assume_aligned(Hbuf + PAIS_H_STRIDE * (c0 + u), 16);
+            const double2 ha = H2[0], hb = H2[1], hc = H2[2], hd = H2[3], he = H2[4];
+            const double h0 = ha.x, h1 = ha.y, h2 = hb.x, h3 = hb.y, h4 = hc.x, h5 = hc.y, h6 = hd.x, h7 = hd.y, h8 = he.x;
+            tapWord[u] = (uint64_t)__double_as_longlong(he.y);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                w[q][u] = fma(h7, y[q], fma(h6, x[q], h8));
+                nx[q][u] = fma(h1, y[q], fma(h0, x[q], h2));
+                ny[q][u] = fma(h4, y[q], fma(h3, x[q], h5));
+            }
+        }
+    }
+    // one reciprocal per group and pixel: tap_group's statements by group size
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        if (PAIS_PIPE_CAP == 3 && G == 3) {
+            constexpr int L = PAIS_PIPE_CAP - 1;
+            const double p01 = w[q][0] * w[q][1];
+            const double r = rcp_cr(p01 * w[q][L]);
+            rw[q][L] = r * p01;
+            const double r01 = r * w[q][L];
+            rw[q][0] = r01 * w[q][1];
+            rw[q][1] = r01 * w[q][0];
+        } else if (G == 2) {
+            const double r = rcp_cr(w[q][0] * w[q][1]);
+            rw[q][0] = r * w[q][1];
+            rw[q][1] = r * w[q][0];
+        } else {
+            rw[q][0] = rcp_cr(w[q][0]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PAIS_PIPE_CAP; ++u) {
+        if (u < G) {
+            const int c = c0 + u;
+            int qxmax = 0, qymax = 0;
+            if (CHECK) {
+                const uint32_t qp = cams[c].qpack;
+                qxmax = (int)(qp & 0xffffu);
+                qymax = (int)(qp >> 16);
+            }
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)tapWord[u]), hi = __builtin_amdgcn_readfirstlane((uint32_t)(tapWord[u] >> 32));
+            const unsigned char *base = Tap<BYTES>::blob(sc) + (((uint64_t)(hi & 0xffu) << 32) | lo) * kElem;
+            const uint32_t cw = hi >> 8;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const double ix = nx[q][u] * rw[q][u], iy = ny[q][u] * rw[q][u];
+                const int qx = (int)ix, qy = (int)iy;
+                int px = qx, py = qy;
+                if (CHECK) {
+                    px = clamp_i32(qx, 2, qxmax);
+                    py = clamp_i32(qy, 2, qymax);
+                    badBits[q] = badBits[q] | (uint32_t)(px ^ qx) | (uint32_t)(py ^ qy);
+                }
+                P.bx[q][u] = __builtin_amdgcn_fract(ix);
+                P.by[q][u] = __builtin_amdgcn_fract(iy);
+                const uint32_t off = (__umul24((uint32_t)py, cw) + (uint32_t)px) * kElem;
+                P.r0[q][u] = load_row_at<RowTap>(base, off);
+                P.r1[q][u] = load_row_at<RowTap>(base, off + cw * kElem);
+            }
+        }
+    }
+}
+// ... and the rest of tap_group: lerps, colour rows, running sums (camera order within the pixel as in tap_group)
+template <int NS, bool BYTES>
+__device__ __forceinline__ void tap_finish(const TapPend<NS, BYTES> &P, double *myc, int c0, int G, double *sum)
+{
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int u = 0; u < PAIS_PIPE_CAP; ++u) {
+            if (u < G) {
+                const double col = lerp3(P.r0[q][u], P.r1[q][u], P.bx[q][u], P.by[q][u]);
+                myc[((c0 + u) * NS + q) * 64] = col;
+                sum[q] += col;
+            }
+        }
+}
+
+template <int NS, bool CHECK, bool BYTES, bool ACCR>
+__device__ int eval_window_pipe(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
+                                const WinPix *win, int lane, int part, int nparts, double *f4, double *w4)
+{
+    static_assert(NS == 2, "the rotated walk is the two-pixel kernels' (<= 12 cameras: one sequential colour sum)");
+    const int M = __builtin_amdgcn_readfirstlane(ep->M), K = ep->K;
+    const int S = sc.cfg.patchSize, S2 = S * S;
+    const double a0 = ep->a0, b0 = ep->b0;
+    const double invDiffW = uniform_d(1.0 / sc.cfg.diffWeighting);
+    const bool useDiff = sc.cfg.adaptiveDifferenceEnable != 0;
+    const bool hasRef = ep->hasRef != 0;
+    const double invK = 1.0 / (double)K;
+    double *myc = cbuf + lane;
+    constexpr bool ACCREG = ACCR;
+    double accF[4] = {0, 0, 0, 0}, accW[4] = {0, 0, 0, 0};
+    double *myacc = cbuf + (size_t)M * NS * 64 + lane;
+    if (!ACCREG) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) myacc[a * 64] = 0;
+    }
+    const int adv = 64 * nparts;
+    const int qA = adv / S, rA = adv - qA * S;
+    int yw = (64 * part + lane) / S, xw = (64 * part + lane) - yw * S;
+    // first group of the partition: pairs while 4 or more (or exactly 2) cameras remain, then a triple or a single one
+    const int G1 = M == 0 ? 0 : (M == 1 ? 1 : (M == 3 ? (PAIS_PIPE_CAP == 3 ? 3 : 0) : 2)); // (0: nothing in flight, the groups as in eval_window)
+    double x[NS], y[NS];
+    WinPix wp[NS];
+    uint32_t badBits[NS];
+    int gi[NS];
+    TapPend<NS, BYTES> P;
+    int st = part;
+    bool have = 64 * st < S2;
+#define PAIS_TRIP_HEAD()                                               \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q)                    \
+    {                                                                  \
+        const int stq = st + q * nparts;                               \
+        const int k = 64 * stq + lane;                                 \
+        wp[q] = win[64 * stq < S2 ? k : (S2 - 1)];                     \
+        x[q] = a0 + (double)xw;                                        \
+        y[q] = b0 + (double)yw;                                        \
+        badBits[q] = 0;                                                \
+        gi[q] = stq & 3;                                               \
+        xw += rA; yw += qA;                                            \
+        yw += (xw >= S) ? 1 : 0;                                       \
+        xw -= (xw >= S) ? S : 0;                                       \
+    }
+    if (have) {
+        PAIS_TRIP_HEAD()
+        if (G1) tap_issue<NS, CHECK, BYTES>(sc, cams, Hbuf, 0, G1, x, y, badBits, P);
+    }
+    while (have) {
+        double sum[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sum[q] = hasRef ? wp[q].refCol : 0.0;
+        if (G1) tap_finish<NS, BYTES>(P, myc, 0, G1, sum);
+        int c0 = G1;
+        for (; M - c0 >= 4 || M - c0 == 2; c0 += 2) tap_group<2, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);
+        if (M - c0 == 3) tap_group<3, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);
+        else if (M - c0 == 1) tap_group<1, NS, CHECK, BYTES>(sc, cams, Hbuf, myc, c0, x, y, badBits, sum);
+        // what the tail of this trip needs, set aside; then the next trip's head and the request of its first group
+        double tRef[NS], tStat[NS];
+        uint32_t tBad[NS];
+        int tGi[NS];
+        const int tSt = st;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            tRef[q] = wp[q].refCol;
+            tStat[q] = wp[q].wStat;
+            tBad[q] = badBits[q];
+            tGi[q] = gi[q];
+        }
+        st += NS * nparts;
+        have = 64 * st < S2;
+        if (have) {
+            PAIS_TRIP_HEAD()
+            if (G1) tap_issue<NS, CHECK, BYTES>(sc, cams, Hbuf, 0, G1, x, y, badBits, P);
+        }
+        // tail of trip tSt (eval_window's statements)
+        double mean[NS], sad[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            mean[q] = sum[q] * invK;
+            sad[q] = hasRef ? fabs(tRef[q] - mean[q]) : 0.0;
+        }
+        for (int c = 0; c < M; ++c) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) sad[q] += fabs(myc[(c * NS + q) * 64] - mean[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (64 * (tSt + q * nparts) >= S2) break; // uniform: the window has no such step
+            const bool act = tStat[q] >= 0.0;
+            if (CHECK && __any(act && tBad[q] != 0)) return 1; // :1001 -- whole call
+            const double sadq = sad[q] * invK;
+            double weight = tStat[q];
+            if (useDiff) weight *= det_exp_poly(mul_uniform(-(sadq * sadq), invDiffW));
+            if (ACCREG) {
+#define PAIS_ACC(a)                                           \
+    {                                                         \
+        accW[a] = act ? (accW[a] + weight) : accW[a];         \
+        accF[a] = act ? fma(weight, sadq, accF[a]) : accF[a]; \
+    }
+                const int ga = __builtin_amdgcn_readfirstlane(tGi[q]);
+                if (ga == 0) PAIS_ACC(0) else if (ga == 1) PAIS_ACC(1) else if (ga == 2) PAIS_ACC(2) else PAIS_ACC(3)
+#undef PAIS_ACC
+            } else {
+                double *pa = myacc + tGi[q] * 128;
+                const double w0 = pa[64], f0 = pa[0];
+                pa[64] = act ? (w0 + weight) : w0;
+                pa[0] = act ? fma(weight, sadq, f0) : f0;
+            }
+        }
+    }
+#undef PAIS_TRIP_HEAD
+    if (nparts == 1) {
+        double a8[8], t8[8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            a8[a] = ACCREG ? accF[a] : myacc[a * 128];
+            a8[4 + a] = ACCREG ? accW[a] : myacc[a * 128 + 64];
+        }
+        wave_sum8(a8, t8);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f4[a] = t8[a];
+            w4[a] = t8[4 + a];
+        }
+        return 0;
+    }
+    if (ACCREG) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if ((a - part) % nparts != 0 || a < part) continue;
+            f4[a] = wave_sum_x(accF[a]);
+            w4[a] = wave_sum_x(accW[a]);
+        }
+    } else {
+        for (int a = part; a < 4; a += nparts) {
+            f4[a] = wave_sum_x(myacc[a * 128]);
+            w4[a] = wave_sum_x(myacc[a * 128 + 64]);
+        }
+    }
+    return 0;
+}
+
 // the window walk of one evaluation (homographies in Hbuf); CHECK: see corners_inside
 template <int NS, bool CHECK, bool BYTES, bool ACCR>
 __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCam *cams, double *Hbuf, double *cbuf,
                            const WinPix *win, int lane, int part, int nparts, double *f4, double *w4)
 {
+#if PAIS_PIPE_TAPS
+    if constexpr (NS == 2) return eval_window_pipe<NS, CHECK, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
+#endif
     const int M = ep->M, K = ep->K;
     const int S = sc.cfg.patchSize, S2 = S * S;
     const double a0 = ep->a0, b0 = ep->b0;

@@ -2439,7 +2439,10 @@ hipError_t pso_eval(const DevScene &sc, unsigned char *states, int n, int Nmax, 
 // the evaluation records of the initial swarm of every active candidate (pais_pre.hpp); behind k_begin / k_pso_init
 size_t pre_bytes_per_candidate(int Nmax, int Kmax) { return pre_rec_bytes(Kmax) * (size_t)Nmax; }
 // (the one-pixel ring kernel with the step's record code needs 177 VGPRs -- 2 waves / SIMD instead of 3: it keeps setting itself up)
-bool pre_ring_ok(int Kmax) { return eval_shape(Kmax) != 2; }
+#ifndef PAIS_PRE_RING_NS1
+#define PAIS_PRE_RING_NS1 0
+#endif
+bool pre_ring_ok(int Kmax) { return PAIS_PRE_RING_NS1 || eval_shape(Kmax) != 2; }
 hipError_t pso_setup0(const DevScene &sc, unsigned char *states, int n, int Nmax, int Kmax, const unsigned char *evalBlocks, double *pre,
                       hipStream_t stream)
 {
