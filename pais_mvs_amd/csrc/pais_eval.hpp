@@ -532,7 +532,7 @@ __device__ int eval_fitness_parts(const DevScene &sc, const EvalPatch *ep, const
 // same order per value: same bits.  The group is taken with a wave-uniform size (1, 2 or 3 cameras: the first group of the
 // partition tap_group's callers use), so one copy of the code serves every camera count.
 #ifndef PAIS_PIPE_TAPS
-#define PAIS_PIPE_TAPS 1
+#define PAIS_PIPE_TAPS 0 // measured slower (register spills: profiles/r06_pipe_taps_ab.txt); 1 builds it
 #endif
 #ifndef PAIS_PIPE_CAP
 #define PAIS_PIPE_CAP 3 // cameras of the group in flight under the tail (3: also the triple of a 4-camera patch; 2: pairs and singles only)
