@@ -787,7 +787,9 @@ __device__ int eval_window(const DevScene &sc, const EvalPatch *ep, const EvalCa
 #if PAIS_PIPE_TAPS
     if constexpr (NS == 2) return eval_window_pipe<NS, CHECK, BYTES, ACCR>(sc, ep, cams, Hbuf, cbuf, win, lane, part, nparts, f4, w4);
 #endif
-    const int M = ep->M, K = ep->K;
+    // (wave-uniform by construction; said to the compiler, which otherwise keeps the camera loops' counters in vector registers and
+    //  runs them under exec masks: 3 of the 7 VALU instructions per camera of the deviation loop were the counter)
+    const int M = __builtin_amdgcn_readfirstlane(ep->M), K = __builtin_amdgcn_readfirstlane(ep->K);
     const int S = sc.cfg.patchSize, S2 = S * S;
     const double a0 = ep->a0, b0 = ep->b0;
     const double invDiffW = uniform_d(1.0 / sc.cfg.diffWeighting);
