@@ -835,6 +835,35 @@ __global__ __launch_bounds__(64) void k_pso_init(DevScene sc, const pais_patch_r
 // Device-coherent access to the swarm state (k_pso_ring: the state of a candidate is handed from wave to wave INSIDE a launch,
 // across XCDs with their own L2): agent-scope relaxed atomics compile to plain loads / stores with the sc1 bit -- served
 // at the device's coherence point, no fence, no cache invalidation under the image taps.
+// EXPERIMENT (-DPAIS_RING_XCD_SCOPE=1, profiles/r06_ring_xcd_scope.txt; NOT a product configuration): the ring's shared state at the
+// scope of ONE XCD's L2 instead of the device -- loads as returning atomic ORs of 0 without sc1 (an atomic executes in the L2), stores
+// as plain write-through stores, counters as workgroup-scope atomics.  Correct only while every wave that works a ring runs on the
+// same XCD as the ring's other waves (workgroup b -> XCD b % 8 is how the dispatcher deals workgroups out today; nothing guarantees it).
+#ifndef PAIS_RING_XCD_SCOPE
+#define PAIS_RING_XCD_SCOPE 0
+#endif
+#if PAIS_RING_XCD_SCOPE
+#define PAIS_RING_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+__device__ __forceinline__ unsigned long long l2_load64(const void *p)
+{
+    unsigned long long r, z = 0;
+    asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p), "v"(z) : "memory");
+    return r;
+}
+__device__ __forceinline__ unsigned l2_load32(const void *p)
+{
+    unsigned r, z = 0;
+    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p), "v"(z) : "memory");
+    return r;
+}
+__device__ __forceinline__ double cload(const double *p) { return __longlong_as_double((long long)l2_load64(p)); }
+__device__ __forceinline__ void cstore(double *p, double v) { __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int cload(const int *p) { return (int)l2_load32(p); }
+__device__ __forceinline__ void cstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned rload(const unsigned *p) { return l2_load32(p); }
+__device__ __forceinline__ void rstore(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#else
+#define PAIS_RING_SCOPE __HIP_MEMORY_SCOPE_AGENT
 __device__ __forceinline__ double cload(const double *p)
 {
     return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -845,6 +874,9 @@ __device__ __forceinline__ void cstore(double *p, double v)
 }
 __device__ __forceinline__ int cload(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cstore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned rload(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rstore(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 template <bool COH, class T> __device__ __forceinline__ T sload(const T *p) { return COH ? cload(p) : *p; }
 template <bool COH, class T> __device__ __forceinline__ void sstore(T *p, T v)
 {
@@ -1868,22 +1900,22 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
     for (;;) {
         PAIS_RP_MARK(rpA)
         unsigned idx = 0;
-        if (lane == 0) idx = __hip_atomic_fetch_add(&ctl->head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) idx = __hip_atomic_fetch_add(&ctl->head, 1u, __ATOMIC_RELAXED, PAIS_RING_SCOPE);
         idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
         if (idx >= cap) break;
         PAIS_RP_MARK(rpB)
         unsigned e = PAIS_RING_EMPTY;
         unsigned long long t0 = 0;
         for (int spins = 0;; ++spins) {
-            e = __hip_atomic_load(&ring[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e = rload(&ring[idx]);
             if (e != PAIS_RING_EMPTY) break;
             if ((spins & 7) == 7) { // (the shared words are looked at now and then: thousands of idle waves poll)
-                if (__hip_atomic_load(&ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break; // every run of this ring has ended
-                if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (rload(&ctl->done) >= total) break; // every run of this ring has ended
+                if (rload(&ctl->error) != 0) break;
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (spins == 7) t0 = now;
                 if (now - t0 >= timeoutTicks) { // nobody has published this entry for `timeoutTicks` of wall time
-                    if (lane == 0) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) rstore(&ctl->error, 1u);
                     break;
                 }
             }
@@ -1924,7 +1956,7 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         if (lane == 0) {
             cstore(&A.fit[i], st ? DBL_MAX : combine_parts(f4, w4));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the fitness is at the coherence point before it is counted
-            old = __hip_atomic_fetch_add(&arrive[(size_t)c * PAIS_ARRIVE_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __hip_atomic_fetch_add(&arrive[(size_t)c * PAIS_ARRIVE_STRIDE], 1, __ATOMIC_RELAXED, PAIS_RING_SCOPE);
         }
         old = __builtin_amdgcn_readfirstlane(old);
 #if PAIS_RING_PROFILE
@@ -1949,15 +1981,15 @@ __global__ PAIS_EVAL_BOUNDS(NS) void k_pso_ring(DevScene sc, pais_patch_result *
         wave_sync();
         if (__builtin_amdgcn_readfirstlane(cont)) {
             unsigned base = 0;
-            if (lane == 0) base = __hip_atomic_fetch_add(&ctl->tail, (unsigned)N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) base = __hip_atomic_fetch_add(&ctl->tail, (unsigned)N, __ATOMIC_RELAXED, PAIS_RING_SCOPE);
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             if (base + (unsigned)N > cap) { // cannot happen (a segment holds every task of its candidates); never write past it
-                if (lane == 0) __hip_atomic_store(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) rstore(&ctl->error, 2u);
                 break;
             }
-            if (lane < N) __hip_atomic_store(&ring[base + lane], ((unsigned)c << 8) | (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < N) rstore(&ring[base + lane], ((unsigned)c << 8) | (unsigned)lane);
         } else if (lane == 0) {
-            __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, PAIS_RING_SCOPE);
         }
         __builtin_amdgcn_s_setprio(0);
 #if PAIS_RING_PROFILE
