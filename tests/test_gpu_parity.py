@@ -1304,7 +1304,7 @@ def test_task_ring_pass_is_the_launch_per_iteration_pass(request, scene_name, mo
             cands.append(make_candidate(cen, list(r.normal[:]), [r.cam_idx[k] for k in range(r.num_cam)], 5000 + 11 * i + j, 1, normalS=list(r.normalS[:])))
 
     def run(env):
-        for k in ("PAIS_SPLIT_ABOVE", "PAIS_PSO_RING", "PAIS_RING_PER_CAM"):
+        for k in ("PAIS_SPLIT_ABOVE", "PAIS_PSO_RING", "PAIS_RING_PER_CAM", "PAIS_PRE_SETUP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1314,13 +1314,20 @@ def test_task_ring_pass_is_the_launch_per_iteration_pass(request, scene_name, mo
         c.close()
         return out, ks
 
-    ref, _ = run({})                                                       # small batch: k_pso_iter
+    ref, _ = run({})                                                       # small batch: k_pso_iter (every evaluation sets itself up)
     ring, ks = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "1", "PAIS_RING_PER_CAM": "0"})   # (no size threshold: this batch is small)
     assert ks.eval2_launches == 1 and ks.ring_launches == 1 and ks.ring_fallbacks == 0, (ks.eval2_launches, ks.ring_launches)
     assert ks.ring_evals == ks.eval2_evals > 0
     launches, ks2 = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "0"})
     assert ks2.eval2_launches > 10 and ks2.ring_launches == 0
     assert ring == launches == ref
+    # round 6: in both large-batch pipelines the swarm step writes the evaluations' set-up records (pais_pre.hpp: normal, early
+    # exits, homographies, corner test with the particles across the lanes); PAIS_PRE_SETUP=0 runs the kernels whose evaluation
+    # waves compute them -- the same records byte for byte
+    ring0, ks4 = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "1", "PAIS_RING_PER_CAM": "0", "PAIS_PRE_SETUP": "0"})
+    assert ks4.ring_launches == 1 and ks4.ring_fallbacks == 0
+    launches0, _ = run({"PAIS_SPLIT_ABOVE": "1", "PAIS_PSO_RING": "0", "PAIS_PRE_SETUP": "0"})
+    assert ring0 == launches0 == ref
     # a ring pass that does not complete (here: no patience at all -- the first wave that has to wait for an entry raises the
     # error word) is re-run through the per-iteration launches: the same records, and the re-run is counted
     for k in ("PAIS_RING_TIMEOUT_MS",):
