@@ -57,6 +57,8 @@ typedef struct pais_mvs_stats {
     int64_t exchange_retries;     /* sharded batches that took a SECOND exchange: some rank's one-launch PSO pass (k_pso_ring) did not
                                    * complete and its shard was refined again.  Correct, but never expected: bench.py --gpus N > 1
                                    * refuses to print a line when it happened */
+    int64_t rounds_enum_sharded;  /* rounds whose listing (skip test + claim of the units) was dealt to the ranks by (camera, tile) and
+                                   * merged with one all-gather of the unit states (PAIS_SHARD_ENUM=1; off by default) */
 } pais_mvs_stats;
 
 /* One entry per GPU batch of the last reconstruction (the seed batch first, then one per expansion round with

@@ -350,6 +350,15 @@ struct pais_mvs {
     std::vector<WorkItem> work;
     std::vector<unsigned char> workState;
     std::vector<std::vector<uint32_t>> workBucket;
+    // sharded enumeration (round 6, opt-in: PAIS_SHARD_ENUM=1): in a world of N ranks the skip test + claim of a
+    // round's units -- the cache-miss chains that are most of a large round's listing -- are dealt to the ranks by (camera, tile)
+    // exactly as the threaded walk deals them to threads; the unit states (one byte each) are exchanged with one small
+    // all-gather and merged; every rank then builds the same candidate list.  Rounds handled this way are not streamed.
+    int shardEnum = 0;
+    size_t shardEnumAbove = 2048;      // PAIS_SHARD_ENUM_ABOVE: units of a round from which the listing is sharded
+    std::vector<unsigned char> enumAll; // host: world x units
+    unsigned char *d_en = nullptr, *d_enAll = nullptr, *h_en = nullptr; // RCCL instance of the exchange (device + pinned host)
+    size_t enCap = 0;
     // streamed rounds (pais_mvs_expansion_patches on one GPU): the candidates of the first part of a round's work list are on
     // the GPU (this context) while the host enumerates the rest (-> lane1), and the first part's records are committed while
     // the second part is still being refined.  Same work list, same commit order: same result.
@@ -416,6 +425,7 @@ struct pais_mvs {
                 if (b.done) (void)hipEventDestroy(b.done);
             }
             (void)hipFree(d_hs); (void)hipFree(d_hsAll); (void)hipHostFree(h_hs);
+            (void)hipFree(d_en); (void)hipFree(d_enAll); (void)hipHostFree(h_en);
         }
         if (ctx) pais_ctx_destroy(ctx);
     }
@@ -850,6 +860,8 @@ extern "C" int pais_mvs_create(const pais_config *cfg, int num_cams, const pais_
         if (const char *e = getenv("PAIS_ENUM_THREADS")) m->enumThreads = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("PAIS_ENUM_ABOVE")) m->enumThreadsAbove = (size_t)std::max(0, atoi(e));
     }
+    if (const char *e = getenv("PAIS_SHARD_ENUM")) m->shardEnum = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("PAIS_SHARD_ENUM_ABOVE")) m->shardEnumAbove = (size_t)std::max(0, atoi(e));
     if (const char *e = getenv("PAIS_STREAM_ROUNDS")) m->streamRounds = atoi(e);
     if (const char *e = getenv("PAIS_STREAM_ABOVE")) m->streamAbove = (size_t)std::max(0, atoi(e));
     if (const char *e = getenv("PAIS_STREAM_HOST_MS")) m->streamHostMs = atof(e);
@@ -1615,6 +1627,51 @@ extern "C" int pais_mvs_expansion_begin(pais_mvs *m)
 //   3. (caller) the claimed units are refined in ONE GPU batch -- a superset of what the sequential
 //      order evaluates, because insertions can only turn a candidate into a skip;
 //   4. round_commit replays the sequential order with the skip test re-applied on the live state.
+// The exchange of a sharded listing: every rank holds the states (0 dropped or not mine, 1 deferred, 2 claimed) of the units
+// of ITS (camera, tile) buckets; afterwards every rank holds every unit's state (the maximum over the ranks: exactly one
+// rank owns a unit).  Host transport: the caller's all-gather; RCCL: up, ncclAllGather, down, one synchronisation.
+static int enum_exchange(pais_mvs *m, std::vector<unsigned char> &st)
+{
+    const size_t n = st.size(), W = (size_t)m->world;
+    if (n == 0) return 0;
+    const double t0 = now_ms();
+    const unsigned char *all = nullptr;
+    if (host_transport(m)) {
+        m->enumAll.resize(n * W);
+        if (all_gather_host(m, st.data(), m->enumAll.data(), n)) return -3;
+        all = m->enumAll.data();
+    } else {
+        if (!m->nccl) return mfail("sharded enumeration: no communicator");
+        hipStream_t xs = (hipStream_t)pais_ctx_stream(m->ctx);
+        std::string err;
+        rccl::Api *a = rccl::api(err);
+        if (!a) return mfail(err.c_str());
+        if (n > m->enCap) {
+            MHIP(hipStreamSynchronize(xs));
+            (void)hipFree(m->d_en); (void)hipFree(m->d_enAll); (void)hipHostFree(m->h_en);
+            m->d_en = m->d_enAll = m->h_en = nullptr;
+            m->enCap = n + n / 2 + 4096; // (grows for the same rounds on every rank: the unit count is replicated state)
+            MHIP(hipMalloc((void **)&m->d_en, m->enCap));
+            MHIP(hipMalloc((void **)&m->d_enAll, m->enCap * W));
+            MHIP(hipHostMalloc((void **)&m->h_en, m->enCap * (W + 1), hipHostMallocDefault));
+        }
+        memcpy(m->h_en, st.data(), n);
+        MHIP(hipMemcpyAsync(m->d_en, m->h_en, n, hipMemcpyHostToDevice, xs));
+        const int nr = a->allGather(m->d_en, m->d_enAll, n, rccl::kInt8, m->nccl, xs);
+        if (nr != 0) { g_mvs_err = std::string("ncclAllGather (unit states): ") + (a->errorString ? a->errorString(nr) : "error"); return -3; }
+        MHIP(hipMemcpyAsync(m->h_en + m->enCap, m->d_enAll, n * W, hipMemcpyDeviceToHost, xs));
+        MHIP(hipStreamSynchronize(xs));
+        all = m->h_en + m->enCap;
+    }
+    for (size_t r = 0; r < W; ++r) {
+        const unsigned char *blk = all + r * n;
+        for (size_t k = 0; k < n; ++k) st[k] = std::max(st[k], blk[k]);
+    }
+    m->st.exchange_ms += now_ms() - t0;
+    m->st.exchange_bytes += (int64_t)(n * W);
+    return 0;
+}
+
 extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **cands, int *n)
 {
     if (!m || !cands || !n) return mfail("pais_mvs_round_begin: bad argument");
@@ -1665,6 +1722,105 @@ extern "C" int pais_mvs_round_begin(pais_mvs *m, int B, const pais_candidate **c
     // thread runs the skip test and the claim for its units (the cell maps, the pool and the dense patch copies are only
     // read; a claim stamp belongs to its tile's thread); (3) one thread walks the states in order and builds the candidates.
     // Same candidates, same order, same deferred list as the single-thread walk below (tests/test_scheduler_cpu.py runs both).
+    // Sharded listing (opt-in): the same three phases as the threaded walk below, with the world's ranks in the place of the
+    // threads -- (1) every rank lists every unit in order, (2) rank r runs the skip test and the claim for the units of ITS
+    // (camera, tile) buckets, the states are exchanged, (3) every rank builds the candidates of the claimed units in order.
+    // Same candidates, same order, same deferred list as the single-rank walk (tests/test_distributed_cpu.py).
+    if (m->shardEnum && m->world > 1 && !m->onFirstPart && (host_transport(m) || m->nccl || m->emuMode == 2) &&
+        m->deferred.size() + 4 * m->active.size() >= m->shardEnumAbove) {
+        const uint32_t W = (uint32_t)m->world;
+        m->partEnd.clear();
+        m->work.clear();
+        m->workBucket.resize((size_t)W);
+        for (auto &b : m->workBucket) b.clear();
+        auto addUnit = [&](const Unit &u, int camI, int x, int y) {
+            CellMap &map = m->cellMaps[camI];
+            if (!map.inMap(x, y)) return;
+            (void)map.slot(x, y); // (the tile exists on every rank alike, whoever owns the unit)
+            const uint32_t key = (uint32_t)camI * 0x9E3779B1u + (uint32_t)(y >> CellMap::kShift) * 0x85EBCA6Bu + (uint32_t)(x >> CellMap::kShift) * 0xC2B2AE35u;
+            m->workBucket[(key >> 8) % W].push_back((uint32_t)m->work.size());
+            m->work.push_back(WorkItem{u, camI, x, y});
+        };
+        for (const Unit &u : m->deferred) {
+            const pais_patch_result &pr = m->patches[u.id]->r;
+            addUnit(u, pr.cam_idx[u.slot], (int)(pr.imgPoint[u.slot][0] / m->cfg.cellSize) + dx[u.j], (int)(pr.imgPoint[u.slot][1] / m->cfg.cellSize) + dy[u.j]);
+        }
+        const size_t nA = m->active.size();
+        for (size_t k = 0; k < nA; ++k) {
+            if (k + 16 < nA) {
+                const pais_patch_result &q = m->patches[m->active[k + 16].id]->r;
+                __builtin_prefetch(&q.imgPoint[m->active[k + 16].slot][0]);
+                __builtin_prefetch(&q.cam_idx[m->active[k + 16].slot]);
+            }
+            Active &a = m->active[k];
+            const pais_patch_result &pr = m->patches[a.id]->r;
+            const int sEnd = thin ? pr.num_cam : a.slot + 1;
+            for (int sl = a.slot; sl < sEnd; ++sl) {
+                const int cx = (int)(pr.imgPoint[sl][0] / m->cfg.cellSize), cy = (int)(pr.imgPoint[sl][1] / m->cfg.cellSize);
+                for (int j = 0; j < 4; ++j) addUnit(Unit{a.id, sl, j}, pr.cam_idx[sl], cx + dx[j], cy + dy[j]);
+            }
+            a.slot = sEnd - 1; // round_commit advances past it
+        }
+        m->workState.assign(m->work.size(), 0);
+        const int round = m->curRound;
+        auto runBucket = [&](uint32_t w) {
+            const std::vector<uint32_t> &mine = m->workBucket[(size_t)w];
+            const size_t nMine = mine.size();
+            for (size_t q = 0; q < nMine; ++q) {
+                if (q + 8 < nMine) { // the tile row of the unit 8 ahead, the first pool entry of the unit 4 ahead
+                    const WorkItem &f = m->work[mine[q + 8]];
+                    m->cellMaps[f.cam].prefetch(f.x, f.y);
+                    const WorkItem &g = m->work[mine[q + 4]];
+                    const int e = m->cellMaps[g.cam].first(g.x, g.y);
+                    if (e >= 0) __builtin_prefetch(&m->pool[e]);
+                }
+                const WorkItem &it = m->work[mine[q]];
+                const pais_patch_result &pr = m->patches[it.u.id]->r;
+                CellMap &map = m->cellMaps[it.cam];
+                if (m->skipNeighborCell(map, it.x, it.y, pr, round)) continue;                  // state 0: dropped
+                m->workState[mine[q]] = map.claim(it.x, it.y, round) ? 2 : 1;                   // 2 claimed, 1 deferred
+            }
+        };
+        runBucket((uint32_t)m->rank);
+        if (m->emuMode == 2) {
+            // one-GPU emulation: there are no peers -- their buckets are walked here, off the emulated rank's clock (emu_replay_ms),
+            // and the exchange is charged with the modelled latency of a collective
+            const double tE = now_ms();
+            for (uint32_t w = 0; w < W; ++w)
+                if (w != (uint32_t)m->rank) runBucket(w);
+            m->st.emu_replay_ms += now_ms() - tE;
+            if (m->emuLatencyUs > 0) {
+                const double t1 = now_ms() + m->emuLatencyUs * 1e-3;
+                while (now_ms() < t1) {}
+                m->st.exchange_ms += m->emuLatencyUs * 1e-3;
+            }
+        } else if (enum_exchange(m, m->workState)) {
+            return -2;
+        }
+        m->st.rounds_enum_sharded++;
+        for (size_t k = 0; k < m->work.size(); ++k) {
+            const WorkItem &it = m->work[k];
+            if (m->workState[k] == 1) { m->nextDeferred.push_back(it.u); continue; }
+            if (m->workState[k] != 2) continue;
+            const pais_patch_result &pr = m->patches[it.u.id]->r;
+            double center[3];
+            m->expansionCenter(it.cam, pr, it.x, it.y, center);
+            pais_candidate rec;
+            m->makeExpandCandidate(m->patches[it.u.id], center, pais_child_key(pr.key, it.cam, it.x, it.y), &rec);
+            m->cands.push_back(Candidate{it.u, it.cam, it.x, it.y});
+            m->candRecs.push_back(rec);
+        }
+        if (m->truncatedVisible > 0) {
+            m->truncatedVisible = 0;
+            return mfail("a candidate's visibility cone holds more than PAIS_MAX_VIS cameras (patch.cpp:723-761 keeps them all): "
+                         "this rig needs a larger PAIS_MAX_VIS or a larger visibleCorrelation");
+        }
+        *cands = m->candRecs.data();
+        *n = (int)m->candRecs.size();
+        m->lastEnumerateMs = now_ms() - t0;
+        m->st.host_enumerate_ms += m->lastEnumerateMs;
+        return 0;
+    }
     if (m->enumThreads > 1 && m->deferred.size() + 4 * m->active.size() >= m->enumThreadsAbove) {
         if (!m->enumPool) m->enumPool = new EnumPool(m->enumThreads - 1);
         const int T = m->enumPool->workers();

@@ -20,7 +20,7 @@ class MvsStats(C.Structure):
                 ("host_enumerate_ms", C.c_double), ("host_commit_ms", C.c_double), ("gpu_refine_ms", C.c_double),
                 ("batches_sharded", C.c_int64), ("batches_replicated", C.c_int64), ("exchange_ms", C.c_double),
                 ("exchange_bytes", C.c_int64), ("rounds_streamed", C.c_int64), ("emu_replay_ms", C.c_double),
-                ("exchange_retries", C.c_int64)]
+                ("exchange_retries", C.c_int64), ("rounds_enum_sharded", C.c_int64)]
 
 
 class RoundLog(C.Structure):

@@ -18,10 +18,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q, replicate_below, fail_rank=-1, inject=None):
+def _worker(rank, world, port, q, replicate_below, fail_rank=-1, inject=None, shard_enum=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"] = str(rank); os.environ["WORLD_SIZE"] = str(world)
+    if shard_enum:   # (read when the driver is created: the listing of every round with a unit is dealt to the ranks)
+        os.environ["PAIS_SHARD_ENUM"] = "1"; os.environ["PAIS_SHARD_ENUM_ABOVE"] = "0"
     from pais_mvs_amd import synth, _lib
     from pais_mvs_amd.config import readme_config
     from pais_mvs_amd.mvs import MVS
@@ -58,17 +60,18 @@ def _worker(rank, world, port, q, replicate_below, fail_rank=-1, inject=None):
         return
     cloud = m.cloud()
     st = m.stats()
-    q.put((rank, cloud.tobytes(), cloud.shape, int(st.candidates_effective), int(st.batches_sharded), int(st.batches_replicated),
-           calls["cands"], int(st.exchange_bytes), [l.n for l in m.round_log()]))
+    out = (rank, cloud.tobytes(), cloud.shape, int(st.candidates_effective), int(st.batches_sharded), int(st.batches_replicated),
+           calls["cands"], int(st.exchange_bytes), [l.n for l in m.round_log()])
+    q.put(out + ((int(st.rounds_enum_sharded), int(st.rounds)),) if shard_enum else out)
     job.close()
 
 
-def _run(world, replicate_below, fail_rank=-1, inject=None):
+def _run(world, replicate_below, fail_rank=-1, inject=None, shard_enum=False):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     port = _free_port()
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q, replicate_below, fail_rank, inject)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, replicate_below, fail_rank, inject, shard_enum)) for r in range(world)]
     for p in ps:
         p.start()
     got = [q.get(timeout=600) for _ in range(world)]
@@ -112,6 +115,21 @@ def test_many_ranks_with_ragged_and_empty_shards(world):
     if world == 8:
         assert any(p * (world - 1) >= n for n, p in zip(ns, per)), ns   # some batch left a rank without a candidate
     assert sum(g[6] for g in got) == ref[6]                   # disjoint shards: together exactly one replica's work
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_enumeration_gives_the_single_rank_cloud(world):
+    """Round 6 (opt-in PAIS_SHARD_ENUM=1): the skip test + claim of a round's units dealt to the ranks by
+    (camera, tile), the unit states merged with one all-gather per round, every rank building the same candidate list --
+    same cloud, same candidates per round as one rank; sharded and replicated batches both occur behind it."""
+    ref = _run(1, 1024)[0]
+    got = _run(world, 72, shard_enum=True)
+    assert len(got) == world
+    for g in got:
+        rank, blob, shape, eff, sharded, replicated, cands, xbytes, ns, (enum_rounds, rounds) = g
+        assert shape == ref[2] and blob == ref[1] and eff == ref[3], rank
+        assert ns == ref[8], rank                      # the same candidates in every round
+        assert enum_rounds > 0 and enum_rounds <= rounds and sharded > 0, (enum_rounds, rounds, sharded)
 
 
 def test_a_failing_rank_fails_every_rank_together():
